@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""
+Generate the golden vectors under tests/golden/ by importing the REAL reference
+(/root/reference, read-only) on CPU.  Runs only in the authoring container — the
+reference never travels to the GPU box; only the .npz data files produced here do.
+
+    python tests/golden/make_fixtures.py
+
+What is imported from the reference: models.build.VQ_model and the modules it pulls in
+(Swin_3D, CNN_3D encoder, LFQ, classifier CNN_3D) plus models.losses.  `timm` is absent
+from this image; the two symbols the path uses (DropPath, trunc_normal_) are provided by
+an in-memory stub.  Parameters are re-randomised after construction
+(seeded) so that every bias / table / affine term is exercised — parity is by
+state_dict, so the reference's own init RNG is irrelevant.
+
+Each fixture is inputs + expected outputs (+ gradients / post-Adam parameters): data
+only, no reference source.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+def _install_timm_stub():
+    timm = types.ModuleType("timm")
+    tm = types.ModuleType("timm.models")
+    tl = types.ModuleType("timm.models.layers")
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            if self.p == 0.0 or not self.training:
+                return x
+            keep = 1 - self.p
+            m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            return x * m / keep
+
+    tl.DropPath = DropPath
+    tl.trunc_normal_ = nn.init.trunc_normal_
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl})
+
+
+_install_timm_stub()
+sys.path.insert(0, "/root/reference")
+import config as ref_config  # noqa: E402
+from models.build import VQ_model  # noqa: E402
+from models import losses as ref_losses  # noqa: E402
+from models.encoder import Swin_3D as ref_swin  # noqa: E402
+from models.encoder import CNN_3D as ref_cnn  # noqa: E402
+from models.codebook.LFQ import LFQ as RefLFQ  # noqa: E402
+from models.classifier.CNN_3D import CNN_3D as RefCls  # noqa: E402
+
+
+def ref_cfg(**kw):
+    cfg = ref_config.add_all_arguments(argparse.ArgumentParser()).parse_args([])
+    cfg.encoder = "Swin_3D"
+    cfg.in_channels = 1
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def rerandomise(module, seed):
+    """Seeded, well-scaled values for every parameter (weights ~ 1/sqrt(fan_in), biases 0.1,
+    rel-pos tables 0.5, LN affine 1 +- 0.1)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if "relative_position_bias_table" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+            elif "norm" in name and name.endswith("weight"):
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+            elif p.ndim >= 2:
+                fan_in = int(np.prod(p.shape[1:]))
+                p.copy_(torch.randn(p.shape, generator=g) * (0.7 / np.sqrt(fan_in)))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+
+
+def sd_arrays(module, prefix="sd/"):
+    return {prefix + k: v.detach().cpu().clone().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"{name}.npz  {os.path.getsize(path) / 1e6:.2f} MB  ({len(arrs)} arrays)")
+
+
+def rand(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ----------------------------------------------------------------------------
+# module-level fixtures
+# ----------------------------------------------------------------------------
+
+
+def fx_swin_block(tag, window, shift, D, H, W, C=16, heads=2, B=2, seed=0):
+    blk = ref_swin.SwinTransformerBlock3D(C, heads, window_size=window, shift_size=shift, qkv_bias=True)
+    rerandomise(blk, seed)
+    x = rand((B, D, H, W, C), seed + 1).requires_grad_()
+    ws, ss = ref_swin.get_window_size((D, H, W), window, shift)
+    Dp, Hp, Wp = (int(np.ceil(a / b)) * b for a, b in zip((D, H, W), ws))
+    mask = ref_swin.compute_mask(Dp, Hp, Wp, ws, ss, x.device)
+    y = blk(x, mask)
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x.detach(), y=y.detach(), r=r, dx=x.grad, window=np.array(window), shift=np.array(shift),
+               heads=np.array(heads), mask=mask)
+    out.update(sd_arrays(blk))
+    out.update({"grad/" + k: p.grad for k, p in blk.named_parameters()})
+    save("swin_block_" + tag, **out)
+
+
+def fx_patch_embed(tag, cls, cin, seed):
+    pe = cls(patch_size=(1, 1, 1), in_chans=cin, embed_dim=16, norm_layer=nn.LayerNorm)
+    rerandomise(pe, seed)
+    x = rand((2, cin, 8, 6, 10), seed + 1)
+    y = pe(x)
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x, y=y.detach(), r=r)
+    out.update(sd_arrays(pe))
+    out.update({"grad/" + k: p.grad for k, p in pe.named_parameters()})
+    save("patch_embed_" + tag, **out)
+
+
+def fx_conv_block(tag, cin, cout, seed):
+    cb = ref_cnn.conv_block(cin, cout, (3, 3, 3), 0.0, 0.0)
+    rerandomise(cb, seed)
+    x = rand((2, cin, 8, 6, 10), seed + 1).requires_grad_()
+    y = cb(x)
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x.detach(), y=y.detach(), r=r, dx=x.grad)
+    out.update(sd_arrays(cb))
+    out.update({"grad/" + k: p.grad for k, p in cb.named_parameters()})
+    save("conv_block_" + tag, **out)
+
+
+def fx_proj_var(seed):
+    enc = ref_swin.Swin_3D(in_vars=1)
+    pv = enc.proj_var[0]
+    rerandomise(pv, seed)
+    x = rand((2, 16, 8, 6, 10), seed + 1).requires_grad_()
+    y = pv(x)
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x.detach(), y=y.detach(), r=r, dx=x.grad)
+    out.update(sd_arrays(pv))
+    out.update({"grad/" + k: p.grad for k, p in pv.named_parameters()})
+    save("proj_var", **out)
+
+
+def fx_lfq(tag, K, training, seed):
+    q = RefLFQ(dim=16, codebook_size=K, entropy_loss_weight=0.1, diversity_gamma=0.1, commitment_loss_weight=3.0)
+    rerandomise(q, seed)
+    q.train(training)
+    x = rand((2, 300, 16), seed + 1)
+    x[0, :7] = 0.0           # exact-zero tokens
+    with torch.no_grad():    # make s == 0 exactly reachable: zero bias on the first code dim
+        q.project_in.bias[0] = 0.0
+    x.requires_grad_()
+    zq, idx, aux = q(x)
+    r = rand(zq.shape, seed + 2)
+    out = dict(x=x.detach(), z_q=zq.detach(), indices=idx, aux=aux.detach(), r=r, K=np.array(K),
+               training=np.array(int(training)), code0=q.indices_to_codes(torch.tensor([0])).detach())
+    if training:
+        ((zq * r).sum() + 2.5 * aux).backward()
+        out["dx"] = x.grad
+        out.update({"grad/" + k: p.grad for k, p in q.named_parameters()})
+    out.update(sd_arrays(q))
+    save("lfq_" + tag, **out)
+
+
+def fx_classifier(seed, V=2):
+    c = RefCls(in_var=V, embed_dim=16, dim=16, drop_rate=0.0)
+    rerandomise(c, seed)
+    x = rand((2, V, 16, 8, 6, 10), seed + 1).requires_grad_()
+    z, y = c(x)
+    rz = rand(z.shape, seed + 2)
+    ry = rand((V,) + tuple(y[0].shape), seed + 3)
+    ((z * rz).sum() + sum((y[v] * ry[v]).sum() for v in range(V))).backward()
+    out = dict(x=x.detach(), z=z.detach(), y=torch.stack([t.detach() for t in y]), rz=rz, ry=ry, dx=x.grad)
+    out.update(sd_arrays(c))
+    out.update({"grad/" + k: p.grad for k, p in c.named_parameters()})
+    save("classifier_v%d" % V, **out)
+
+
+def fx_losses(seed):
+    g = torch.Generator().manual_seed(seed)
+    N, V, C, T, H, W = 2, 3, 16, 8, 6, 10
+    out = {}
+    bce_s, bce_r = ref_losses.BCE_loss_synthetic(), ref_losses.BCE_loss()
+    an_s = ref_losses.Anomaly_L1_loss_synthetic(n_dynamic=V, delta_t=T, dim=C)
+    an_r = ref_losses.Anomaly_L1_loss(n_dynamic=V, delta_t=T, dim=C)
+    pred = torch.randn((N, 1, H, W), generator=g).requires_grad_()
+    for tag, tgt in (("mixed", (torch.rand((N, 1, H, W), generator=g) < 0.3).float()),
+                     ("zeros", torch.zeros(N, 1, H, W)), ("ones", torch.ones(N, 1, H, W))):
+        pred.grad = None
+        l = bce_s(pred, tgt)
+        l.backward()
+        out.update({f"bce_s/{tag}/target": tgt, f"bce_s/{tag}/loss": l.detach(), f"bce_s/{tag}/dpred": pred.grad.clone()})
+    out["bce_s/pred"] = pred.detach()
+    # real-data BCE (pred (N,H,W), target (N,H,W), mask_valid (N,H,W))
+    p3 = torch.randn((N, H, W), generator=g).requires_grad_()
+    tgt3 = (torch.rand((N, H, W), generator=g) < 0.3).float()
+    mv = (torch.rand((N, H, W), generator=g) < 0.8).float()
+    l = bce_r(p3, tgt3, mv)
+    l.backward()
+    out.update({"bce_r/pred": p3.detach(), "bce_r/target": tgt3, "bce_r/mask_valid": mv, "bce_r/loss": l.detach(),
+                "bce_r/dpred": p3.grad})
+    # anomaly losses
+    zq = torch.randn((N, V, C, T, H, W), generator=g).requires_grad_()
+    vq0 = torch.randn((1, C), generator=g)
+    me = (torch.rand((N, H, W), generator=g) < 0.2).float()
+    l = an_s(zq, me, vq0.clone())
+    l.backward()
+    out.update({"an_s/z_q": zq.detach(), "an_s/vq0": vq0, "an_s/mask": me, "an_s/loss": l.detach(), "an_s/dz_q": zq.grad.clone()})
+    l1 = an_s(zq.detach(), torch.ones(N, H, W), vq0.clone())
+    out["an_s/all_extreme_loss"] = l1.detach()       # 0/0 -> nan in the reference
+    zq.grad = None
+    mvalid = (torch.rand((N, T, H, W), generator=g) < 0.1).float()   # "mask_valid" of Anomaly_L1_loss: (N,T,H,W)
+    l = an_r(zq, me, mvalid, vq0.clone())
+    l.backward()
+    out.update({"an_r/mask_valid": mvalid, "an_r/loss": l.detach(), "an_r/dz_q": zq.grad.clone()})
+    save("losses", **out)
+
+
+# ----------------------------------------------------------------------------
+# end-to-end fixtures (train_synthetic.py:175-205 call sequence)
+# ----------------------------------------------------------------------------
+
+
+def fx_e2e(tag, cfg, N, T, H, W, seed, n_steps=3, with_grads=True):
+    torch.manual_seed(seed)
+    model = VQ_model(cfg)
+    rerandomise(model, seed)
+    model.train()
+    V, C = cfg.in_channels_dynamic, cfg.in_channels
+    g = torch.Generator().manual_seed(seed + 1)
+    x_d = torch.randn((N, V, C, T, H, W), generator=g).clamp_(-10, 10)
+    mask_extreme = (torch.rand((N, H, W), generator=g) < 0.3).float()
+    mask_loss = (torch.rand((N, H, W), generator=g) < 0.4).float()
+    out = dict(x_d=x_d, mask_extreme=mask_extreme, mask_extreme_loss=mask_loss,
+               cfg_V=np.array(V), cfg_C=np.array(C), encoder=np.array(cfg.encoder))
+    out.update(sd_arrays(model))
+    crit = ref_losses.BCE_loss_synthetic()
+    crit_an = ref_losses.Anomaly_L1_loss_synthetic(n_dynamic=V, delta_t=cfg.delta_t, dim=cfg.en_embed_dim[-1])
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay, betas=(cfg.beta1, cfg.beta2))
+
+    # eval-mode forward
+    model.eval()
+    with torch.no_grad():
+        z, y, an, zq, lz = model(x_d)
+    out.update({"eval/z": z, "eval/y": torch.stack(y), "eval/anomaly": an, "eval/z_q": zq, "eval/loss_z_q": lz})
+    model.train()
+
+    losses = []
+    for step in range(n_steps if with_grads else 0):
+        opt.zero_grad(set_to_none=True)
+        pred, pred_y, anomaly, z_q, loss_z_q = model(x_d)
+        tgt = mask_extreme.unsqueeze(1)
+        l_ext = crit(pred, tgt)
+        l_an = crit_an(z_q, mask_loss, model.vq.indices_to_codes(torch.Tensor([0]).long()).clone().detach())
+        l_var = 0
+        for k in range(V):
+            l_var = l_var + crit(pred_y[k], tgt)
+        loss = l_ext + l_an * cfg.lambda_anomaly + l_var + loss_z_q
+        loss.backward()
+        if step == 0:
+            out.update({"train/z": pred.detach(), "train/y": torch.stack([t.detach() for t in pred_y]),
+                        "train/anomaly": anomaly, "train/z_q": z_q.detach(), "train/loss_z_q": loss_z_q.detach(),
+                        "train/l_ext": l_ext.detach(), "train/l_anom": l_an.detach(), "train/l_var": l_var.detach(),
+                        "train/loss": loss.detach()})
+            out.update({"grad/" + k: p.grad.clone() for k, p in model.named_parameters()})
+        opt.step()
+        losses.append(float(loss))
+    if with_grads:
+        out["train/loss_per_step"] = np.array(losses)
+        out.update(sd_arrays(model, prefix=f"sd_after{n_steps}/"))
+    save("e2e_" + tag, **out)
+
+
+def main():
+    fx_swin_block("w244_noshift", (2, 4, 4), (0, 0, 0), 8, 8, 12, seed=10)
+    fx_swin_block("w244_shift", (2, 4, 4), (1, 2, 2), 8, 8, 12, seed=20)
+    fx_swin_block("w244_shift_pad", (2, 4, 4), (1, 2, 2), 8, 6, 10, seed=30)      # pads to 8x12
+    fx_swin_block("w244_noshift_pad", (2, 4, 4), (0, 0, 0), 8, 7, 9, seed=35)
+    fx_swin_block("w811", (8, 1, 1), (4, 0, 0), 8, 6, 10, seed=40)                # shift clamped off (D == window)
+    fx_swin_block("w811_T16_shift", (8, 1, 1), (4, 0, 0), 16, 4, 6, seed=50)      # genuinely shifted temporal window
+    fx_swin_block("w244_c32", (2, 4, 4), (1, 2, 2), 8, 8, 8, C=32, heads=2, seed=60)
+    fx_patch_embed("swin_c1", ref_swin.PatchEmbed3D, 1, 100)
+    fx_patch_embed("swin_c2", ref_swin.PatchEmbed3D, 2, 110)
+    fx_patch_embed("cnn_c1", ref_cnn.PatchEmbed3D, 1, 120)
+    fx_conv_block("1_16", 1, 16, 130)
+    fx_conv_block("16_16", 16, 16, 140)
+    fx_proj_var(150)
+    fx_lfq("k2_train", 2, True, 200)
+    fx_lfq("k2_eval", 2, False, 210)
+    fx_lfq("k4_train", 4, True, 220)
+    fx_classifier(300, V=2)
+    fx_losses(400)
+    fx_e2e("swin_v2_14x18", ref_cfg(in_channels_dynamic=2), N=2, T=8, H=14, W=18, seed=500)
+    fx_e2e("cnn_v2_12x16", ref_cfg(in_channels_dynamic=2, encoder="CNN_3D"), N=2, T=8, H=12, W=16, seed=600)
+    fx_e2e("swin_v6_8x8_c2", ref_cfg(in_channels=2), N=1, T=8, H=8, W=8, seed=700, with_grads=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""Pin oracle/idee_oracle.py (the CPU restatement) to the golden vectors generated from the real
+reference (tests/golden/make_fixtures.py).  CPU only."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import idee_oracle as O
+
+ATOL, RTOL = 1e-5, 1e-4
+
+
+def close(a, b, atol=ATOL, rtol=RTOL):
+    torch.testing.assert_close(a.float(), b.float(), atol=atol, rtol=rtol, equal_nan=True)
+
+
+def leaf(sd):
+    return {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def check_grads(sd, grads, atol=1e-5, rtol=1e-3):
+    for k, g in grads.items():
+        assert sd[k].grad is not None, k
+        close(sd[k].grad, g, atol, rtol)
+
+
+@pytest.mark.parametrize("tag", ["w244_noshift", "w244_shift", "w244_shift_pad", "w244_noshift_pad", "w811",
+                                 "w811_T16_shift", "w244_c32"])
+def test_swin_block(tag):
+    a, sd, grads = load_golden("swin_block_" + tag)
+    sd = leaf(sd)
+    x = a["x"].clone().requires_grad_()
+    y = O.swin_block(x, sd, "", int(a["heads"]), tuple(a["window"].tolist()), tuple(a["shift"].tolist()))
+    close(y, a["y"])
+    (y * a["r"]).sum().backward()
+    close(x.grad, a["dx"], 1e-5, 1e-3)
+    check_grads(sd, grads)
+
+
+def test_mask_closed_form():
+    a, _, _ = load_golden("swin_block_w244_shift_pad")
+    m = O.compute_mask(8, 8, 12, (2, 4, 4), (1, 2, 2))
+    assert torch.equal(m, a["mask"])
+    a, _, _ = load_golden("swin_block_w811_T16_shift")
+    assert torch.equal(O.compute_mask(16, 4, 6, (8, 1, 1), (4, 0, 0)), a["mask"])
+
+
+@pytest.mark.parametrize("tag", ["swin_c1", "swin_c2", "cnn_c1"])
+def test_patch_embed(tag):
+    a, sd, grads = load_golden("patch_embed_" + tag)
+    sd = leaf(sd)
+    y = O.patch_embed(a["x"], sd, "")
+    close(y, a["y"])
+    (y * a["r"]).sum().backward()
+    check_grads(sd, grads)
+
+
+@pytest.mark.parametrize("tag,cin", [("1_16", 1), ("16_16", 16)])
+def test_conv_block(tag, cin):
+    a, sd, grads = load_golden("conv_block_" + tag)
+    sd = leaf(sd)
+    x = a["x"].clone().requires_grad_()
+    y = O.conv_block(x, sd, "", cin, 16)
+    close(y, a["y"])
+    (y * a["r"]).sum().backward()
+    close(x.grad, a["dx"], 1e-5, 1e-3)
+    check_grads(sd, grads)
+
+
+def test_proj_var():
+    a, sd, grads = load_golden("proj_var")
+    sd = leaf(sd)
+    x = a["x"].clone().requires_grad_()
+    y = O.proj_var(x, sd, "")
+    close(y, a["y"])
+    (y * a["r"]).sum().backward()
+    close(x.grad, a["dx"], 1e-5, 1e-3)
+    check_grads(sd, grads)
+
+
+@pytest.mark.parametrize("tag", ["k2_train", "k2_eval", "k4_train"])
+def test_lfq(tag):
+    a, sd, grads = load_golden("lfq_" + tag)
+    sd = leaf(sd)
+    cfg = O.default_cfg(codebook_size=int(a["K"]))
+    training = bool(int(a["training"]))
+    x = a["x"].clone().requires_grad_()
+    zq, idx, aux = O.lfq(x, sd, cfg, training, pre="")
+    close(zq, a["z_q"])
+    assert torch.equal(idx, a["indices"].long())
+    close(aux, a["aux"])
+    close(O.lfq_indices_to_codes(torch.tensor([0]), sd, cfg, pre=""), a["code0"])
+    if training:
+        ((zq * a["r"]).sum() + 2.5 * aux).backward()
+        close(x.grad, a["dx"], 1e-5, 1e-3)
+        check_grads(sd, grads)
+
+
+def test_classifier():
+    a, sd, grads = load_golden("classifier_v2")
+    sd = leaf(sd)
+    x = a["x"].clone().requires_grad_()
+    z, y = O.classifier(x, sd, pre="")
+    close(z, a["z"])
+    close(torch.stack(y), a["y"])
+    ((z * a["rz"]).sum() + sum((y[v] * a["ry"][v]).sum() for v in range(len(y)))).backward()
+    close(x.grad, a["dx"], 1e-5, 1e-3)
+    check_grads(sd, grads)
+
+
+def test_losses():
+    a, _, _ = load_golden("losses")
+    for tag in ("mixed", "zeros", "ones"):
+        p = a["bce_s/pred"].clone().requires_grad_()
+        l = O.bce_loss_synthetic(p, a[f"bce_s/{tag}/target"])
+        close(l, a[f"bce_s/{tag}/loss"])
+        l.backward()
+        close(p.grad, a[f"bce_s/{tag}/dpred"])
+    p = a["bce_r/pred"].clone().requires_grad_()
+    l = O.bce_loss(p, a["bce_r/target"], a["bce_r/mask_valid"])
+    close(l, a["bce_r/loss"])
+    l.backward()
+    close(p.grad, a["bce_r/dpred"])
+    zq = a["an_s/z_q"].clone().requires_grad_()
+    l = O.anomaly_l1_synthetic(zq, a["an_s/mask"], a["an_s/vq0"])
+    close(l, a["an_s/loss"])
+    l.backward()
+    close(zq.grad, a["an_s/dz_q"])
+    assert math.isnan(float(a["an_s/all_extreme_loss"]))
+    assert math.isnan(float(O.anomaly_l1_synthetic(zq.detach(), torch.ones_like(a["an_s/mask"]), a["an_s/vq0"])))
+    zq.grad = None
+    l = O.anomaly_l1(zq, a["an_s/mask"], a["an_r/mask_valid"], a["an_s/vq0"])
+    close(l, a["an_r/loss"])
+    l.backward()
+    close(zq.grad, a["an_r/dz_q"])
+
+
+def _cfg_from(a):
+    return O.default_cfg(in_channels_dynamic=int(a["cfg_V"]), in_channels=int(a["cfg_C"]), encoder=str(a["encoder"]))
+
+
+@pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16", "swin_v6_8x8_c2"])
+def test_e2e_forward(tag):
+    a, sd, _ = load_golden("e2e_" + tag)
+    cfg = _cfg_from(a)
+    with torch.no_grad():
+        z, y, an, zq, lz = O.vq_model_forward(a["x_d"], sd, cfg, training=False)
+    close(z, a["eval/z"])
+    close(torch.stack(y), a["eval/y"])
+    assert torch.equal(an, a["eval/anomaly"].long())
+    close(zq, a["eval/z_q"])
+    close(lz, a["eval/loss_z_q"])
+
+
+@pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16"])
+def test_e2e_train_steps(tag):
+    a, sd, grads = load_golden("e2e_" + tag)
+    cfg = _cfg_from(a)
+    sd = leaf(sd)
+    names = [k for k in grads]
+    state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
+    losses = []
+    for step in range(1, 4):
+        outs = O.vq_model_forward(a["x_d"], sd, cfg, training=True)
+        total, parts = O.train_losses_synthetic(outs, a["mask_extreme"], a["mask_extreme_loss"], sd, cfg)
+        for k in names:
+            sd[k].grad = None
+        total.backward()
+        if step == 1:
+            close(outs[0], a["train/z"])
+            close(torch.stack(outs[1]), a["train/y"])
+            assert torch.equal(outs[2], a["train/anomaly"].long())
+            close(outs[3], a["train/z_q"])
+            close(outs[4], a["train/loss_z_q"])
+            close(parts["extreme"], a["train/l_ext"])
+            close(parts["anomaly"], a["train/l_anom"])
+            close(parts["var"], a["train/l_var"])
+            close(total.reshape(()), a["train/loss"].reshape(()))
+            check_grads(sd, grads, atol=2e-5, rtol=1e-3)
+        losses.append(float(total))
+        with torch.no_grad():
+            for k in names:
+                p, m, v = O.adam_step(sd[k].detach(), sd[k].grad, state[k][0], state[k][1], step, cfg.lr, cfg.beta1,
+                                      cfg.beta2, 1e-8, cfg.weight_decay)
+                state[k] = (m, v)
+                sd[k] = p.requires_grad_()
+    torch.testing.assert_close(torch.tensor(losses, dtype=torch.float64), a["train/loss_per_step"].double(),
+                               rtol=1e-3, atol=1e-4)
+    for k in names:
+        close(sd[k].detach(), a["sd_after3/" + k], atol=5e-5, rtol=1e-3)
