@@ -1,0 +1,125 @@
+"""ctypes binding of libidee_hip.so (the C-ABI declared in include/idee_hip.h).
+
+The product path has no fallback: if the library is missing, cannot be loaded, or a call
+returns non-zero, this module raises.  Nothing here imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libidee_hip.so")
+
+c_float_p = C.c_void_p  # raw device pointers travel as void*
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class SwinGeom(C.Structure):
+    _fields_ = [(n, _I) for n in ("N", "V", "D", "H", "W", "C", "heads", "hidden", "wd", "wh", "ww", "sd", "sh", "sw")] + [
+        ("scale", _F)]
+
+
+class SwinParams(C.Structure):
+    _fields_ = [(n, _P) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "rel_bias")]
+
+
+class SwinGrads(C.Structure):
+    _fields_ = SwinParams._fields_
+
+
+class ConvDesc(C.Structure):
+    _fields_ = ([("mode", _I), ("B", _I), ("wsets", _I), ("T", _I), ("H", _I), ("W", _I), ("Cin", _I), ("Cout", _I)]
+                + [(n, _L) for n in ("x_sB", "x_sT", "x_sH", "x_sW", "x_sG", "y_sB", "y_sT", "y_sH", "y_sW", "y_sG")]
+                + [("relu", _I)])
+
+
+CONV_K333_REPLICATE, CONV_K233_S2_ZERO = 0, 1
+
+# name -> (restype, argtypes); every symbol include/idee_hip.h declares
+_SIGS = {
+    "idee_version": (C.c_char_p, []),
+    "idee_last_error": (C.c_char_p, []),
+    "idee_check_device": (_I, [_I]),
+    "idee_patch_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "idee_patch_embed_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "idee_swin_block_fwd": (_I, [_P, _P, C.POINTER(SwinParams), C.POINTER(SwinGeom), _P]),
+    "idee_swin_block_bwd": (_I, [_P, _P, _P, C.POINTER(SwinParams), C.POINTER(SwinGrads), C.POINTER(SwinGeom), _P]),
+    "idee_relpos_bias_gather": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "idee_relpos_bias_scatter": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "idee_conv_packed_floats": (_L, [C.POINTER(ConvDesc)]),
+    "idee_conv_wgrad_floats": (_L, [C.POINTER(ConvDesc)]),
+    "idee_conv_pack_weights": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "idee_conv_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "idee_conv_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P]),
+    "idee_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "idee_conv_unpack_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P]),
+    "idee_lfq_workspace_floats": (_L, [_L, _I]),
+    "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P]),
+    "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _P]),
+    "idee_bce_class_counts": (_I, [_P, _P, _L, _P, _P]),
+    "idee_bce_workspace_floats": (_L, [_I, _L]),
+    "idee_bce_weighted_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P]),
+    "idee_bce_weighted_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P]),
+    "idee_anomaly_workspace_floats": (_L, [_L]),
+    "idee_anomaly_l1_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "idee_anomaly_l1_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "idee_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+class IdeeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libidee_hip.so (once) and attach signatures.  Raises if it is missing: there is no
+    CPU or eager-PyTorch fallback for the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IdeeHipError(
+            f"{LIB_PATH} not found: build it with `python idee_amd/csrc/build.py` "
+            "(hipcc --offload-arch=gfx950). The HIP library is required; there is no fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().idee_last_error().decode()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise IdeeHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous f32/int64 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise IdeeHipError("idee_amd kernels need tensors on a HIP device (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise IdeeHipError("idee_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

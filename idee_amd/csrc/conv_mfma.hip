@@ -1,0 +1,523 @@
+// Implicit-GEMM 3-D convolutions on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) for gfx950.
+//
+// Covers every convolution of the hot path, channels-last, V per-variable weight sets batched:
+//   mode K333_REPLICATE : Conv3d 3x3x3, stride 1, replicate padding 1  (proj_var, Swin_3D.py:586-592;
+//                         conv_block convs, encoder/CNN_3D.py:99-106)
+//   mode K233_S2_ZERO   : Conv3d (2,3,3), stride (2,1,1), zero padding (0,1,1)
+//                         (classifier heads, classifier/CNN_3D.py:38-40,83-85)
+// forward, data gradient and weight gradient.  Output tile of a wave = up to 64 pixels along W
+// (4 MFMA column blocks of 16) x NT blocks of 16 output channels, D^T orientation
+// (rows = channels, cols = pixels) so that each lane ends up with 4 consecutive channels of one
+// pixel and stores them as one 16-byte word.  The GEMM K dimension runs over (tap, 16-channel
+// group, 4 k-steps); each lane fetches 4 consecutive input channels of its pixel with one 16-byte
+// load and the matching 4 k-steps of the weight fragment with one 16-byte load from a
+// fragment-ordered ("packed") weight buffer (LDS-resident for the 16->16 convs, L2-resident
+// for the 96-wide joint head).  Replicate padding is a clamp on the gather address; its data
+// gradient uses the exact (q, tap) pair lists in T and H (tile-uniform) and a padded frame with
+// float atomics on the two edge columns in W.
+#include "common.h"
+
+namespace {
+
+using namespace idee;
+
+enum { FWD_REP = 0, DGRAD_REP = 1, FWD_S2 = 2, DGRAD_S2 = 3 };
+
+struct ConvArgs {
+  const float* in;
+  const float* wp;        // packed fragments
+  const float* bias;      // fwd: (wsets, CoutPad) or null
+  const float* relu_ref;  // dgrad: multiply by (relu_ref > 0), same layout as out, or null
+  float* out;
+  int B, wsets;
+  int Ti, Hi, Wi;         // extent of `in`
+  int To, Ho, Wo;         // extent of `out`
+  int Gk;                 // K groups (16 channels each) of `in`
+  int GnTot;              // output channel groups in total
+  int cout_real;          // real output channels (1 => scalar store)
+  int relu;
+  int accumulate;         // out += result (plain-store path)
+  int ntaps;
+  long i_sB, i_sT, i_sH, i_sW, i_sG;
+  long o_sB, o_sT, o_sH, o_sW, o_sG;
+  int nsub, wtiles, sub_base, sub_rem;   // 16-pixel column blocks per row and their split into wave tiles
+  int hgroups, tiles;                    // ceil(Ho/4); To*hgroups*wtiles
+};
+
+struct Slot { int src, tap; bool ok; };
+
+template <int MODE>
+__device__ __forceinline__ Slot slot_t(int o, int t, int Ti) {
+  Slot s;
+  if (MODE == FWD_REP) { s.src = min(max(t + o - 1, 0), Ti - 1); s.tap = o; s.ok = true; }
+  else if (MODE == DGRAD_REP) {
+    const int q = t - (o - 1);
+    const bool in = q >= 0 && q < Ti;
+    s.src = min(max(q, 0), Ti - 1); s.tap = in ? o : 2 - o; s.ok = true;
+  } else if (MODE == FWD_S2) { s.src = 2 * t + o; s.tap = o; s.ok = (o < 2) && (s.src < Ti); }
+  else { s.src = t >> 1; s.tap = t & 1; s.ok = (o == 0) && (s.src < Ti); }
+  return s;
+}
+template <int MODE>
+__device__ __forceinline__ Slot slot_h(int o, int h, int Hi) {
+  Slot s;
+  if (MODE == FWD_REP) { s.src = min(max(h + o - 1, 0), Hi - 1); s.tap = o; s.ok = true; }
+  else if (MODE == DGRAD_REP) {
+    const int q = h - (o - 1);
+    const bool in = q >= 0 && q < Hi;
+    s.src = min(max(q, 0), Hi - 1); s.tap = in ? o : 2 - o; s.ok = true;
+  } else if (MODE == FWD_S2) { s.src = h + o - 1; s.tap = o; s.ok = s.src >= 0 && s.src < Hi; }
+  else { s.src = h - (o - 1); s.tap = o; s.ok = s.src >= 0 && s.src < Hi; }
+  return s;
+}
+// per-lane source column for output column index p (p counts the padded frame in DGRAD_REP)
+template <int MODE>
+__device__ __forceinline__ int src_w(int o, int p, int Wi, bool& ok) {
+  int q;
+  if (MODE == FWD_REP) { q = min(max(p + o - 1, 0), Wi - 1); ok = true; }
+  else if (MODE == DGRAD_REP) { q = (p - 1) - (o - 1); ok = q >= 0 && q < Wi; }
+  else if (MODE == FWD_S2) { q = p + o - 1; ok = q >= 0 && q < Wi; }
+  else { q = p - (o - 1); ok = q >= 0 && q < Wi; }
+  return q;
+}
+
+template <int MODE, int NT, bool WLDS, bool CIN1>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+  constexpr int MT = 4;
+  __shared__ __attribute__((aligned(16))) float s_w[WLDS ? 27 * 256 : 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, ntg = blockIdx.z;
+  const int wset = b % a.wsets;
+  const long tapstride = (long)a.Gk * a.GnTot * 256;
+  const float* wp = a.wp + (long)wset * a.ntaps * tapstride + (long)ntg * NT * 256;
+  if (WLDS) {   // NT == GnTot == 1, Gk == 1: ntaps KB, loaded once per workgroup
+    for (int e = threadIdx.x * 4; e < a.ntaps * 256; e += 1024) st4(s_w + e, ld4(wp + e));
+    __syncthreads();
+  }
+  // width in pixels of the frame the tile columns index (padded by 2 for the replicate dgrad)
+  const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
+
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    const int wt = tile % a.wtiles, r = tile / a.wtiles;
+    const int hg = r % a.hgroups, t = r / a.hgroups;
+    const int h = hg * 4 + wave;
+    if (h >= a.Ho) continue;   // no barriers inside the tile loop
+    const int my_mt = a.sub_base + (wt < a.sub_rem ? 1 : 0);
+    const int w0 = 16 * (wt * a.sub_base + min(wt, a.sub_rem));
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* in_b = a.in + (long)b * a.i_sB;
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot) {
+      const Slot st = slot_t<MODE>(ot, t, a.Ti);
+      if (!st.ok) continue;
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const Slot sh = slot_h<MODE>(oh, h, a.Hi);
+        if (!sh.ok) continue;
+        const float* rowp = in_b + st.src * a.i_sT + sh.src * a.i_sH + (CIN1 ? 0 : 4 * kq);
+#pragma unroll
+        for (int ow = 0; ow < 3; ++ow) {
+          const int tap = (st.tap * 3 + sh.tap) * 3 + ow;
+          long off[MT];
+          bool okm[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int p = w0 + m * 16 + j;
+            bool ok;
+            const int q = src_w<MODE>(ow, p, a.Wi, ok);
+            okm[m] = ok && (p < Wframe) && (m < my_mt);
+            off[m] = (long)q * a.i_sW;
+          }
+          for (int g = 0; g < a.Gk; ++g) {
+            f32x4 xf[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              if (CIN1) {
+                float v0 = (okm[m] && kq == 0) ? rowp[off[m]] : 0.f;
+                xf[m] = f32x4{v0, 0.f, 0.f, 0.f};
+              } else {
+                xf[m] = okm[m] ? ld4(rowp + off[m] + g * a.i_sG) : f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              f32x4 wf;
+              if (WLDS) wf = ld4(s_w + tap * 256 + lane * 4);
+              else wf = ld4(wp + tap * tapstride + ((long)g * a.GnTot + n) * 256 + lane * 4);
+#pragma unroll
+              for (int s = 0; s < (CIN1 ? 1 : 4); ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xf[m][s], acc[m][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: lane holds channels 4kq..4kq+3 of block n for pixel column j ----
+    float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+    const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m >= my_mt) continue;
+      const int p = w0 + m * 16 + j;
+      if (p >= Wframe) continue;
+      int wdst = p;
+      bool atomic = false;
+      if (MODE == DGRAD_REP) {
+        wdst = min(max(p - 1, 0), a.Wo - 1);
+        atomic = (p <= 1) || (p >= a.Wo);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int cg = ntg * NT + n;
+        f32x4 v = acc[m][n];
+        if (a.bias) {
+          if (a.cout_real == 1) v[0] += a.bias[wset];   // (wsets, 1) bias of the single-class heads
+          else v += ld4(a.bias + (long)wset * a.GnTot * 16 + cg * 16 + 4 * kq);
+        }
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const long o = (long)wdst * a.o_sW + (long)cg * a.o_sG + 4 * kq;
+        if (ref_r) {
+          const f32x4 rr = ld4(ref_r + o);
+          v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+          v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+        }
+        if (a.cout_real == 1) {
+          if (kq == 0) out_r[(long)wdst * a.o_sW] = a.accumulate ? out_r[(long)wdst * a.o_sW] + v[0] : v[0];
+        } else if (atomic) {
+          atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
+          atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
+        } else {
+          if (a.accumulate) v += ld4(out_r + o);
+          st4(out_r + o, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: dWp[wset][tap][cin][coutPad] += sum_pixels x[src(pixel, tap)][cin] * dy[pixel][cout]
+// One wave owns TPW taps x NTA input-channel blocks x NTB output-channel blocks and a share of
+// the (b, t, h) pixel rows; K runs over pixels, 4 per MFMA.
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* dwp;     // (wsets, ntaps, Cin, CoutPad)
+  float* dbias;   // (wsets, CoutPad) or null
+  int B, wsets;
+  int T, H, W;    // x extent
+  int To;         // dy extent in T (H, W equal)
+  int Cin, CoutPad, cout_real;
+  int ntaps;
+  long x_sB, x_sT, x_sH, x_sW, x_sG;
+  long y_sB, y_sT, y_sH, y_sW, y_sG;
+  int rows;       // To * H  (pixel rows per batch item)
+  int row_chunks; // gridDim.x
+  int tap_groups; // ntaps / TPW
+  int ga_groups;  // (Cin/16) / NTA
+};
+
+template <int MODE /*FWD_REP or FWD_S2*/, int TPW, int NTA, int NTB>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  // blockIdx.z = wset ; blockIdx.y = (tap group, cin group, cout group) ; blockIdx.x = row chunk
+  const int wset = blockIdx.z;
+  int yy = blockIdx.y;
+  const int tg = yy % a.tap_groups; yy /= a.tap_groups;
+  const int gag = yy % a.ga_groups; const int gbg = yy / a.ga_groups;
+  const int tap0 = tg * TPW, ga0 = gag * NTA, gb0 = gbg * NTB;
+
+  f32x4 acc[TPW][NTA][NTB];
+  float bsum[NTB];
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+    for (int i = 0; i < NTA; ++i)
+#pragma unroll
+      for (int n = 0; n < NTB; ++n) acc[tp][i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < NTB; ++n) bsum[n] = 0.f;
+
+  const int nb = a.B / a.wsets;   // batch items that share this weight set
+  const long total_rows = (long)nb * a.rows;
+  const int steps = (a.W + 3) / 4;
+  for (long row = (long)blockIdx.x * 4 + wave; row < total_rows; row += (long)gridDim.x * 4) {
+    const int bi = (int)(row / a.rows), rr = (int)(row % a.rows);
+    const int b = bi * a.wsets + wset;
+    const int t = rr / a.H, h = rr % a.H;
+    const float* dy_r = a.dy + (long)b * a.y_sB + (long)t * a.y_sT + (long)h * a.y_sH + r16;
+    const float* x_b = a.x + (long)b * a.x_sB + r16;
+    for (int s = 0; s < steps; ++s) {
+      const int p = 4 * s + kq;
+      const bool pin = p < a.W;
+      float bf[NTB];
+#pragma unroll
+      for (int n = 0; n < NTB; ++n) {
+        const int co = (gb0 + n) * 16 + r16;
+        bf[n] = (pin && co < a.cout_real) ? dy_r[(long)p * a.y_sW + (a.cout_real == 1 ? -r16 : (long)(gb0 + n) * a.y_sG)] : 0.f;
+        bsum[n] += bf[n];
+      }
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        const int tap = tap0 + tp;
+        const int ot = tap / 9, oh = (tap / 3) % 3, ow = tap % 3;
+        int st, sh, sw;
+        bool ok = pin;
+        if (MODE == FWD_REP) {
+          st = min(max(t + ot - 1, 0), a.T - 1); sh = min(max(h + oh - 1, 0), a.H - 1);
+          sw = min(max(p + ow - 1, 0), a.W - 1);
+        } else {
+          st = 2 * t + ot; sh = h + oh - 1; sw = p + ow - 1;
+          ok = ok && sh >= 0 && sh < a.H && sw >= 0 && sw < a.W;
+        }
+        const float* xp = x_b + (long)st * a.x_sT + (long)sh * a.x_sH + (long)sw * a.x_sW;
+#pragma unroll
+        for (int i = 0; i < NTA; ++i) {
+          const float af = ok ? xp[(long)(ga0 + i) * a.x_sG] : 0.f;
+#pragma unroll
+          for (int n = 0; n < NTB; ++n)
+            acc[tp][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[tp][i][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // flush: D[row = cin][col = cout]
+  float* dw = a.dwp + (long)wset * a.ntaps * a.Cin * a.CoutPad;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+    for (int i = 0; i < NTA; ++i)
+#pragma unroll
+      for (int n = 0; n < NTB; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          atomicAdd(dw + ((long)(tap0 + tp) * a.Cin + (ga0 + i) * 16 + r0 + r) * a.CoutPad + (gb0 + n) * 16 + col,
+                    acc[tp][i][n][r]);
+  if (a.dbias && tg == 0 && gag == 0) {
+#pragma unroll
+    for (int n = 0; n < NTB; ++n) {
+      float v = bsum[n];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + (gb0 + n) * 16 + lane, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing (reference layout (wsets, Cout, Cin, kt, kh, kw) -> MFMA fragment order)
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int wsets,
+                            int Cout, int Cin, int ntaps) {
+  const int Gi = Cin / 16, Go = (Cout + 15) / 16;
+  const long per_set = (long)ntaps * Gi * Go * 256;
+  const long total = (long)wsets * per_set;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int s = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    long r = e >> 8;
+    const int ws = (int)(r / ((long)ntaps * Gi * Go));
+    r %= (long)ntaps * Gi * Go;
+    const int tap = (int)(r / (Gi * Go));
+    const int rem = (int)(r % (Gi * Go));
+    const int l15 = lane & 15, kq = lane >> 4;
+    if (pf) {   // [tap][gin][gout]: W[cout = gout*16 + l15][cin = gin*16 + 4kq + s]
+      const int gin = rem / Go, gout = rem % Go;
+      const int co = gout * 16 + l15, ci = gin * 16 + 4 * kq + s;
+      pf[e] = co < Cout ? w[(((long)ws * Cout + co) * Cin + ci) * ntaps + tap] : 0.f;
+    }
+    if (pd) {   // [tap][gK = gout][gN = gin]: W[cout = gK*16 + 4kq + s][cin = gN*16 + l15]
+      const int gk = rem / Gi, gn = rem % Gi;
+      const int co = gk * 16 + 4 * kq + s, ci = gn * 16 + l15;
+      pd[e] = co < Cout ? w[(((long)ws * Cout + co) * Cin + ci) * ntaps + tap] : 0.f;
+    }
+  }
+}
+
+// dWp (wsets, ntaps, Cin, CoutPad) -> dW (wsets, Cout, Cin, ntaps)
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int wsets, int Cout, int Cin,
+                                    int ntaps, int CoutPad) {
+  const long total = (long)wsets * Cout * Cin * ntaps;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(e % ntaps);
+    long r = e / ntaps;
+    const int ci = (int)(r % Cin); r /= Cin;
+    const int co = (int)(r % Cout);
+    const int ws = (int)(r / Cout);
+    dw[e] = dwp[(((long)ws * ntaps + tap) * Cin + ci) * CoutPad + co];
+  }
+}
+
+int check_desc(const idee_conv_desc* d) {
+  IDEE_CHECK_ARG(d, "conv: null descriptor");
+  IDEE_CHECK_ARG(d->mode == IDEE_CONV_K333_REPLICATE || d->mode == IDEE_CONV_K233_S2_ZERO, "conv: bad mode %d", d->mode);
+  IDEE_CHECK_ARG(d->B > 0 && d->wsets > 0 && d->B % d->wsets == 0, "conv: B %d must be a multiple of wsets %d", d->B, d->wsets);
+  IDEE_CHECK_ARG(d->T > 0 && d->H > 0 && d->W > 0, "conv: empty extent");
+  IDEE_CHECK_ARG(d->Cin > 0 && d->Cin % 16 == 0, "conv: Cin %d must be a multiple of 16", d->Cin);
+  IDEE_CHECK_ARG(d->Cout == 1 || (d->Cout > 0 && d->Cout % 16 == 0), "conv: Cout %d must be 1 or a multiple of 16", d->Cout);
+  if (d->mode == IDEE_CONV_K233_S2_ZERO) IDEE_CHECK_ARG(d->T >= 2, "conv (2,3,3): T %d < kernel 2", d->T);
+  return IDEE_OK;
+}
+inline int out_T(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REPLICATE ? d->T : (d->T - 2) / 2 + 1; }
+inline int n_taps(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REPLICATE ? 27 : 18; }
+inline int pick_nt(int G) { return G % 6 == 0 ? 6 : G % 3 == 0 ? 3 : G % 2 == 0 ? 2 : 1; }
+
+void split_tiles(ConvArgs& a, int Wframe) {
+  a.nsub = cdiv(Wframe, 16);
+  a.wtiles = cdiv(a.nsub, 4);
+  a.sub_base = a.nsub / a.wtiles;
+  a.sub_rem = a.nsub % a.wtiles;
+  a.hgroups = cdiv(a.Ho, 4);
+  a.tiles = a.To * a.hgroups * a.wtiles;
+}
+
+template <int MODE>
+int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
+  const int NT = pick_nt(a.GnTot);
+  const bool wlds = (a.GnTot == 1 && a.Gk == 1 && !cin1);
+  int gx = imin(a.tiles, cdiv((long)kCUs * 4, (long)a.B * (a.GnTot / NT)));
+  if (wlds) gx = imin(a.tiles, cdiv((long)kCUs * 3, a.B));
+  if (gx < 1) gx = 1;
+  const dim3 grid(gx, a.B, a.GnTot / NT), block(256);
+#define LC(NT_, WL_, C1_) hipLaunchKernelGGL((conv_kernel<MODE, NT_, WL_, C1_>), grid, block, 0, stream, a)
+  if (cin1) { if (NT == 1) LC(1, false, true); else if (NT == 2) LC(2, false, true); else if (NT == 3) LC(3, false, true); else LC(6, false, true); }
+  else if (wlds) LC(1, true, false);
+  else if (NT == 1) LC(1, false, false);
+  else if (NT == 2) LC(2, false, false);
+  else if (NT == 3) LC(3, false, false);
+  else LC(6, false, false);
+#undef LC
+  return IDEE_OK;
+}
+
+}  // namespace
+
+extern "C" long idee_conv_packed_floats(const idee_conv_desc* d) {
+  if (!d || d->Cin % 16) return -1;
+  return (long)d->wsets * n_taps(d) * (d->Cin / 16) * ((d->Cout + 15) / 16) * 256;
+}
+extern "C" long idee_conv_wgrad_floats(const idee_conv_desc* d) {
+  if (!d) return -1;
+  return (long)d->wsets * n_taps(d) * d->Cin * (((d->Cout + 15) / 16) * 16);
+}
+
+extern "C" int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, float* packed_fwd, float* packed_dgrad,
+                                      idee_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  IDEE_CHECK_ARG(w && (packed_fwd || packed_dgrad), "conv_pack_weights: null argument");
+  const long total = idee_conv_packed_floats(d);
+  hipLaunchKernelGGL(pack_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, w, packed_fwd,
+                     packed_dgrad, d->wsets, d->Cout, d->Cin, n_taps(d));
+  IDEE_LAUNCH_CHECK("conv_pack_weights");
+  return IDEE_OK;
+}
+
+extern "C" int idee_conv_unpack_wgrad(const idee_conv_desc* d, const float* dw_packed, float* dw, idee_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  IDEE_CHECK_ARG(dw_packed && dw, "conv_unpack_wgrad: null argument");
+  const long total = (long)d->wsets * d->Cout * d->Cin * n_taps(d);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream,
+                     dw_packed, dw, d->wsets, d->Cout, d->Cin, n_taps(d), ((d->Cout + 15) / 16) * 16);
+  IDEE_LAUNCH_CHECK("conv_unpack_wgrad");
+  return IDEE_OK;
+}
+
+extern "C" int idee_conv_fwd(const idee_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                             idee_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  IDEE_CHECK_ARG(x && w_packed && y, "conv_fwd: null argument");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = x; a.wp = w_packed; a.bias = bias; a.relu_ref = nullptr; a.out = y;
+  a.B = d->B; a.wsets = d->wsets;
+  a.Ti = d->T; a.Hi = d->H; a.Wi = d->W;
+  a.To = out_T(d); a.Ho = d->H; a.Wo = d->W;
+  a.Gk = d->Cin / 16; a.GnTot = (d->Cout + 15) / 16; a.cout_real = d->Cout; a.relu = d->relu; a.ntaps = n_taps(d);
+  a.i_sB = d->x_sB; a.i_sT = d->x_sT; a.i_sH = d->x_sH; a.i_sW = d->x_sW; a.i_sG = d->x_sG;
+  a.o_sB = d->y_sB; a.o_sT = d->y_sT; a.o_sH = d->y_sH; a.o_sW = d->y_sW; a.o_sG = d->y_sG;
+  split_tiles(a, a.Wo);
+  if (d->mode == IDEE_CONV_K333_REPLICATE) launch_conv<FWD_REP>(a, false, (hipStream_t)stream);
+  else launch_conv<FWD_S2>(a, false, (hipStream_t)stream);
+  IDEE_LAUNCH_CHECK("conv_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
+                               float* dx, int accumulate, idee_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  IDEE_CHECK_ARG(dy && w_packed_dgrad && dx, "conv_dgrad: null argument");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = dy; a.wp = w_packed_dgrad; a.bias = nullptr; a.relu_ref = relu_ref; a.out = dx; a.accumulate = accumulate;
+  a.B = d->B; a.wsets = d->wsets;
+  a.Ti = out_T(d); a.Hi = d->H; a.Wi = d->W;
+  a.To = d->T; a.Ho = d->H; a.Wo = d->W;
+  a.Gk = (d->Cout + 15) / 16; a.GnTot = d->Cin / 16; a.cout_real = d->Cin; a.relu = 0; a.ntaps = n_taps(d);
+  a.i_sB = d->y_sB; a.i_sT = d->y_sT; a.i_sH = d->y_sH; a.i_sW = d->y_sW; a.i_sG = d->y_sG;
+  a.o_sB = d->x_sB; a.o_sT = d->x_sT; a.o_sH = d->x_sH; a.o_sW = d->x_sW; a.o_sG = d->x_sG;
+  const bool cin1 = d->Cout == 1;
+  if (d->mode == IDEE_CONV_K333_REPLICATE) {
+    IDEE_CHECK_ARG(!cin1, "conv_dgrad: Cout == 1 is only built for the (2,3,3) mode");
+    IDEE_CHECK_ARG(!accumulate, "conv_dgrad: accumulate is not built for the replicate mode (dx is zero-initialised)");
+    split_tiles(a, a.Wo + 2);
+    launch_conv<DGRAD_REP>(a, false, (hipStream_t)stream);
+  } else {
+    split_tiles(a, a.Wo);
+    launch_conv<DGRAD_S2>(a, cin1, (hipStream_t)stream);
+  }
+  IDEE_LAUNCH_CHECK("conv_dgrad");
+  return IDEE_OK;
+}
+
+extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
+                               idee_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  IDEE_CHECK_ARG(x && dy && dw_packed, "conv_wgrad: null argument");
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.dy = dy; a.dwp = dw_packed; a.dbias = dbias;
+  a.B = d->B; a.wsets = d->wsets; a.T = d->T; a.H = d->H; a.W = d->W; a.To = out_T(d);
+  a.Cin = d->Cin; a.CoutPad = ((d->Cout + 15) / 16) * 16; a.cout_real = d->Cout; a.ntaps = n_taps(d);
+  a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;
+  a.y_sB = d->y_sB; a.y_sT = d->y_sT; a.y_sH = d->y_sH; a.y_sW = d->y_sW; a.y_sG = d->y_sG;
+  a.rows = a.To * d->H;
+  const int Ga = d->Cin / 16, Gb = a.CoutPad / 16;
+  const long total_rows = (long)(d->B / d->wsets) * a.rows;
+  const bool rep = d->mode == IDEE_CONV_K333_REPLICATE;
+  hipStream_t st = (hipStream_t)stream;
+#define LW(MODE_, TPW_, NTA_, NTB_)                                                                          \
+  do {                                                                                                       \
+    a.tap_groups = a.ntaps / TPW_; a.ga_groups = Ga / NTA_;                                                  \
+    const int gy = a.tap_groups * a.ga_groups * (Gb / NTB_);                                                 \
+    int gx = imin(cdiv(total_rows, 4), cdiv((long)kCUs * 4, (long)gy * d->wsets));                           \
+    if (gx < 1) gx = 1;                                                                                      \
+    a.row_chunks = gx;                                                                                       \
+    hipLaunchKernelGGL((wgrad_kernel<MODE_, TPW_, NTA_, NTB_>), dim3(gx, gy, d->wsets), dim3(256), 0, st, a); \
+  } while (0)
+  if (Ga == 1 && Gb == 1) { if (rep) LW(FWD_REP, 27, 1, 1); else LW(FWD_S2, 18, 1, 1); }
+  else {
+    const int na = pick_nt(Ga), nb = pick_nt(Gb);
+    // one tap per wave; channel blocks up to 6x6
+#define LWT(NA_, NB_) do { if (rep) LW(FWD_REP, 1, NA_, NB_); else LW(FWD_S2, 1, NA_, NB_); } while (0)
+    if (na == 6 && nb == 6) LWT(6, 6); else if (na == 6 && nb == 1) LWT(6, 1);
+    else if (na == 3 && nb == 3) LWT(3, 3); else if (na == 3 && nb == 1) LWT(3, 1);
+    else if (na == 2 && nb == 2) LWT(2, 2); else if (na == 2 && nb == 1) LWT(2, 1);
+    else LWT(1, 1);   // any other block counts: one 16x16 block per wave
+#undef LWT
+  }
+#undef LW
+  IDEE_LAUNCH_CHECK("conv_wgrad");
+  return IDEE_OK;
+}

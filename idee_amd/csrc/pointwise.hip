@@ -1,0 +1,666 @@
+// Bandwidth-bound kernels of the path: PatchEmbed3D(k=1)+LayerNorm, LFQ, the losses, Adam.
+// All are one-pass streaming kernels with 16-byte accesses; batch-wide sums are reduced
+// per block into a workspace and finished by a single block in fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+using namespace idee;
+
+constexpr float kLnEps = 1e-5f;
+
+// block-wide sum of R values per thread -> thread 0 holds the totals in v[]
+template <int R>
+__device__ __forceinline__ void block_sum(float (&v)[R], float* smem /* >= R * 4 */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = wave_sum(v[r]);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int r = 0; r < R; ++r) smem[wave * R + r] = v[r];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += smem[w * R + r];
+      v[r] = s;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// PatchEmbed3D with patch (1,1,1): 1x1x1 conv (optional bias) + non-affine LN over channels.
+// Swin_3D.py:473-491 ; encoder/CNN_3D.py:44-71.   x (N,V,CIN,L) -> y (N,V,L,E)
+// -------------------------------------------------------------------------------------------
+template <int E, int CIN>
+__global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int V, long L) {
+  const int b = blockIdx.y, v = b % V;
+  const float* wv = w + (long)v * E * CIN;
+  const float* bv = bias ? bias + v * E : nullptr;
+  const float* xb = x + (long)b * CIN * L;
+  float* yb = y + (long)b * L * E;
+  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < L; tok += (long)gridDim.x * 256) {
+    float xi[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) xi[c] = xb[c * L + tok];
+    float e[E], mean = 0.f;
+#pragma unroll
+    for (int o = 0; o < E; ++o) {
+      float a = bv ? bv[o] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) a = fmaf(wv[o * CIN + c], xi[c], a);
+      e[o] = a;
+      mean += a;
+    }
+    mean *= (1.f / E);
+    float var = 0.f;
+#pragma unroll
+    for (int o = 0; o < E; ++o) { const float d = e[o] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(var * (1.f / E) + kLnEps);
+#pragma unroll
+    for (int o = 0; o < E; o += 4)
+      st4(yb + tok * E + o, f32x4{(e[o] - mean) * rstd, (e[o + 1] - mean) * rstd, (e[o + 2] - mean) * rstd, (e[o + 3] - mean) * rstd});
+  }
+}
+
+template <int E, int CIN>
+__global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, float* __restrict__ db, int V, long L) {
+  const int b = blockIdx.y, v = b % V;
+  const float* wv = w + (long)v * E * CIN;
+  const float* bv = bias ? bias + v * E : nullptr;
+  const float* xb = x + (long)b * CIN * L;
+  const float* dyb = dy + (long)b * L * E;
+  float gw[E][CIN], gb[E];
+#pragma unroll
+  for (int o = 0; o < E; ++o) { gb[o] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) gw[o][c] = 0.f; }
+  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < L; tok += (long)gridDim.x * 256) {
+    float xi[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) xi[c] = xb[c * L + tok];
+    float e[E], mean = 0.f;
+#pragma unroll
+    for (int o = 0; o < E; ++o) {
+      float a = bv ? bv[o] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) a = fmaf(wv[o * CIN + c], xi[c], a);
+      e[o] = a; mean += a;
+    }
+    mean *= (1.f / E);
+    float var = 0.f;
+#pragma unroll
+    for (int o = 0; o < E; ++o) { const float d = e[o] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(var * (1.f / E) + kLnEps);
+    float g[E], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int o = 0; o < E; o += 4) {
+      const f32x4 d4 = ld4(dyb + tok * E + o);
+      g[o] = d4[0]; g[o + 1] = d4[1]; g[o + 2] = d4[2]; g[o + 3] = d4[3];
+    }
+#pragma unroll
+    for (int o = 0; o < E; ++o) { e[o] = (e[o] - mean) * rstd; s1 += g[o]; s2 = fmaf(g[o], e[o], s2); }
+    s1 *= (1.f / E); s2 *= (1.f / E);
+#pragma unroll
+    for (int o = 0; o < E; ++o) {
+      const float de = rstd * (g[o] - s1 - e[o] * s2);
+      gb[o] += de;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) gw[o][c] = fmaf(de, xi[c], gw[o][c]);
+    }
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 0; o < E; ++o) {
+    const float sb = wave_sum(gb[o]);
+    if (lane == 0 && db) atomicAdd(db + v * E + o, sb);
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float sw = wave_sum(gw[o][c]);
+      if (lane == 0) atomicAdd(dw + ((long)v * E + o) * CIN + c, sw);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// LFQ (models/codebook/LFQ.py:183-307), projections on, D = log2(codebook_size) code bits.
+// tokens: z (M, E) -> z_q (M, E), indices int64 (M).  Training adds the aux-loss sums.
+// sums per block: [0] sum_i H_i  [1] sum (s-q)^2  [2..2+K) sum_i p_ik
+// -------------------------------------------------------------------------------------------
+constexpr float kLogEps = 1e-5f;   // LFQ.py:52
+constexpr float kInvTemp2 = 200.f; // 2 * inv_temperature(100): logits = -(-2 x.c) * 100   LFQ.py:238-240
+
+template <int D>
+__device__ __forceinline__ void lfq_probs(const float (&s)[D], float (&p)[1 << D]) {
+  constexpr int K = 1 << D;
+  float mx = -3.4e38f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) l += ((k >> (D - 1 - i)) & 1) ? s[i] : -s[i];
+    p[k] = l * kInvTemp2;
+    mx = fmaxf(mx, p[k]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { p[k] = __expf(p[k] - mx); sum += p[k]; }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int k = 0; k < K; ++k) p[k] *= inv;
+}
+
+template <int E, int D>
+__global__ __launch_bounds__(256) void lfq_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w_in,
+                                                      const float* __restrict__ b_in, const float* __restrict__ w_out,
+                                                      const float* __restrict__ b_out, float* __restrict__ zq,
+                                                      long long* __restrict__ indices, float* __restrict__ partials,
+                                                      long M, int training) {
+  constexpr int K = 1 << D, R = 2 + K;
+  __shared__ float smem[R * 4];
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
+    float zi[E];
+#pragma unroll
+    for (int e = 0; e < E; e += 4) { const f32x4 t = ld4(z + tok * E + e); zi[e] = t[0]; zi[e + 1] = t[1]; zi[e + 2] = t[2]; zi[e + 3] = t[3]; }
+    float s[D], q[D];
+    long long idx = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float a = b_in[i];
+#pragma unroll
+      for (int e = 0; e < E; ++e) a = fmaf(w_in[i * E + e], zi[e], a);
+      s[i] = a;
+      q[i] = a > 0.f ? 1.f : -1.f;                 // strict > (LFQ.py:222,234)
+      idx |= (long long)(a > 0.f) << (D - 1 - i);
+    }
+    indices[tok] = idx;
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      f32x4 o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float a = b_out[e + u];
+#pragma unroll
+        for (int i = 0; i < D; ++i) a = fmaf(w_out[(e + u) * D + i], q[i], a);
+        o[u] = a;
+      }
+      st4(zq + tok * E + e, o);
+    }
+    if (training) {
+      float p[K];
+      lfq_probs<D>(s, p);
+#pragma unroll
+      for (int k = 0; k < K; ++k) { acc[0] -= p[k] * __logf(fmaxf(p[k], kLogEps)); acc[2 + k] += p[k]; }
+#pragma unroll
+      for (int i = 0; i < D; ++i) { const float d = s[i] - q[i]; acc[1] = fmaf(d, d, acc[1]); }
+    }
+  }
+  if (training) {
+    block_sum<R>(acc, smem);
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int r = 0; r < R; ++r) partials[(long)blockIdx.x * R + r] = acc[r];
+  }
+}
+
+// stats out: [0] aux loss, [1] per-sample entropy, [2] batch entropy, [3] commit, [4..4+K) avg prob
+template <int D>
+__global__ void lfq_finalize_kernel(const float* __restrict__ partials, int nblocks, float* __restrict__ stats, long M,
+                                    float w_ent, float gamma, float w_commit) {
+  constexpr int K = 1 << D, R = 2 + K;
+  __shared__ double sm[R][64];
+  const int t = threadIdx.x;   // 64 threads
+  for (int r = 0; r < R; ++r) {
+    double s = 0.0;
+    for (int b = t; b < nblocks; b += 64) s += (double)partials[(long)b * R + r];
+    sm[r][t] = s;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double tot[R];
+    for (int r = 0; r < R; ++r) { double s = 0.0; for (int i = 0; i < 64; ++i) s += sm[r][i]; tot[r] = s; }
+    const float per_sample = (float)(tot[0] / (double)M);
+    const float commit = (float)(tot[1] / ((double)M * D));
+    float hb = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float a = (float)(tot[2 + k] / (double)M);
+      stats[4 + k] = a;
+      hb -= a * logf(fmaxf(a, kLogEps));
+    }
+    stats[1] = per_sample; stats[2] = hb; stats[3] = commit;
+    stats[0] = commit * w_commit + w_ent * per_sample - gamma * hb;
+  }
+}
+
+// backward.  gscal[0] = upstream gradient of the aux loss.  grads accumulate with atomics.
+template <int E, int D>
+__global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dzq,
+                                                      const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                      const float* __restrict__ w_out, const float* __restrict__ stats,
+                                                      const float* __restrict__ gscal, float* __restrict__ dz,
+                                                      float* __restrict__ dw_in, float* __restrict__ db_in,
+                                                      float* __restrict__ dw_out, float* __restrict__ db_out, long M,
+                                                      float w_ent, float gamma, float w_commit) {
+  constexpr int K = 1 << D;
+  const float g = gscal[0];
+  const float invM = 1.f / (float)M;
+  float ub[K];   // d Hbatch / d a_k
+#pragma unroll
+  for (int k = 0; k < K; ++k) { const float a = stats[4 + k]; ub[k] = -(logf(fmaxf(a, kLogEps)) + (a >= kLogEps ? 1.f : 0.f)); }
+  float gwi[D][E], gbi[D], gwo[E][D], gbo[E];
+#pragma unroll
+  for (int i = 0; i < D; ++i) { gbi[i] = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { gwi[i][e] = 0.f; gwo[e][i] = 0.f; } }
+#pragma unroll
+  for (int e = 0; e < E; ++e) gbo[e] = 0.f;
+
+  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
+    float zi[E], go[E];
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      const f32x4 t = ld4(z + tok * E + e), u = ld4(dzq + tok * E + e);
+      zi[e] = t[0]; zi[e + 1] = t[1]; zi[e + 2] = t[2]; zi[e + 3] = t[3];
+      go[e] = u[0]; go[e + 1] = u[1]; go[e + 2] = u[2]; go[e + 3] = u[3];
+    }
+    float s[D], q[D], ds[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float a = b_in[i];
+#pragma unroll
+      for (int e = 0; e < E; ++e) a = fmaf(w_in[i * E + e], zi[e], a);
+      s[i] = a; q[i] = a > 0.f ? 1.f : -1.f;
+      float d = 0.f;                               // straight-through: d x_ste = W_out^T dz_q
+#pragma unroll
+      for (int e = 0; e < E; ++e) d = fmaf(go[e], w_out[e * D + i], d);
+      ds[i] = d + g * w_commit * 2.f * (s[i] - q[i]) * invM * (1.f / D);
+    }
+    float p[K];
+    lfq_probs<D>(s, p);
+    float us = 0.f, ubs = 0.f, u[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      u[k] = -(__logf(fmaxf(p[k], kLogEps)) + (p[k] >= kLogEps ? 1.f : 0.f));
+      us = fmaf(u[k], p[k], us);
+      ubs = fmaf(ub[k], p[k], ubs);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      // d/dlogit_k of (w_ent * H_i / M - gamma * Hbatch)
+      const float dl = p[k] * (w_ent * (u[k] - us) - gamma * (ub[k] - ubs)) * invM * g * kInvTemp2;
+#pragma unroll
+      for (int i = 0; i < D; ++i) ds[i] += ((k >> (D - 1 - i)) & 1) ? dl : -dl;
+    }
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      f32x4 o;
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < D; ++i) a = fmaf(ds[i], w_in[i * E + e + uu], a);
+        o[uu] = a;
+      }
+      st4(dz + tok * E + e, o);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      gbi[i] += ds[i];
+#pragma unroll
+      for (int e = 0; e < E; ++e) { gwi[i][e] = fmaf(ds[i], zi[e], gwi[i][e]); gwo[e][i] = fmaf(go[e], q[i], gwo[e][i]); }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) gbo[e] += go[e];
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const float a = wave_sum(gbi[i]);
+    if (lane == 0) atomicAdd(db_in + i, a);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float b = wave_sum(gwi[i][e]), c = wave_sum(gwo[e][i]);
+      if (lane == 0) { atomicAdd(dw_in + i * E + e, b); atomicAdd(dw_out + e * D + i, c); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const float a = wave_sum(gbo[e]);
+    if (lane == 0) atomicAdd(db_out + e, a);
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// class-frequency-weighted BCE with logits (models/losses.py:64-124)
+// -------------------------------------------------------------------------------------------
+// counts[0..1] = torch.histc(target[valid], bins=2) with its data-derived range (min==max -> [min-1,max+1])
+__global__ void bce_counts_kernel(const float* __restrict__ target, const float* __restrict__ valid, long M,
+                                  float* __restrict__ counts) {
+  __shared__ float smem[3 * 16];
+  float v[3] = {3.4e38f, -3.4e38f, 0.f};
+  for (long i = threadIdx.x; i < M; i += blockDim.x) {
+    if (valid && valid[i] == 0.f) continue;
+    v[0] = fminf(v[0], target[i]); v[1] = fmaxf(v[1], target[i]);
+  }
+  // min / max reduce
+  for (int o = 32; o > 0; o >>= 1) { v[0] = fminf(v[0], __shfl_xor(v[0], o, 64)); v[1] = fmaxf(v[1], __shfl_xor(v[1], o, 64)); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) { smem[wave] = v[0]; smem[16 + wave] = v[1]; }
+  __syncthreads();
+  float mn = smem[0], mx = smem[16];
+  for (int w = 1; w < nw; ++w) { mn = fminf(mn, smem[w]); mx = fmaxf(mx, smem[16 + w]); }
+  if (mn == mx) { mn -= 1.f; mx += 1.f; }
+  float c1 = 0.f, c0 = 0.f;
+  for (long i = threadIdx.x; i < M; i += blockDim.x) {
+    if (valid && valid[i] == 0.f) continue;
+    int bin = (int)((target[i] - mn) / (mx - mn) * 2.f);
+    bin = bin > 1 ? 1 : bin;
+    if (bin == 1) c1 += 1.f; else c0 += 1.f;
+  }
+  c0 = wave_sum(c0); c1 = wave_sum(c1);
+  __syncthreads();
+  if (lane == 0) { smem[wave] = c0; smem[16 + wave] = c1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < nw; ++w) { a += smem[w]; b += smem[16 + w]; }
+    counts[0] = a; counts[1] = b;
+  }
+}
+
+__device__ __forceinline__ void class_weights(const float* counts, float& w0, float& w1) {
+  const float tot = counts[0] + counts[1];
+  w0 = logf(powf(counts[0] / tot, -0.5f) + 1.1f);   // losses.py:83-84 / :118-119
+  w1 = logf(powf(counts[1] / tot, -0.5f) + 1.1f);
+}
+
+// pred (P, M), target (M): sums[p] = sum_i bce(pred[p,i], t_i) * w[t_i] (* valid_i); sums[P] = sum valid (or M)
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      const float* __restrict__ valid, const float* __restrict__ counts,
+                                                      float* __restrict__ partials, int P, long M) {
+  __shared__ float smem[8];
+  float w0, w1;
+  class_weights(counts, w0, w1);
+  for (int p = 0; p <= P; ++p) {
+    float acc[1] = {0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long)gridDim.x * 256) {
+      const float vm = valid ? (valid[i] != 0.f ? 1.f : 0.f) : 1.f;
+      if (p == P) { acc[0] += valid ? valid[i] : 1.f; continue; }
+      const float t = target[i], x = pred[(long)p * M + i];
+      const float w = ((long long)t == 0 ? w0 : w1) * vm;
+      const float l = fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+      acc[0] += (vm != 0.f) ? l * w : 0.f;
+    }
+    block_sum<1>(acc, smem);
+    if (threadIdx.x == 0) partials[(long)blockIdx.x * (P + 1) + p] = acc[0];
+  }
+}
+// out[p] = sum_blocks partial[p] / sum_blocks partial[P]   (P+1 columns, fixed order)
+__global__ void ratio_finalize_kernel(const float* __restrict__ partials, int nblocks, int P, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  double den = 0.0;
+  for (int b = 0; b < nblocks; ++b) den += (double)partials[(long)b * (P + 1) + P];
+  for (int p = 0; p < P; ++p) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partials[(long)b * (P + 1) + p];
+    out[p] = (float)(s / den);
+  }
+  out[P] = (float)den;
+}
+// dpred[p,i] = gout[p] * w[t_i] * valid_i * (sigmoid(x) - t) / denom
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      const float* __restrict__ valid, const float* __restrict__ counts,
+                                                      const float* __restrict__ gout, const float* __restrict__ denom,
+                                                      float* __restrict__ dpred, int P, long M) {
+  float w0, w1;
+  class_weights(counts, w0, w1);
+  const float inv = 1.f / denom[0];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)P * M; e += (long)gridDim.x * 256) {
+    const long i = e % M; const int p = (int)(e / M);
+    const float t = target[i], x = pred[e];
+    const bool vm = valid ? valid[i] != 0.f : true;
+    const float w = ((long long)t == 0 ? w0 : w1);
+    const float sg = 1.f / (1.f + __expf(-x));
+    dpred[e] = vm ? gout[p] * w * (sg - t) * inv : 0.f;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// masked L1 "anomaly" loss (models/losses.py:15-61, :127-168) on channels-last z_q (N,V,T,H,W,E)
+// weight = 1 - min(mask_extreme[n,h,w] + mask_valid[n,t,h,w], 1); target = vq0[e]
+// partial sums per block: [0] sum |z_q - vq0| * weight   [1] sum weight (over the full repeated shape)
+// -------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void anomaly_fwd_kernel(const float* __restrict__ zq, const float* __restrict__ mask,
+                                                          const float* __restrict__ mvalid, const float* __restrict__ vq0,
+                                                          float* __restrict__ partials, int N, int V, int T, long HW) {
+  __shared__ float smem[8];
+  float c[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) c[e] = vq0[e];
+  float acc[2] = {0.f, 0.f};
+  const long M = (long)N * V * T * HW;
+  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
+    const long hw = tok % HW; long r = tok / HW;
+    const int t = (int)(r % T); r /= T;
+    const int n = (int)(r / V);
+    float m = mask[(long)n * HW + hw];
+    if (mvalid) m = fminf(m + mvalid[((long)n * T + t) * HW + hw], 1.f);
+    const float wgt = 1.f - m;
+    acc[1] += wgt * E;
+    if (m == 1.f) continue;   // target := prediction there (losses.py:162): exactly zero contribution
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      const f32x4 v = ld4(zq + tok * E + e);
+      s += fabsf(v[0] - c[e]) + fabsf(v[1] - c[e + 1]) + fabsf(v[2] - c[e + 2]) + fabsf(v[3] - c[e + 3]);
+    }
+    acc[0] = fmaf(s, wgt, acc[0]);
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) { partials[(long)blockIdx.x * 2] = acc[0]; partials[(long)blockIdx.x * 2 + 1] = acc[1]; }
+}
+template <int E>
+__global__ __launch_bounds__(256) void anomaly_bwd_kernel(const float* __restrict__ zq, const float* __restrict__ mask,
+                                                          const float* __restrict__ mvalid, const float* __restrict__ vq0,
+                                                          const float* __restrict__ gout, const float* __restrict__ denom,
+                                                          float* __restrict__ dzq, int N, int V, int T, long HW) {
+  float c[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) c[e] = vq0[e];
+  const float sc = gout[0] / denom[0];
+  const long M = (long)N * V * T * HW;
+  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
+    const long hw = tok % HW; long r = tok / HW;
+    const int t = (int)(r % T); r /= T;
+    const int n = (int)(r / V);
+    float m = mask[(long)n * HW + hw];
+    if (mvalid) m = fminf(m + mvalid[((long)n * T + t) * HW + hw], 1.f);
+    const float k = sc * (1.f - m);
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      f32x4 v = ld4(zq + tok * E + e);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = v[u] - c[e + u];
+        v[u] = (m == 1.f) ? 0.f : (d > 0.f ? k : (d < 0.f ? -k : 0.f));
+      }
+      st4(dzq + tok * E + e, v);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// Adam over one flat buffer (torch.optim.Adam math: L2 decay in the gradient, eps outside the sqrt)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float gi = g[i] * gscale + wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+int stream_grid(long items) { return imin(cdiv(items, 256), kCUs * 8); }
+
+}  // namespace
+
+// ---- C-ABI ----------------------------------------------------------------------------------
+extern "C" int idee_patch_embed_ln_fwd(const float* x, const float* w, const float* b, float* y, int N, int V, int Cin,
+                                       long L, int E, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && w && y && N > 0 && V > 0 && L > 0, "patch_embed_ln_fwd: bad argument");
+  const dim3 grid(imin(cdiv(L, 256), cdiv((long)kCUs * 8, (long)N * V)), N * V);
+#define PE(E_, C_) hipLaunchKernelGGL((patch_embed_fwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, V, L)
+  if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
+  else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "patch_embed_ln: (E=%d, Cin=%d) not built", E, Cin);
+#undef PE
+  IDEE_LAUNCH_CHECK("patch_embed_ln_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dw, float* db,
+                                       int N, int V, int Cin, long L, int E, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && w && dy && dw && N > 0 && V > 0 && L > 0, "patch_embed_ln_bwd: bad argument");
+  const dim3 grid(imin(cdiv(L, 256), cdiv((long)kCUs * 4, (long)N * V)), N * V);
+#define PE(E_, C_) hipLaunchKernelGGL((patch_embed_bwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, dy, dw, db, V, L)
+  if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
+  else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "patch_embed_ln: (E=%d, Cin=%d) not built", E, Cin);
+#undef PE
+  IDEE_LAUNCH_CHECK("patch_embed_ln_bwd");
+  return IDEE_OK;
+}
+
+extern "C" long idee_lfq_workspace_floats(long M, int codebook_size) {
+  return (long)stream_grid(M) * (2 + codebook_size);
+}
+
+#define LFQ_DISPATCH(CALL)                                                                             \
+  if (E == 16 && D == 1) { CALL(16, 1); } else if (E == 16 && D == 2) { CALL(16, 2); }                   \
+  else if (E == 16 && D == 3) { CALL(16, 3); } else if (E == 32 && D == 1) { CALL(32, 1); }              \
+  else if (E == 32 && D == 2) { CALL(32, 2); }                                                           \
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "lfq: (dim=%d, codebook_size=%d) not built", E, 1 << D);
+
+static int log2i(int k) { int d = 0; while ((1 << d) < k) ++d; return d; }
+
+extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                            float* zq, int64_t* indices, float* stats, float* workspace, long M, int E, int codebook_size,
+                            int training, float w_entropy, float gamma, float w_commit, idee_stream_t stream) {
+  IDEE_CHECK_ARG(z && w_in && b_in && w_out && b_out && zq && indices && M > 0, "lfq_fwd: bad argument");
+  IDEE_CHECK_ARG(!training || (stats && workspace), "lfq_fwd: training needs stats and workspace");
+  const int D = log2i(codebook_size);
+  IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
+  const int nb = stream_grid(M);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(E_, D_)                                                                                           \
+  hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, st, z, w_in, b_in, w_out, b_out, zq,     \
+                     (long long*)indices, workspace, M, training);                                             \
+  if (training) hipLaunchKernelGGL((lfq_finalize_kernel<D_>), dim3(1), dim3(64), 0, st, workspace, nb, stats, M, \
+                                   w_entropy, gamma, w_commit)
+  LFQ_DISPATCH(CALL)
+#undef CALL
+  IDEE_LAUNCH_CHECK("lfq_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const float* b_in, const float* w_out,
+                            const float* stats, const float* gloss, float* dz, float* dw_in, float* db_in, float* dw_out,
+                            float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma, float w_commit,
+                            idee_stream_t stream) {
+  IDEE_CHECK_ARG(z && dzq && w_in && b_in && w_out && stats && gloss && dz && dw_in && db_in && dw_out && db_out && M > 0,
+                 "lfq_bwd: bad argument");
+  const int D = log2i(codebook_size);
+  IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
+  const int nb = imin(cdiv(M, 256), kCUs * 4);
+#define CALL(E_, D_)                                                                                               \
+  hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in, w_out, \
+                     stats, gloss, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
+  LFQ_DISPATCH(CALL)
+#undef CALL
+  IDEE_LAUNCH_CHECK("lfq_bwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_bce_class_counts(const float* target, const float* valid, long M, float* counts, idee_stream_t stream) {
+  IDEE_CHECK_ARG(target && counts && M > 0, "bce_class_counts: bad argument");
+  hipLaunchKernelGGL(bce_counts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, target, valid, M, counts);
+  IDEE_LAUNCH_CHECK("bce_class_counts");
+  return IDEE_OK;
+}
+
+extern "C" long idee_bce_workspace_floats(int P, long M) { return (long)imin(cdiv(M, 256), 256) * (P + 1); }
+
+extern "C" int idee_bce_weighted_fwd(const float* pred, const float* target, const float* valid, const float* counts,
+                                     float* loss, float* workspace, int P, long M, idee_stream_t stream) {
+  IDEE_CHECK_ARG(pred && target && counts && loss && workspace && P > 0 && M > 0, "bce_weighted_fwd: bad argument");
+  const int nb = imin(cdiv(M, 256), 256);
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, target, valid, counts, workspace, P, M);
+  hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, nb, P, loss);
+  IDEE_LAUNCH_CHECK("bce_weighted_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_bce_weighted_bwd(const float* pred, const float* target, const float* valid, const float* counts,
+                                     const float* gout, const float* denom, float* dpred, int P, long M, idee_stream_t stream) {
+  IDEE_CHECK_ARG(pred && target && counts && gout && denom && dpred && P > 0 && M > 0, "bce_weighted_bwd: bad argument");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(stream_grid((long)P * M)), dim3(256), 0, (hipStream_t)stream, pred, target, valid,
+                     counts, gout, denom, dpred, P, M);
+  IDEE_LAUNCH_CHECK("bce_weighted_bwd");
+  return IDEE_OK;
+}
+
+extern "C" long idee_anomaly_workspace_floats(long tokens) { return (long)stream_grid(tokens) * 2; }
+
+extern "C" int idee_anomaly_l1_fwd(const float* zq, const float* mask_extreme, const float* mask_valid, const float* vq0,
+                                   float* out /* [loss, denom] */, float* workspace, int N, int V, int T, long HW, int E,
+                                   idee_stream_t stream) {
+  IDEE_CHECK_ARG(zq && mask_extreme && vq0 && out && workspace && N > 0 && V > 0 && T > 0 && HW > 0, "anomaly_l1_fwd: bad argument");
+  const long M = (long)N * V * T * HW;
+  const int nb = stream_grid(M);
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 16) hipLaunchKernelGGL((anomaly_fwd_kernel<16>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, workspace, N, V, T, HW);
+  else if (E == 32) hipLaunchKernelGGL((anomaly_fwd_kernel<32>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, workspace, N, V, T, HW);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "anomaly_l1: E=%d not built", E);
+  hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, nb, 1, out);
+  IDEE_LAUNCH_CHECK("anomaly_l1_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_anomaly_l1_bwd(const float* zq, const float* mask_extreme, const float* mask_valid, const float* vq0,
+                                   const float* gout, const float* denom, float* dzq, int N, int V, int T, long HW, int E,
+                                   idee_stream_t stream) {
+  IDEE_CHECK_ARG(zq && mask_extreme && vq0 && gout && denom && dzq && N > 0 && V > 0 && T > 0 && HW > 0, "anomaly_l1_bwd: bad argument");
+  const long M = (long)N * V * T * HW;
+  const int nb = stream_grid(M);
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 16) hipLaunchKernelGGL((anomaly_bwd_kernel<16>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, gout, denom, dzq, N, V, T, HW);
+  else if (E == 32) hipLaunchKernelGGL((anomaly_bwd_kernel<32>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, gout, denom, dzq, N, V, T, HW);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "anomaly_l1: E=%d not built", E);
+  IDEE_LAUNCH_CHECK("anomaly_l1_bwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, float grad_scale, idee_stream_t stream) {
+  IDEE_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad argument");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2s, grad_scale);
+  IDEE_LAUNCH_CHECK("adam_step");
+  return IDEE_OK;
+}

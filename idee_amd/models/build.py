@@ -1,0 +1,82 @@
+"""Model assembly on MI355X — drop-in for the reference's models/build.py: same `VQ_model(config)`
+constructor, `.encoder / .vq / .cls` attributes, `forward(x_d)` return tuple, `import_class`
+plugin rule and state-dict keys (models/build.py:17-159 of the reference).
+
+Internally activations stay channels-last tokens (N,V,T,H,W,C) from the encoder through LFQ to
+the classifier, so the two (N, V*T*H*W, C) permute copies of build.py:150,153 do not exist; the
+returned `z_q` is the permuted VIEW (N,V,C,T,H,W) the reference also returns."""
+from __future__ import annotations
+
+import importlib
+
+import torch
+import torch.nn as nn
+
+
+def import_class(en_de, name):
+    """Import class `name` from module models.<en_de>.<name> of THIS package (build.py:17-20)."""
+    module = importlib.import_module(f"{__package__}.{en_de}.{name}")
+    return getattr(module, name)
+
+
+class VQ_model(nn.Module):
+    """Encoder -> LFQ -> classifier.  `config` is the argparse namespace of config.py."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.encoder == "CNN_3D":
+            self.encoder = import_class('encoder', config.encoder)(
+                in_vars=config.in_channels_dynamic, in_channels=config.in_channels, out_channels=config.en_embed_dim,
+                drop_path_rate=config.en_drop_path_rate, drop_rate=config.en_drop_rate)
+        elif config.encoder == "Swin_3D":
+            self.encoder = import_class('encoder', config.encoder)(
+                in_vars=config.in_channels_dynamic, in_chans=config.in_channels, embed_dim=config.en_embed_dim,
+                window_size=config.en_window_size, depths=config.en_depths, num_heads=config.en_n_heads,
+                mlp_ratio=config.en_mlp_ratio, drop_rate=config.en_drop_rate, attn_drop_rate=config.en_attn_drop_rate,
+                drop_path_rate=config.en_drop_path_rate, qkv_bias=config.en_qkv_bias, qk_scale=config.en_qk_scale,
+                patch_size=config.en_patch_size, patch_norm=config.en_patch_norm, use_checkpoint=config.en_use_checkpoint)
+        elif config.encoder == "Mamba":
+            raise NotImplementedError("Encoder Mamba is outside the MI355X hot path (its arithmetic lives in the CUDA-only "
+                                      "mamba_ssm package); use encoder='Swin_3D' or 'CNN_3D'")
+        else:
+            raise NotImplementedError(f"Encoder {config.encoder} not implemented")
+
+        self.cls = import_class('classifier', 'CNN_3D')(in_var=config.in_channels_dynamic, embed_dim=config.codebook_dim,
+                                                        dim=config.cls_dim, drop_rate=config.cls_drop_rate)
+        self.vq = import_class('codebook', 'LFQ')(dim=config.codebook_dim, codebook_size=config.codebook_size,
+                                                  entropy_loss_weight=config.lambda_entropy,
+                                                  diversity_gamma=config.diversity_gamma,
+                                                  commitment_loss_weight=config.lambda_commitment)
+        self.pretrained = config.en_de_pretrained
+        self._init_weights()
+
+    def _init_weights(self, init_type='normal', gain=.02):
+        """Conv/Linear weights ~ N(0.02, gain), biases 0, LayerNorm affine (1, 0); relative-position
+        tables keep the encoder's trunc-normal (build.py:96-118)."""
+        if init_type != 'normal':
+            raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+        with torch.no_grad():
+            for mod in (self.encoder, self.cls):
+                ws, bs, _tables = mod.weight_names()
+                for n in ws:
+                    getattr(mod, n).normal_(0.02, gain)
+                for n in bs:
+                    getattr(mod, n).zero_()
+                for n in getattr(mod, "norm_names", lambda: ([], []))()[0]:
+                    getattr(mod, n).fill_(1.0)
+            for lin in (self.vq.project_in, self.vq.project_out):
+                lin.weight.normal_(0.02, gain)
+                lin.bias.zero_()
+        if self.pretrained:
+            print('initialize weights from pretrained model {} ...'.format(self.pretrained))
+            checkpoint = torch.load(self.pretrained, map_location='cpu')
+            state_dict = {k.replace('module.', ''): v for k, v in checkpoint['model_state_dict'].items()}
+            self.load_state_dict(state_dict, strict=True)
+
+    def forward(self, x_d):
+        """x_d (N,V,C,T,H,W) -> z (N,1,H,W), y [V x (N,1,H,W)], anomaly int64 (N,V,T,H,W),
+        z_q (N,V,C,T,H,W), loss_z_q (1,)   — build.py:130-159."""
+        z = self.encoder.forward_tokens(x_d)                 # (N,V,T,H,W,E)
+        z_q, anomaly, loss_z_q = self.vq.quantize_tokens(z)
+        zc, y = self.cls.forward_tokens(z_q)
+        return zc, y, anomaly, z_q.permute(0, 1, 5, 2, 3, 4), loss_z_q.unsqueeze(0)

@@ -1,0 +1,72 @@
+"""3-D CNN classifier on MI355X — drop-in for the reference's models/classifier/CNN_3D.py
+(class CNN_3D :61-139, Layer_v :17-58).  The joint head and the V per-variable heads are six
+MFMA implicit-GEMM convolutions (idee_conv_*) run from one autograd node; the V heads' weight
+sets are V-stacked.  state_dict()/load_state_dict() speak the reference's keys
+(conv{1,2,3}.*, layers.{v}.conv{1,2,3}.*)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _stacked
+from ... import ops
+
+
+class CNN_3D(_stacked.StackedModule):
+    def __init__(self, in_var: int = 6, embed_dim: int = 16, dim: int = 16, n_classes: int = 1, drop_rate: int = 0.2):
+        super().__init__()
+        if n_classes != 1:
+            raise NotImplementedError("idee_amd classifier: n_classes != 1 is not built (models/build.py:81-84 uses 1)")
+        self.in_var, self.embed_dim, self.dim = in_var, embed_dim * in_var, dim * in_var
+        self.n_classes, self.drop_rate = n_classes, drop_rate
+        V, E, D, Dj, Ej = in_var, embed_dim, dim, dim * in_var, embed_dim * in_var
+        k = (2, 3, 3)
+        self.j_w1 = nn.Parameter(torch.empty(Dj, Ej, *k)); self.j_b1 = nn.Parameter(torch.zeros(Dj))
+        self.j_w2 = nn.Parameter(torch.empty(Dj, Dj, *k)); self.j_b2 = nn.Parameter(torch.zeros(Dj))
+        self.j_w3 = nn.Parameter(torch.empty(1, Dj, *k)); self.j_b3 = nn.Parameter(torch.zeros(1))
+        self.h_w1 = nn.Parameter(torch.empty(V, D, E, *k)); self.h_b1 = nn.Parameter(torch.zeros(V, D))
+        self.h_w2 = nn.Parameter(torch.empty(V, D, D, *k)); self.h_b2 = nn.Parameter(torch.zeros(V, D))
+        self.h_w3 = nn.Parameter(torch.empty(V, 1, D, *k)); self.h_b3 = nn.Parameter(torch.zeros(V, 1))
+        self.reset_parameters()
+
+    def weight_names(self):
+        ws = ["j_w1", "j_w2", "j_w3", "h_w1", "h_w2", "h_w3"]
+        return ws, [n.replace("_w", "_b") for n in ws], []
+
+    def reset_parameters(self):
+        """nn.Conv3d's default init (kaiming-uniform, a=sqrt(5)) — the reference never calls its
+        own init_weights (classifier/CNN_3D.py:95-110); VQ_model._init_weights overrides anyway."""
+        with torch.no_grad():
+            for n in self.weight_names()[0]:
+                w = getattr(self, n)
+                fan_in = w[0].numel() if w.ndim == 5 else w[0, 0].numel()
+                bound = 1.0 / fan_in ** 0.5
+                w.uniform_(-bound, bound)
+                getattr(self, n.replace("_w", "_b")).uniform_(-bound, bound)
+
+    def init_weights(self):
+        with torch.no_grad():
+            for n in self.weight_names()[0]:
+                nn.init.trunc_normal_(getattr(self, n), std=.04)
+                getattr(self, n.replace("_w", "_b")).zero_()
+
+    def _key_map(self):
+        m = []
+        for i in (1, 2, 3):
+            m += [(f"conv{i}.weight", f"j_w{i}", None), (f"conv{i}.bias", f"j_b{i}", None)]
+        for v in range(self.in_var):
+            for i in (1, 2, 3):
+                m += [(f"layers.{v}.conv{i}.weight", f"h_w{i}", v), (f"layers.{v}.conv{i}.bias", f"h_b{i}", v)]
+        return m
+
+    def forward_tokens(self, zq):
+        """zq (N,V,T,H,W,C) channels-last -> (z (N,1,H,W), [y_v (N,1,H,W)] * V)."""
+        if self.training and self.drop_rate and self.drop_rate > 0:
+            raise NotImplementedError("idee_amd classifier: dropout > 0 is not built (cls_drop_rate default is 0)")
+        z, y = ops.ClassifierHeads.apply(zq, self.j_w1, self.j_b1, self.j_w2, self.j_b2, self.j_w3, self.j_b3, self.h_w1,
+                                         self.h_b1, self.h_w2, self.h_b2, self.h_w3, self.h_b3)
+        return z, [y[:, v:v + 1] for v in range(self.in_var)]
+
+    def forward(self, x):
+        """x (N,V,C,T,H,W) as CNN_3D.forward (classifier/CNN_3D.py:112-139)."""
+        return self.forward_tokens(x.permute(0, 1, 3, 4, 5, 2).contiguous())

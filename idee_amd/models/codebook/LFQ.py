@@ -1,0 +1,73 @@
+"""Lookup-free quantisation on MI355X — drop-in for the reference's models/codebook/LFQ.py
+(class LFQ, LFQ.py:68-307): sign quantisation of a dim -> log2(K) projection, straight-through
+gradient, entropy + commitment auxiliary loss, all in one streaming HIP kernel per direction
+(idee_lfq_fwd / idee_lfq_bwd).  Parameter names match the reference (project_in / project_out,
+buffer `mask`), so state dicts interchange."""
+from __future__ import annotations
+
+from collections import namedtuple
+from math import log2
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+Return = namedtuple("Return", ["quantized", "indices", "entropy_aux_loss"])
+
+
+class LFQ(nn.Module):
+    def __init__(self, *, dim=16, dim_out=16, codebook_size=2, entropy_loss_weight=0.1, commitment_loss_weight=1.5,
+                 diversity_gamma=1., straight_through_activation=None, num_codebooks=1, keep_num_codebooks_dim=None,
+                 codebook_scale=1., frac_per_sample_entropy=1.):
+        super().__init__()
+        assert log2(codebook_size).is_integer(), "your codebook size must be a power of 2 for lookup free quantization"
+        if num_codebooks != 1 or codebook_scale != 1. or frac_per_sample_entropy != 1. or \
+                (straight_through_activation is not None and not isinstance(straight_through_activation, nn.Identity)):
+            raise NotImplementedError("idee_amd LFQ: only the configuration models/build.py:87-91 constructs is built")
+        codebook_dim = int(log2(codebook_size))
+        if dim == codebook_dim:
+            raise NotImplementedError("idee_amd LFQ: dim == log2(codebook_size) (no projections) is not built")
+        self.dim, self.dim_out, self.codebook_dim, self.codebook_size = dim, dim_out, codebook_dim, codebook_size
+        self.num_codebooks, self.keep_num_codebooks_dim, self.has_projections = 1, False, True
+        self.project_in = nn.Linear(dim, codebook_dim)
+        self.project_out = nn.Linear(codebook_dim, dim)
+        self.diversity_gamma = diversity_gamma
+        self.entropy_loss_weight = entropy_loss_weight
+        self.commitment_loss_weight = commitment_loss_weight
+        self.codebook_scale = codebook_scale
+        self.register_buffer("mask", 2 ** torch.arange(codebook_dim - 1, -1, -1))
+        self.register_buffer("zero", torch.tensor(0.), persistent=False)
+        bits = ((torch.arange(codebook_size)[..., None].int() & self.mask) != 0).float()
+        self.register_buffer("codebook", bits * 2 - 1, persistent=False)
+
+    def indices_to_codes(self, indices, project_out=True):
+        """LFQ.indices_to_codes (LFQ.py:152-181) for index tensors of up to 2 dims, e.g. the
+        `indices_to_codes(LongTensor([0]))` call of train_synthetic.py:193-194 -> (1, dim).
+        A handful of codes: plain tensor indexing, not a kernel."""
+        if indices.ndim >= 3:
+            raise NotImplementedError("idee_amd LFQ.indices_to_codes: image/video index maps are not built")
+        codes = self.codebook[indices]
+        if project_out:
+            codes = codes @ self.project_out.weight.t() + self.project_out.bias
+        return codes
+
+    def quantize_tokens(self, z):
+        """z (..., dim) channels-last tokens -> (z_q (..., dim), indices int64 (...), aux loss ())."""
+        assert z.shape[-1] == self.dim, f"expected dimension of {self.dim} but received {z.shape[-1]}"
+        return ops.LFQQuantize.apply(z, self.project_in.weight, self.project_in.bias, self.project_out.weight,
+                                     self.project_out.bias, self.codebook_size, self.training,
+                                     float(self.entropy_loss_weight), float(self.diversity_gamma),
+                                     float(self.commitment_loss_weight))
+
+    def forward(self, x, inv_temperature=100., return_loss_breakdown=False, mask=None):
+        """x (b, n, dim) as models/build.py:150-151 passes it (or (b, dim, ...) image/video)."""
+        if inv_temperature != 100. or return_loss_breakdown or mask is not None:
+            raise NotImplementedError("idee_amd LFQ.forward: non-default inv_temperature / breakdown / mask are not built")
+        if x.ndim >= 4:   # (b, d, ...) -> tokens last, and back (LFQ.py:205-207, :289-291)
+            perm = (0,) + tuple(range(2, x.ndim)) + (1,)
+            zq, idx, aux = self.quantize_tokens(x.permute(*perm).contiguous())
+            inv = (0, x.ndim - 1) + tuple(range(1, x.ndim - 1))
+            return Return(zq.permute(*inv), idx, aux)
+        zq, idx, aux = self.quantize_tokens(x.contiguous())
+        return Return(zq, idx, aux)

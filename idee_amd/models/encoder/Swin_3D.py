@@ -1,0 +1,160 @@
+"""Video-Swin-3D encoder on MI355X — drop-in for the reference's models/encoder/Swin_3D.py.
+
+Same class name, module path (models.encoder.Swin_3D.Swin_3D, see models/build.py:17-20 of the
+reference) and constructor keywords as the reference (Swin_3D.py:494-512).  Differences are
+internal: the V per-variable stacks are one set of V-stacked parameters, activations are
+channels-last tokens (N,V,T,H,W,C), and each SwinTransformerBlock3D is one fused HIP kernel
+(idee_swin_block_fwd/bwd), PatchEmbed3D+LN one (idee_patch_embed_ln_*), proj_var two MFMA
+convolutions (idee_conv_*).  state_dict()/load_state_dict() speak the reference's keys.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _stacked
+from ... import ops
+
+
+def relative_position_index(ws):
+    """(Nw, Nw) int64 index into the bias table.  Reference: Swin_3D.py:115-135."""
+    wd, wh, ww = ws
+    d, h, w = torch.meshgrid(torch.arange(wd), torch.arange(wh), torch.arange(ww), indexing="ij")
+    c = torch.stack([d.reshape(-1), h.reshape(-1), w.reshape(-1)])
+    rel = c[:, :, None] - c[:, None, :]
+    return ((rel[0] + wd - 1) * ((2 * wh - 1) * (2 * ww - 1)) + (rel[1] + wh - 1) * (2 * ww - 1) + (rel[2] + ww - 1)).contiguous()
+
+
+def _check_no_dropout(training, **rates):
+    bad = {k: v for k, v in rates.items() if v and v > 0.0}
+    if training and bad:
+        raise NotImplementedError(f"idee_amd: stochastic regularisation {bad} is not built (reference defaults are 0)")
+
+
+class Swin_3D(_stacked.StackedModule):
+    def __init__(self, in_vars: int = 6, in_chans: int = 1, embed_dim: list = None, window_size: list = None,
+                 depths: list = None, num_heads: list = None, mlp_ratio: int = 4, drop_rate: float = 0.,
+                 attn_drop_rate: float = 0., drop_path_rate: float = 0., qkv_bias: bool = True, qk_scale: float = None,
+                 patch_size: tuple = (1, 1, 1), patch_norm: bool = False, use_checkpoint: bool = False):
+        super().__init__()
+        self.in_vars, self.in_chans = in_vars, in_chans
+        self.embed_dim = list(embed_dim) if embed_dim is not None else [16, 16]
+        self.num_layers = len(self.embed_dim)
+        self.window_size = [tuple(w) for w in (window_size if window_size is not None else [(2, 4, 4), (8, 1, 1)])]
+        self.depths = list(depths) if depths is not None else [2, 1]
+        self.num_heads = list(num_heads) if num_heads is not None else [2, 2]
+        self.mlp_ratio = mlp_ratio
+        self.drop_rate, self.attn_drop_rate, self.drop_path_rate = drop_rate, attn_drop_rate, drop_path_rate
+        self.qkv_bias, self.qk_scale = qkv_bias, qk_scale
+        self.patch_size = tuple(patch_size)
+        self.patch_norm = patch_norm            # no-op in the reference too (Swin_3D.py:417-418)
+        self.use_checkpoint = use_checkpoint    # backward always recomputes the block from its input
+        if self.patch_size != (1, 1, 1):
+            raise NotImplementedError("idee_amd Swin_3D: only patch_size (1,1,1) is built (the reference's setting)")
+        if not qkv_bias:
+            raise NotImplementedError("idee_amd Swin_3D: qkv_bias=False is not built")
+        V = in_vars
+        self._stages = []
+        for s in range(self.num_layers):
+            C = self.embed_dim[s]
+            in_dim = self.embed_dim[s - 1] if s > 0 else in_chans
+            has_ds = in_dim != C                # patch (1,1,1): downsample iff the width changes (Swin_3D.py:414-419)
+            hid = int(C * mlp_ratio)
+            wd, wh, ww = self.window_size[s]
+            L = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1)
+            if has_ds:
+                self.register_parameter(f"s{s}_ds_w", nn.Parameter(torch.empty(V, C, in_dim)))
+                self.register_parameter(f"s{s}_ds_b", nn.Parameter(torch.zeros(V, C)))
+            self.register_buffer(f"s{s}_index", relative_position_index((wd, wh, ww)), persistent=False)
+            for b in range(self.depths[s]):
+                p = f"s{s}_b{b}_"
+                for name, shape in (("table", (V, L, self.num_heads[s])), ("qkv_w", (V, 3 * C, C)), ("qkv_b", (V, 3 * C)),
+                                    ("proj_w", (V, C, C)), ("proj_b", (V, C)), ("fc1_w", (V, hid, C)), ("fc1_b", (V, hid)),
+                                    ("fc2_w", (V, C, hid)), ("fc2_b", (V, C))):
+                    self.register_parameter(p + name, nn.Parameter(torch.zeros(shape)))
+            self._stages.append((s, C, in_dim, has_ds))
+        E = self.embed_dim[-1]
+        self.pv_w1 = nn.Parameter(torch.empty(V, E, E, 3, 3, 3))
+        self.pv_b1 = nn.Parameter(torch.zeros(V, E))
+        self.pv_w2 = nn.Parameter(torch.empty(V, E, E, 3, 3, 3))
+        self.pv_b2 = nn.Parameter(torch.zeros(V, E))
+        self.init_weights()
+
+    # ---- initialisation (Swin_3D.py:596-613: trunc-normal weights, zero biases) ----
+    def weight_names(self):
+        """-> (matrix-like weights, biases, relative-position tables)."""
+        ws, bs, ts = [], [], []
+        for n, _ in self.named_parameters(recurse=False):
+            if n.endswith("table"):
+                ts.append(n)
+            elif n.endswith("_w") or n.endswith("_w1") or n.endswith("_w2"):
+                ws.append(n)
+            else:
+                bs.append(n)
+        return ws, bs, ts
+
+    def init_weights(self):
+        ws, bs, ts = self.weight_names()
+        with torch.no_grad():
+            for n in ws + ts:
+                nn.init.trunc_normal_(getattr(self, n), std=.02)
+            for n in bs:
+                getattr(self, n).zero_()
+
+    # ---- reference state-dict keys ----
+    def _key_map(self):
+        m = []
+        for v in range(self.in_vars):
+            for s, C, in_dim, has_ds in self._stages:
+                base = f"layers_var.{v}.{s}."
+                for b in range(self.depths[s]):
+                    k, p = f"{base}blocks.{b}.", f"s{s}_b{b}_"
+                    m += [(k + "attn.relative_position_bias_table", p + "table", v),
+                          (k + "attn.relative_position_index", f"s{s}_index", None),
+                          (k + "attn.qkv.weight", p + "qkv_w", v), (k + "attn.qkv.bias", p + "qkv_b", v),
+                          (k + "attn.proj.weight", p + "proj_w", v), (k + "attn.proj.bias", p + "proj_b", v),
+                          (k + "mlp.fc1.weight", p + "fc1_w", v), (k + "mlp.fc1.bias", p + "fc1_b", v),
+                          (k + "mlp.fc2.weight", p + "fc2_w", v), (k + "mlp.fc2.bias", p + "fc2_b", v)]
+                if has_ds:
+                    m += [(base + "downsample.proj.weight", f"s{s}_ds_w5", v), (base + "downsample.proj.bias", f"s{s}_ds_b", v)]
+            m += [(f"proj_var.{v}.0.weight", "pv_w1", v), (f"proj_var.{v}.0.bias", "pv_b1", v),
+                  (f"proj_var.{v}.2.weight", "pv_w2", v), (f"proj_var.{v}.2.bias", "pv_b2", v)]
+        return m
+
+    def __getattr__(self, name):
+        # "<stage>_ds_w5": the (V, C, Cin, 1, 1, 1) view of the 1x1x1 conv weight, for the state dict
+        if name.endswith("_ds_w5"):
+            w = super().__getattr__(name[:-1])
+            return w.view(*w.shape, 1, 1, 1)
+        return super().__getattr__(name)
+
+    # ---- forward ----
+    def forward_tokens(self, x):
+        """x (N,V,C,T,H,W) -> channels-last tokens (N,V,T,H,W,E)."""
+        _check_no_dropout(self.training, drop_rate=self.drop_rate, attn_drop_rate=self.attn_drop_rate,
+                          drop_path_rate=self.drop_path_rate)
+        if x.shape[1] != self.in_vars or x.shape[2] != self.in_chans:
+            raise ValueError(f"Swin_3D: expected (N,{self.in_vars},{self.in_chans},T,H,W), got {tuple(x.shape)}")
+        t = None
+        for s, C, in_dim, has_ds in self._stages:
+            if has_ds:
+                if s == 0:
+                    t = ops.PatchEmbedLN.apply(x, getattr(self, f"s{s}_ds_w"), getattr(self, f"s{s}_ds_b"))
+                else:
+                    raise NotImplementedError("idee_amd Swin_3D: a width change between stages is not built "
+                                              "(reference default embed_dim is [16, 16])")
+            elif s == 0:
+                raise NotImplementedError("idee_amd Swin_3D: in_chans == embed_dim[0] (no patch embedding) is not built")
+            wsz = self.window_size[s]
+            shift = tuple(i // 2 for i in wsz)
+            index = getattr(self, f"s{s}_index")
+            for b in range(self.depths[s]):
+                p = f"s{s}_b{b}_"
+                t = ops.SwinBlock.apply(t, *(getattr(self, p + n) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w",
+                                                                           "fc1_b", "fc2_w", "fc2_b", "table")),
+                                        index, self.num_heads[s], wsz, (0, 0, 0) if b % 2 == 0 else shift, self.qk_scale)
+        return ops.ProjVar.apply(t, self.pv_w1, self.pv_b1, self.pv_w2, self.pv_b2)
+
+    def forward(self, x):
+        """x (N,V,C,T,H,W) -> (N,V,E,T,H,W), as Swin_3D.forward (Swin_3D.py:616-636)."""
+        return self.forward_tokens(x).permute(0, 1, 5, 2, 3, 4)

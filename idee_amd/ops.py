@@ -1,0 +1,385 @@
+"""torch.autograd.Function wrappers over the C-ABI (idee_amd/_lib.py -> libidee_hip.so).
+
+PyTorch is used here for device memory (torch.empty/zeros through the caching allocator),
+the current HIP stream, and the autograd graph; every numerical operation of the path is a
+call into libidee_hip.so.  Internal activation layout is channels-last tokens
+(N, V, T, H, W, C); parameters are V-stacked (leading V axis).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ptr
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------
+# PatchEmbed3D(k=1) + LN
+# ----------------------------------------------------------------------------------------
+class PatchEmbedLN(torch.autograd.Function):
+    """x (N,V,Cin,T,H,W) [reference layout], w (V,E,Cin), b (V,E)|None -> (N,V,T,H,W,E).
+    Reference: PatchEmbed3D.forward, models/encoder/Swin_3D.py:473-491, encoder/CNN_3D.py:44-71."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _f32c(x), _f32c(w)
+        b = _f32c(b) if b is not None else None
+        N, V, Cin, T, H, W = x.shape
+        E = w.shape[1]
+        y = torch.empty((N, V, T, H, W, E), device=x.device, dtype=torch.float32)
+        L.call("idee_patch_embed_ln_fwd", ptr(x), ptr(w), ptr(b), ptr(y), N, V, Cin, T * H * W, E, L.stream())
+        ctx.save_for_backward(x, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        N, V, Cin, T, H, W = x.shape
+        E = w.shape[1]
+        dy = _f32c(dy)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(b) if b is not None else None
+        L.call("idee_patch_embed_ln_bwd", ptr(x), ptr(w), ptr(b), ptr(dy), ptr(dw), ptr(db), N, V, Cin, T * H * W, E,
+               L.stream())
+        return None, dw, db
+
+
+# ----------------------------------------------------------------------------------------
+# fused Swin block
+# ----------------------------------------------------------------------------------------
+def clamp_window(extent, window, shift):
+    """get_window_size, Swin_3D.py:77-90."""
+    ws, ss = list(window), list(shift)
+    for i, n in enumerate(extent):
+        if n <= window[i]:
+            ws[i] = n
+            ss[i] = 0
+    return tuple(ws), tuple(ss)
+
+
+class SwinBlock(torch.autograd.Function):
+    """One SwinTransformerBlock3D on (N,V,D,H,W,C).  Reference: Swin_3D.py:224-287."""
+
+    @staticmethod
+    def forward(ctx, x, qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, table, index, heads, window, shift,
+                qk_scale):
+        x = _f32c(x)
+        params = [_f32c(t) for t in (qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b)]
+        table = _f32c(table)
+        N, V, D, H, W, Cc = x.shape
+        ws, ss = clamp_window((D, H, W), window, shift)
+        Nw = ws[0] * ws[1] * ws[2]
+        hd = Cc // heads
+        geom = L.SwinGeom(N, V, D, H, W, Cc, heads, fc1_w.shape[1], ws[0], ws[1], ws[2], ss[0], ss[1], ss[2],
+                          float(qk_scale) if qk_scale else float(hd) ** -0.5)
+        idx = index[:Nw, :Nw].contiguous()
+        dense = torch.empty((V, heads, Nw, Nw), device=x.device, dtype=torch.float32)
+        L.call("idee_relpos_bias_gather", ptr(table), ptr(idx), ptr(dense), V, table.shape[1], heads, Nw, L.stream())
+        y = torch.empty_like(x)
+        sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense))
+        L.call("idee_swin_block_fwd", ptr(x), ptr(y), C.byref(sp), C.byref(geom), L.stream())
+        ctx.save_for_backward(x, *params, table, idx, dense)
+        ctx.geom = geom
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *rest = ctx.saved_tensors
+        params, table, idx, dense = rest[:8], rest[8], rest[9], rest[10]
+        geom = ctx.geom
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        grads = [torch.zeros_like(t) for t in params]
+        ddense = torch.zeros_like(dense)
+        sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense))
+        sg = L.SwinGrads(*[ptr(t) for t in grads], ptr(ddense))
+        L.call("idee_swin_block_bwd", ptr(x), ptr(dy), ptr(dx), C.byref(sp), C.byref(sg), C.byref(geom), L.stream())
+        dtable = torch.zeros_like(table)
+        V, heads, Nw, _ = dense.shape
+        L.call("idee_relpos_bias_scatter", ptr(ddense), ptr(idx), ptr(dtable), V, table.shape[1], heads, Nw, L.stream())
+        return (dx, *grads, dtable, None, None, None, None, None)
+
+
+# ----------------------------------------------------------------------------------------
+# convolution layers (not autograd by themselves: composed by the Functions below)
+# ----------------------------------------------------------------------------------------
+class ConvLayer:
+    """One convolution of the path, described once (idee_conv_desc) and run fwd / dgrad / wgrad."""
+
+    def __init__(self, mode, B, wsets, T, H, W, Cin, Cout, xs, ys, relu):
+        self.desc = L.ConvDesc(mode, B, wsets, T, H, W, Cin, Cout, *xs, *ys, int(relu))
+        self.mode, self.B, self.wsets, self.Cin, self.Cout = mode, B, wsets, Cin, Cout
+        self.ntaps = 27 if mode == L.CONV_K333_REPLICATE else 18
+        self.packed_floats = L.load().idee_conv_packed_floats(C.byref(self.desc))
+        self.wgrad_floats = L.load().idee_conv_wgrad_floats(C.byref(self.desc))
+
+    def pack(self, w, want_fwd=True, want_dgrad=True):
+        dev = w.device
+        pf = torch.empty(self.packed_floats, device=dev, dtype=torch.float32) if want_fwd else None
+        pd = torch.empty(self.packed_floats, device=dev, dtype=torch.float32) if want_dgrad else None
+        L.call("idee_conv_pack_weights", C.byref(self.desc), ptr(w), ptr(pf), ptr(pd), L.stream())
+        return pf, pd
+
+    def fwd(self, x, pf, bias, y):
+        L.call("idee_conv_fwd", C.byref(self.desc), ptr(x), ptr(pf), ptr(bias), ptr(y), L.stream())
+
+    def dgrad(self, dy, pd, relu_ref, dx, accumulate=False):
+        L.call("idee_conv_dgrad", C.byref(self.desc), ptr(dy), ptr(pd), ptr(relu_ref), ptr(dx), int(accumulate), L.stream())
+
+    def wgrad(self, x, dy, w_like, want_bias=True):
+        """-> (dw in the reference layout of w_like, dbias (wsets, Cout) | None)."""
+        dev = x.device
+        dwp = torch.zeros(self.wgrad_floats, device=dev, dtype=torch.float32)
+        cpad = ((self.Cout + 15) // 16) * 16
+        dbp = torch.zeros((self.wsets, cpad), device=dev, dtype=torch.float32) if want_bias else None
+        L.call("idee_conv_wgrad", C.byref(self.desc), ptr(x), ptr(dy), ptr(dwp), ptr(dbp), L.stream())
+        dw = torch.empty_like(w_like)
+        L.call("idee_conv_unpack_wgrad", C.byref(self.desc), ptr(dwp), ptr(dw), L.stream())
+        db = dbp[:, : self.Cout].contiguous() if want_bias else None
+        return dw, db
+
+
+def _cl_strides(T, H, W, Cc):
+    """(sB, sT, sH, sW, sG) of a contiguous (B, T, H, W, Cc) tensor with 16-channel groups."""
+    return (T * H * W * Cc, H * W * Cc, W * Cc, Cc, 16)
+
+
+class ProjVar(torch.autograd.Function):
+    """Conv3d 3^3 replicate -> ReLU -> Conv3d 3^3 replicate, per variable.
+    x (N,V,T,H,W,C); w1, w2 (V,C,C,3,3,3); b1, b2 (V,C).  Reference: Swin_3D.py:586-592."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x, w1, b1, w2, b2 = (_f32c(t) for t in (x, w1, b1, w2, b2))
+        N, V, T, H, W, Cc = x.shape
+        s = _cl_strides(T, H, W, Cc)
+        c1 = ConvLayer(L.CONV_K333_REPLICATE, N * V, V, T, H, W, Cc, Cc, s, s, True)
+        c2 = ConvLayer(L.CONV_K333_REPLICATE, N * V, V, T, H, W, Cc, Cc, s, s, False)
+        p1f, p1d = c1.pack(w1)
+        p2f, p2d = c2.pack(w2)
+        a1 = torch.empty_like(x)
+        y = torch.empty_like(x)
+        c1.fwd(x, p1f, b1, a1)
+        c2.fwd(a1, p2f, b2, y)
+        ctx.save_for_backward(x, a1, w1, w2, p1d, p2d)
+        ctx.convs = (c1, c2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a1, w1, w2, p1d, p2d = ctx.saved_tensors
+        c1, c2 = ctx.convs
+        dy = _f32c(dy)
+        dw2, db2 = c2.wgrad(a1, dy, w2)
+        da1 = torch.zeros_like(a1)
+        c2.dgrad(dy, p2d, a1, da1)              # masked by ReLU'(a1)
+        dw1, db1 = c1.wgrad(x, da1, w1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x)
+            c1.dgrad(da1, p1d, None, dx)
+        return dx, dw1, db1, dw2, db2
+
+
+class ClassifierHeads(torch.autograd.Function):
+    """The whole classifier: joint head on the V*C channels + V per-variable heads, each
+    conv(2,3,3)s(2,1,1) -> ReLU -> conv -> ReLU -> conv -> squeeze.  Reference:
+    classifier/CNN_3D.py:112-139, Layer_v.forward :43-58.
+      zq (N,V,T,H,W,C)
+      joint: jw1 (D,V*C,2,3,3) jb1 (D) jw2 (D,D,2,3,3) jb2 (D) jw3 (1,D,2,3,3) jb3 (1),  D = V*dim
+      heads: hw1 (V,dim,C,2,3,3) hb1 (V,dim) hw2 (V,dim,dim,..) hb2 hw3 (V,1,dim,..) hb3 (V,1)
+    -> z (N,1,H,W), y (N,V,H,W)"""
+
+    @staticmethod
+    def forward(ctx, zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3):
+        ts = [_f32c(t) for t in (zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3)]
+        zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3 = ts
+        N, V, T, H, W, Cc = zq.shape
+        dim = hw1.shape[1]
+        Dj = jw1.shape[0]
+        T1 = (T - 2) // 2 + 1
+        T2 = (T1 - 2) // 2 + 1
+        T3 = (T2 - 2) // 2 + 1
+        if T3 != 1:
+            raise L.IdeeHipError(f"classifier: T={T} does not reduce to one step (the reference squeezes dim 2); T must be 8")
+        dev = zq.device
+        K = L.CONV_K233_S2_ZERO
+        # joint head: channel groups of conv1's input are the V slices of zq
+        j1 = ConvLayer(K, N, 1, T, H, W, V * Cc, Dj, (V * T * H * W * Cc, H * W * Cc, W * Cc, Cc, T * H * W * Cc),
+                       _cl_strides(T1, H, W, Dj), True)
+        j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True)
+        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (H * W, H * W, W, 1, 1), False)
+        h1 = ConvLayer(K, N * V, V, T, H, W, Cc, dim, _cl_strides(T, H, W, Cc), _cl_strides(T1, H, W, dim), True)
+        h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True)
+        h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (H * W, H * W, W, 1, 1), False)
+        convs = (j1, j2, j3, h1, h2, h3)
+        weights = (jw1, jw2, jw3, hw1, hw2, hw3)
+        packs = [c.pack(w) for c, w in zip(convs, weights)]
+        ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=torch.float32)
+        ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=torch.float32)
+        z = torch.empty((N, 1, H, W), device=dev, dtype=torch.float32)
+        ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=torch.float32)
+        ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=torch.float32)
+        y = torch.empty((N, V, H, W), device=dev, dtype=torch.float32)
+        j1.fwd(zq, packs[0][0], jb1, ja1)
+        j2.fwd(ja1, packs[1][0], jb2, ja2)
+        j3.fwd(ja2, packs[2][0], jb3, z)
+        h1.fwd(zq, packs[3][0], hb1, ha1)
+        h2.fwd(ha1, packs[4][0], hb2, ha2)
+        h3.fwd(ha2, packs[5][0], hb3, y)
+        ctx.save_for_backward(zq, ja1, ja2, ha1, ha2, *weights, *[p[1] for p in packs])
+        ctx.convs = convs
+        return z, y
+
+    @staticmethod
+    def backward(ctx, dz, dy):
+        saved = ctx.saved_tensors
+        zq, ja1, ja2, ha1, ha2 = saved[:5]
+        jw1, jw2, jw3, hw1, hw2, hw3 = saved[5:11]
+        pd = saved[11:17]
+        j1, j2, j3, h1, h2, h3 = ctx.convs
+        dz, dy = _f32c(dz), _f32c(dy)
+        # joint head
+        djw3, djb3 = j3.wgrad(ja2, dz, jw3)
+        dja2 = torch.empty_like(ja2)
+        j3.dgrad(dz, pd[2], ja2, dja2)
+        djw2, djb2 = j2.wgrad(ja1, dja2, jw2)
+        dja1 = torch.empty_like(ja1)
+        j2.dgrad(dja2, pd[1], ja1, dja1)
+        djw1, djb1 = j1.wgrad(zq, dja1, jw1)
+        # per-variable heads
+        dhw3, dhb3 = h3.wgrad(ha2, dy, hw3)
+        dha2 = torch.empty_like(ha2)
+        h3.dgrad(dy, pd[5], ha2, dha2)
+        dhw2, dhb2 = h2.wgrad(ha1, dha2, hw2)
+        dha1 = torch.empty_like(ha1)
+        h2.dgrad(dha2, pd[4], ha1, dha1)
+        dhw1, dhb1 = h1.wgrad(zq, dha1, hw1)
+        dzq = None
+        if ctx.needs_input_grad[0]:
+            dzq = torch.empty_like(zq)
+            j1.dgrad(dja1, pd[0], None, dzq)
+            h1.dgrad(dha1, pd[3], None, dzq, accumulate=True)
+        return (dzq, djw1, djb1.reshape(-1), djw2, djb2.reshape(-1), djw3, djb3.reshape(-1), dhw1, dhb1, dhw2, dhb2, dhw3,
+                dhb3)
+
+
+# ----------------------------------------------------------------------------------------
+# LFQ
+# ----------------------------------------------------------------------------------------
+class LFQQuantize(torch.autograd.Function):
+    """z (..., E) tokens -> z_q (..., E), indices int64 (...), aux loss ().  Reference:
+    LFQ.forward, models/codebook/LFQ.py:183-307."""
+
+    @staticmethod
+    def forward(ctx, z, w_in, b_in, w_out, b_out, codebook_size, training, w_entropy, gamma, w_commit):
+        z, w_in, b_in, w_out, b_out = (_f32c(t) for t in (z, w_in, b_in, w_out, b_out))
+        E = z.shape[-1]
+        M = z.numel() // E
+        dev = z.device
+        zq = torch.empty_like(z)
+        idx = torch.empty(z.shape[:-1], device=dev, dtype=torch.int64)
+        stats = torch.zeros(4 + codebook_size, device=dev, dtype=torch.float32)
+        ws = torch.empty(L.load().idee_lfq_workspace_floats(M, codebook_size), device=dev, dtype=torch.float32)
+        L.call("idee_lfq_fwd", ptr(z), ptr(w_in), ptr(b_in), ptr(w_out), ptr(b_out), ptr(zq), ptr(idx), ptr(stats), ptr(ws),
+               M, E, codebook_size, int(training), w_entropy, gamma, w_commit, L.stream())
+        ctx.save_for_backward(z, w_in, b_in, w_out, stats)
+        ctx.cfg = (M, E, codebook_size, w_entropy, gamma, w_commit)
+        ctx.mark_non_differentiable(idx)
+        return zq, idx, stats[0]
+
+    @staticmethod
+    def backward(ctx, dzq, _didx, dloss):
+        z, w_in, b_in, w_out, stats = ctx.saved_tensors
+        M, E, K, w_entropy, gamma, w_commit = ctx.cfg
+        dzq = _f32c(dzq) if dzq is not None else torch.zeros_like(z)
+        gl = _f32c(dloss).reshape(1) if dloss is not None else torch.zeros(1, device=z.device)
+        dz = torch.empty_like(z)
+        dw_in, db_in, dw_out = torch.zeros_like(w_in), torch.zeros_like(b_in), torch.zeros_like(w_out)
+        db_out = torch.zeros(E, device=z.device, dtype=torch.float32)
+        L.call("idee_lfq_bwd", ptr(z), ptr(dzq), ptr(w_in), ptr(b_in), ptr(w_out), ptr(stats), ptr(gl), ptr(dz), ptr(dw_in),
+               ptr(db_in), ptr(dw_out), ptr(db_out), M, E, K, w_entropy, gamma, w_commit, L.stream())
+        return dz, dw_in, db_in, dw_out, db_out, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------
+def bce_class_counts(target, valid=None):
+    """torch.histc(target[valid], bins=2) as a device tensor (2,) — models/losses.py:80,115."""
+    target = _f32c(target)
+    valid = _f32c(valid) if valid is not None else None
+    counts = torch.empty(2, device=target.device, dtype=torch.float32)
+    L.call("idee_bce_class_counts", ptr(target), ptr(valid), target.numel(), ptr(counts), L.stream())
+    return counts
+
+
+class WeightedBCE(torch.autograd.Function):
+    """pred (P, M...) logits sharing one target (M...) -> (P,) losses.  valid (M...)|None.
+    Reference: BCE_loss_synthetic / BCE_loss, models/losses.py:64-124."""
+
+    @staticmethod
+    def forward(ctx, pred, target, valid, counts):
+        pred, target = _f32c(pred), _f32c(target)
+        valid = _f32c(valid) if valid is not None else None
+        P = pred.shape[0]
+        M = target.numel()
+        assert pred.numel() == P * M
+        out = torch.empty(P + 1, device=pred.device, dtype=torch.float32)
+        ws = torch.empty(L.load().idee_bce_workspace_floats(P, M), device=pred.device, dtype=torch.float32)
+        L.call("idee_bce_weighted_fwd", ptr(pred), ptr(target), ptr(valid), ptr(counts), ptr(out), ptr(ws), P, M, L.stream())
+        ctx.save_for_backward(pred, target, valid, counts, out)
+        return out[:P]
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, valid, counts, out = ctx.saved_tensors
+        P, M = pred.shape[0], target.numel()
+        gout = _f32c(gout)
+        dpred = torch.empty_like(pred)
+        denom = out[P:]
+        L.call("idee_bce_weighted_bwd", ptr(pred), ptr(target), ptr(valid), ptr(counts), ptr(gout), ptr(denom), ptr(dpred), P,
+               M, L.stream())
+        return dpred, None, None, None
+
+
+class AnomalyL1(torch.autograd.Function):
+    """Masked L1 of z_q (N,V,T,H,W,E) against the code-0 vector outside extremes -> (num, den)
+    so that data-parallel ranks can all-reduce both before dividing.  Reference:
+    Anomaly_L1_loss(_synthetic), models/losses.py:15-61, :127-168.  Returns loss = num/den."""
+
+    @staticmethod
+    def forward(ctx, zq, mask_extreme, mask_valid, vq0):
+        zq, mask_extreme, vq0 = _f32c(zq), _f32c(mask_extreme), _f32c(vq0).reshape(-1)
+        mask_valid = _f32c(mask_valid) if mask_valid is not None else None
+        N, V, T, H, W, E = zq.shape
+        out = torch.empty(2, device=zq.device, dtype=torch.float32)
+        ws = torch.empty(L.load().idee_anomaly_workspace_floats(N * V * T * H * W), device=zq.device, dtype=torch.float32)
+        L.call("idee_anomaly_l1_fwd", ptr(zq), ptr(mask_extreme), ptr(mask_valid), ptr(vq0), ptr(out), ptr(ws), N, V, T, H * W,
+               E, L.stream())
+        ctx.save_for_backward(zq, mask_extreme, mask_valid, vq0, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        zq, mask_extreme, mask_valid, vq0, out = ctx.saved_tensors
+        N, V, T, H, W, E = zq.shape
+        g = _f32c(g).reshape(1)
+        dzq = torch.empty_like(zq)
+        L.call("idee_anomaly_l1_bwd", ptr(zq), ptr(mask_extreme), ptr(mask_valid), ptr(vq0), ptr(g), ptr(out[1:]), ptr(dzq), N,
+               V, T, H * W, E, L.stream())
+        return dzq, None, None, None
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """In-place torch.optim.Adam update of the flat buffers (train_synthetic.py:127-129)."""
+    L.call("idee_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, int(step),
+           grad_scale, L.stream())

@@ -1,0 +1,196 @@
+/*
+ * idee_hip.h — C-ABI of libidee_hip.so: the MI355X (gfx950) kernels behind the IDEE
+ * encoder -> codebook -> classifier hot path.
+ *
+ * The reference (HakamShams/IDEE) is pure PyTorch: it has no native extension and no FFI
+ * surface to mirror.  The entry points below are therefore the ones a binding for this path
+ * WOULD bind — one per fused unit of the path — and each cites the reference code it replaces
+ * (paths relative to the reference repo).  The reference-side binding is the ctypes stub in
+ * INTEGRATION.md; idee_amd/_lib.py is the one this repo ships.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is a DEVICE pointer to contiguous f32 unless noted;
+ *   - activations are channels-last tokens: (N, V, T, H, W, C)  [reference: (N, V, C, T, H, W)];
+ *   - the V per-variable weight sets are stacked on a leading V axis; batch item b = n*V + v
+ *     uses weight set b % V;
+ *   - the caller allocates every output and workspace (size queries are provided);
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); no call
+ *     allocates, synchronises or touches host memory asynchronously;
+ *   - return value 0 = ok; non-zero = IDEE_ERR_*; message via idee_last_error() (thread-local);
+ *   - gradient outputs named d* that are documented "accumulate" must be zero-initialised by
+ *     the caller (they are added to with float atomics); all others are overwritten;
+ *   - re-entrant: no global mutable state.
+ */
+#ifndef IDEE_HIP_H
+#define IDEE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* idee_stream_t; /* hipStream_t */
+
+enum { IDEE_OK = 0, IDEE_ERR_INVALID_ARG = 1, IDEE_ERR_UNSUPPORTED = 2, IDEE_ERR_LAUNCH = 3 };
+
+const char* idee_version(void);
+const char* idee_last_error(void);
+/* IDEE_OK iff HIP device `dev` is a gfx950. */
+int idee_check_device(int dev);
+
+/* ------------------------------------------------------------------------------------------
+ * PatchEmbed3D with patch_size (1,1,1) + non-affine LayerNorm over channels.
+ * Replaces PatchEmbed3D.forward, models/encoder/Swin_3D.py:473-491 (bias) and
+ * models/encoder/CNN_3D.py:44-71 (b == NULL).
+ *   x (N, V, Cin, L) [L = T*H*W, the reference input layout], w (V, E, Cin), b (V, E) | NULL
+ *   y (N, V, L, E)
+ * bwd: dw (V, E, Cin), db (V, E) | NULL accumulate.  No dx: x is the model input.
+ * ---------------------------------------------------------------------------------------- */
+int idee_patch_embed_ln_fwd(const float* x, const float* w, const float* b, float* y, int N, int V, int Cin, long L,
+                            int E, idee_stream_t stream);
+int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dw, float* db, int N,
+                            int V, int Cin, long L, int E, idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One fused SwinTransformerBlock3D (norm1, pad, cyclic shift, window partition, WindowAttention3D
+ * with relative-position bias and shift mask, window reverse, un-shift, crop, residual, norm2,
+ * MLP with erf-GELU, residual).  Replaces SwinTransformerBlock3D.forward, Swin_3D.py:224-287,
+ * WindowAttention3D.forward :145-178, window_partition/reverse :45-74, compute_mask :340-352,
+ * Mlp.forward :36-42.  Backward recomputes from x (nothing else is saved).
+ *   x, y, dy, dx: (N, V, D, H, W, C)
+ * Window and shift are the values AFTER get_window_size clamping (Swin_3D.py:77-90).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int N, V;       /* batch, variables (weight sets) */
+  int D, H, W;    /* token grid */
+  int C, heads, hidden;
+  int wd, wh, ww; /* window (clamped) */
+  int sd, sh, sw; /* shift (clamped) */
+  float scale;    /* qk scale: head_dim^-0.5 unless overridden (Swin_3D.py:113) */
+} idee_swin_geom;
+
+typedef struct {
+  const float *qkv_w, *qkv_b;   /* (V, 3C, C), (V, 3C)       attn.qkv    */
+  const float *proj_w, *proj_b; /* (V, C, C), (V, C)         attn.proj   */
+  const float *fc1_w, *fc1_b;   /* (V, hidden, C), (V, hidden) mlp.fc1   */
+  const float *fc2_w, *fc2_b;   /* (V, C, hidden), (V, C)    mlp.fc2     */
+  const float* rel_bias;        /* (V, heads, Nw, Nw) dense bias from idee_relpos_bias_gather */
+} idee_swin_params;
+
+typedef struct { /* all accumulate */
+  float *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *rel_bias;
+} idee_swin_grads;
+
+int idee_swin_block_fwd(const float* x, float* y, const idee_swin_params* p, const idee_swin_geom* g,
+                        idee_stream_t stream);
+int idee_swin_block_bwd(const float* x, const float* dy, float* dx, const idee_swin_params* p, const idee_swin_grads* d,
+                        const idee_swin_geom* g, idee_stream_t stream);
+
+/* relative_position_bias_table[relative_position_index] (Swin_3D.py:158-162):
+ * table (V, table_len, heads), index (Nw, Nw) int64 -> dense (V, heads, Nw, Nw);
+ * scatter: dtable accumulates. */
+int idee_relpos_bias_gather(const float* table, const int64_t* index, float* dense, int V, int table_len, int heads,
+                            int Nw, idee_stream_t stream);
+int idee_relpos_bias_scatter(const float* ddense, const int64_t* index, float* dtable, int V, int table_len, int heads,
+                             int Nw, idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3-D convolutions as implicit GEMM on the f32 MFMA.
+ *   IDEE_CONV_K333_REPLICATE: Conv3d(k=3, s=1, p=1, padding_mode='replicate')
+ *       proj_var (Swin_3D.py:586-592, encoder/CNN_3D.py:185-191), conv_block convs (:99-106)
+ *   IDEE_CONV_K233_S2_ZERO:   Conv3d((2,3,3), (2,1,1), (0,1,1)) zero padding
+ *       classifier heads (classifier/CNN_3D.py:38-40, :83-85)
+ * The descriptor speaks about the FORWARD conv: x (input, extent T,H,W) -> y (output extent
+ * To,H,W with To = T or (T-2)/2+1).  Tensors are addressed by float strides so one kernel
+ * serves per-variable convs (B = N*V, wsets = V) and the joint head whose 16-channel groups
+ * are the V slices of z_q (x_sG = T*H*W*16).  Channel group g, channel c: + g*sG + c.
+ * Cin must be a multiple of 16; Cout a multiple of 16, or 1 (final class conv).
+ * ---------------------------------------------------------------------------------------- */
+enum { IDEE_CONV_K333_REPLICATE = 0, IDEE_CONV_K233_S2_ZERO = 1 };
+
+typedef struct {
+  int mode;
+  int B, wsets; /* batch items; weight sets (item b uses set b % wsets) */
+  int T, H, W;  /* input extent */
+  int Cin, Cout;
+  long x_sB, x_sT, x_sH, x_sW, x_sG;
+  long y_sB, y_sT, y_sH, y_sW, y_sG;
+  int relu; /* fwd: ReLU after the bias */
+} idee_conv_desc;
+
+/* floats in a packed (fragment-ordered) weight buffer / in a packed weight-gradient buffer */
+long idee_conv_packed_floats(const idee_conv_desc* d);
+long idee_conv_wgrad_floats(const idee_conv_desc* d);
+/* w: reference layout (wsets, Cout, Cin, kt, kh, kw) -> fragment order for fwd and/or dgrad */
+int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, float* packed_fwd, float* packed_dgrad,
+                           idee_stream_t stream);
+/* bias: (wsets, Cout) | NULL */
+int idee_conv_fwd(const idee_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                  idee_stream_t stream);
+/* dx = conv^T(dy) [* (relu_ref > 0) if relu_ref != NULL; same layout as x]; accumulate != 0: dx += ...
+ * REPLICATE mode: dx must be zero-initialised (edge columns are accumulated with atomics) and
+ * accumulate must be 0. */
+int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
+                    float* dx, int accumulate, idee_stream_t stream);
+/* dw_packed (wsets, taps, Cin, CoutPad) and dbias (wsets, CoutPad) | NULL accumulate */
+int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
+                    idee_stream_t stream);
+/* packed weight gradient -> reference layout (wsets, Cout, Cin, kt, kh, kw) (overwrites) */
+int idee_conv_unpack_wgrad(const idee_conv_desc* d, const float* dw_packed, float* dw, idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Lookup-free quantisation with projections (dim -> log2 K -> dim), straight-through gradient,
+ * entropy + commitment auxiliary loss.  Replaces LFQ.forward, models/codebook/LFQ.py:183-307.
+ *   z, zq, dz, dzq: (M, E) tokens; indices int64 (M)
+ *   w_in (D, E), b_in (D), w_out (E, D), b_out (E),  D = log2(codebook_size)
+ *   stats (4 + K floats): [aux loss, per-sample entropy, batch entropy, commit, avg prob[K]]
+ *   workspace: idee_lfq_workspace_floats(M, K) floats
+ * bwd: gloss = device pointer to d(loss)/d(aux loss); dw_in, db_in, dw_out, db_out accumulate.
+ * ---------------------------------------------------------------------------------------- */
+long idee_lfq_workspace_floats(long M, int codebook_size);
+int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out, float* zq,
+                 int64_t* indices, float* stats, float* workspace, long M, int E, int codebook_size, int training,
+                 float w_entropy, float gamma, float w_commit, idee_stream_t stream);
+int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const float* b_in, const float* w_out,
+                 const float* stats, const float* gloss, float* dz, float* dw_in, float* db_in, float* dw_out,
+                 float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma, float w_commit,
+                 idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses (models/losses.py).
+ * BCE with logits weighted by log(1.1 + class_freq^-0.5), class counts from torch.histc(bins=2)
+ * semantics: BCE_loss_synthetic :98-124 (valid == NULL) and BCE_loss :64-95 (valid mask).
+ *   counts (2) <- idee_bce_class_counts(target (M), valid (M) | NULL)
+ *   pred (P, M): P predictions sharing one target; loss (P + 1): P means then the denominator
+ * ---------------------------------------------------------------------------------------- */
+int idee_bce_class_counts(const float* target, const float* valid, long M, float* counts, idee_stream_t stream);
+long idee_bce_workspace_floats(int P, long M);
+int idee_bce_weighted_fwd(const float* pred, const float* target, const float* valid, const float* counts, float* loss,
+                          float* workspace, int P, long M, idee_stream_t stream);
+/* gout (P): upstream gradients; denom (1): loss[P] from the forward */
+int idee_bce_weighted_bwd(const float* pred, const float* target, const float* valid, const float* counts,
+                          const float* gout, const float* denom, float* dpred, int P, long M, idee_stream_t stream);
+
+/* Masked L1 pulling z_q to the "normal" code outside extremes: Anomaly_L1_loss_synthetic
+ * :127-168 (mask_valid == NULL) and Anomaly_L1_loss :15-61.
+ *   zq (N, V, T, HW, E); mask_extreme (N, HW); mask_valid (N, T, HW) | NULL; vq0 (E)
+ *   out (2): [loss, denominator]; workspace idee_anomaly_workspace_floats(N*V*T*HW) */
+long idee_anomaly_workspace_floats(long tokens);
+int idee_anomaly_l1_fwd(const float* zq, const float* mask_extreme, const float* mask_valid, const float* vq0,
+                        float* out, float* workspace, int N, int V, int T, long HW, int E, idee_stream_t stream);
+int idee_anomaly_l1_bwd(const float* zq, const float* mask_extreme, const float* mask_valid, const float* vq0,
+                        const float* gout, const float* denom, float* dzq, int N, int V, int T, long HW, int E,
+                        idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * torch.optim.Adam step (train_synthetic.py:127-129,205) over one flat parameter buffer.
+ * g is multiplied by grad_scale first (1/world for data-parallel averaging).
+ * ---------------------------------------------------------------------------------------- */
+int idee_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float grad_scale, idee_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDEE_HIP_H */
