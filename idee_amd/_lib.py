@@ -121,5 +121,24 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-entry-point timing with HIP events on the launch stream (bench.py): name -> [(start, end), ...]
+_event_log = None
+
+
+def set_event_log(names):
+    """names: iterable of C-ABI entry points to bracket with timing events, or None to stop."""
+    global _event_log
+    _event_log = {n: [] for n in names} if names else None
+    return _event_log
+
+
 def call(name, *args):
+    log = _event_log
+    if log is not None and name in log:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(getattr(load(), name)(*args), name)
+        e1.record()
+        log[name].append((e0, e1, args))
+        return
     check(getattr(load(), name)(*args), name)

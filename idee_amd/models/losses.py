@@ -45,7 +45,7 @@ class Anomaly_L1_loss_synthetic(nn.Module):
         self.n_dynamic, self.delta_t, self.dim = n_dynamic, delta_t, dim
 
     def forward(self, pred, mask_extreme, vq_0):
-        return ops.AnomalyL1.apply(_tokens_last(pred), mask_extreme.float(), None, vq_0.detach())
+        return ops.AnomalyL1.apply(_tokens_last(pred), mask_extreme.float(), None, vq_0.detach())[0]
 
 
 class Anomaly_L1_loss(nn.Module):
@@ -56,4 +56,4 @@ class Anomaly_L1_loss(nn.Module):
         self.n_dynamic, self.delta_t, self.dim = n_dynamic, delta_t, dim
 
     def forward(self, pred, mask_extreme, mask_valid, vq_0):
-        return ops.AnomalyL1.apply(_tokens_last(pred), mask_extreme.float(), mask_valid.float(), vq_0.detach())
+        return ops.AnomalyL1.apply(_tokens_last(pred), mask_extreme.float(), mask_valid.float(), vq_0.detach())[0]

@@ -353,8 +353,9 @@ class WeightedBCE(torch.autograd.Function):
 
 class AnomalyL1(torch.autograd.Function):
     """Masked L1 of z_q (N,V,T,H,W,E) against the code-0 vector outside extremes -> (num, den)
-    so that data-parallel ranks can all-reduce both before dividing.  Reference:
-    Anomaly_L1_loss(_synthetic), models/losses.py:15-61, :127-168.  Returns loss = num/den."""
+    Reference: Anomaly_L1_loss(_synthetic), models/losses.py:15-61, :127-168.
+    Returns (loss = num/den, den); den lets data-parallel ranks renormalise by the global
+    denominator (parallel.global_anomaly_scale)."""
 
     @staticmethod
     def forward(ctx, zq, mask_extreme, mask_valid, vq0):
@@ -366,10 +367,12 @@ class AnomalyL1(torch.autograd.Function):
         L.call("idee_anomaly_l1_fwd", ptr(zq), ptr(mask_extreme), ptr(mask_valid), ptr(vq0), ptr(out), ptr(ws), N, V, T, H * W,
                E, L.stream())
         ctx.save_for_backward(zq, mask_extreme, mask_valid, vq0, out)
-        return out[0]
+        den = out[1]
+        ctx.mark_non_differentiable(den)
+        return out[0], den
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gden):
         zq, mask_extreme, mask_valid, vq0, out = ctx.saved_tensors
         N, V, T, H, W, E = zq.shape
         g = _f32c(g).reshape(1)

@@ -1,0 +1,67 @@
+"""Adam over one flat parameter / gradient buffer (idee_adam_step), with torch.optim.Adam's math
+(train_synthetic.py:127-129: L2 weight decay folded into the gradient, not AdamW).
+
+The parameters of the model are re-pointed to views of one flat f32 buffer and their `.grad`s to
+views of one flat gradient buffer, so (a) the optimizer step is ONE kernel instead of ~40 tiny ones
+and (b) the data-parallel gradient exchange is ONE all-reduce of that buffer (parallel.py)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class Adam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_p[off:off + k].view(p.shape)
+                p.grad = self.flat_g[off:off + k].view(p.shape)
+                off += k
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.step_count = 0
+        self.grad_scale = 1.0      # parallel.py sets 1/world after a SUM all-reduce
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Zero the flat gradient buffer.  `set_to_none` is accepted for call compatibility with
+        train_synthetic.py:175 but the views are kept (autograd accumulates into them)."""
+        self.flat_g.zero_()
+        for p, g in zip(self.params, self._grad_views()):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def _grad_views(self):
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            yield self.flat_g[off:off + k].view(p.shape)
+            off += k
+
+    @torch.no_grad()
+    def step(self):
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
+                      float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count, float(self.grad_scale))
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
+                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0].update(sd["param_groups"][0])
