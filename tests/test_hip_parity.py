@@ -42,7 +42,7 @@ def gclose(name, got, ref, rtol=1e-3, floor=1e-4):
     close(name, got, ref, atol=max(1e-6, floor * float(ref[fin].abs().max()) if fin.any() else 1e-6), rtol=rtol)
 
 
-def gclose_relu(name, got, ref, rtol=1e-3, floor=1e-4, max_outlier_frac=0.01, max_rel_l2=3e-3):
+def gclose_relu(name, got, ref, rtol=1e-3, floor=1e-4, max_outlier_frac=0.01, max_rel_l2=1e-2):
     """Gradient check for paths with a ReLU between the op and the loss, at sizes (~1e6 activations) where
     some pre-activation lies within fp32 rounding of zero (|a| ~ 1e-7 was observed in the oracle): that
     ReLU mask may legitimately differ under another summation order and changes the gradient in the
