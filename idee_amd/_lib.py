@@ -45,8 +45,8 @@ _SIGS = {
     "idee_check_device": (_I, [_I]),
     "idee_patch_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
     "idee_patch_embed_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
-    "idee_swin_block_fwd": (_I, [_P, _P, C.POINTER(SwinParams), C.POINTER(SwinGeom), _P]),
-    "idee_swin_block_bwd": (_I, [_P, _P, _P, C.POINTER(SwinParams), C.POINTER(SwinGrads), C.POINTER(SwinGeom), _P]),
+    "idee_swin_block_fwd": (_I, [_P, _P, _P, C.POINTER(SwinParams), C.POINTER(SwinGeom), _P]),
+    "idee_swin_block_bwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(SwinParams), C.POINTER(SwinGrads), C.POINTER(SwinGeom), _P]),
     "idee_relpos_bias_gather": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "idee_relpos_bias_scatter": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "idee_conv_packed_floats": (_L, [C.POINTER(ConvDesc)]),

@@ -1,0 +1,1017 @@
+// Fused Video-Swin block on the f32 MFMA (v_mfma_f32_16x16x4_f32) for gfx950.
+//
+// Replaces, for one SwinTransformerBlock3D (reference models/encoder/Swin_3D.py:224-287):
+//   norm1 -> zero-pad -> roll(-shift) -> window_partition -> WindowAttention3D (:145-178)
+//   -> window_reverse -> roll(+shift) -> crop -> +shortcut -> norm2 -> Mlp (:36-42) -> +residual
+// with no intermediate tensor: shift / pad / partition are index arithmetic on the channels-last
+// token tensor, the 0/-100 shift mask (compute_mask :340-352) comes from coordinates.
+//
+// "Token layout" (TL): a wave owns 64 tokens = 4 column blocks of 16; lane (j = lane&15,
+// kq = lane>>4) holds, for token 16*mt + j, the 4 channels sigma(4kq..4kq+3) of every
+// 16-channel chunk — exactly the B-operand layout of the 16x16x4 MFMA *and* its D layout
+// (rows = channels, cols = tokens).  A linear layer Y = W X is therefore a chain of MFMAs whose
+// A operands are weight fragments held in registers and whose outputs feed the next layer
+// with NO data movement.  Attention scores S[key][query] = K Q^T come out with keys on rows,
+// i.e. already as the B operand of P.V; only V needs a transpose through LDS.  The head split
+// uses a channel permutation sigma that puts each head's channels on whole k-steps.
+#include "common.h"
+
+namespace {
+
+using namespace idee;
+
+struct Geom {
+  int V, D, H, W, Dp, Hp, Wp;
+  int wd, wh, ww, sd, sh, sw;
+  int nWh, nWw, nWin;   // windows per batch item
+  int items;            // window groups (64 tokens) per batch item
+  int shifted;
+  float scale;
+};
+
+constexpr float kLnEps = 1e-5f;
+constexpr int MT = 4;   // 16-token column blocks per wave
+constexpr int VS = 68;  // LDS image row stride in floats (64 tokens + pad); rows stay 16-byte aligned
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float gelu(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float a) {
+  return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.39894228040143268f * __expf(-0.5f * a * a);
+}
+
+// channel permutation inside a 16-chunk: position i = 4*kq + r  ->  channel.  HPC heads per chunk.
+template <int HPC>
+__device__ __forceinline__ int sig(int i) {
+  constexpr int sp = 4 / HPC;
+  const int kq = i >> 2, r = i & 3;
+  return (r / sp) * (16 / HPC) + kq * sp + (r % sp);
+}
+
+struct Tok {
+  long off;
+  int rid;
+  bool valid;
+};
+
+// token tau (0..63) of work item `item` of batch item b
+template <int NW>
+__device__ __forceinline__ Tok locate(const Geom& g, int b, int item, int tau, int C) {
+  constexpr int G = 64 / NW;
+  Tok t;
+  const int gi = tau / NW, i = tau % NW;
+  const int wl = item * G + gi;
+  const bool active = (item < g.items) && (wl < g.nWin);
+  const int wlc = active ? wl : 0;
+  const int iwd = wlc / (g.nWh * g.nWw), r = wlc % (g.nWh * g.nWw);
+  const int iwh = r / g.nWw, iww = r % g.nWw;
+  const int dt = i / (g.wh * g.ww), r2 = i % (g.wh * g.ww);
+  const int dh = r2 / g.ww, dw = r2 % g.ww;
+  const int pd = iwd * g.wd + dt, ph = iwh * g.wh + dh, pw = iww * g.ww + dw;   // rolled frame
+  auto axis = [](int p, int P, int w, int s) { return s == 0 ? 2 : (int)(p >= P - w) + (int)(p >= P - s); };
+  t.rid = axis(pd, g.Dp, g.wd, g.sd) * 9 + axis(ph, g.Hp, g.wh, g.sh) * 3 + axis(pw, g.Wp, g.ww, g.sw);
+  int sd_ = pd + g.sd, sh_ = ph + g.sh, sw_ = pw + g.sw;                         // un-rolled frame
+  if (sd_ >= g.Dp) sd_ -= g.Dp;
+  if (sh_ >= g.Hp) sh_ -= g.Hp;
+  if (sw_ >= g.Wp) sw_ -= g.Wp;
+  t.valid = active && sd_ < g.D && sh_ < g.H && sw_ < g.W;
+  t.off = ((((long)b * g.D + sd_) * g.H + sh_) * g.W + sw_) * C;
+  return t;
+}
+
+// Weight fragment of a [rows][cols] row-major matrix W (leading dim ld) for output block at row0
+// and input chunk at col0: element s = W[row0 + SM(l&15)][col0 + SK(4kq + s)]   (TRANS: W^T)
+template <bool TRANS, int HM, int HK>
+__device__ __forceinline__ f32x4 wfrag(const float* __restrict__ W, int ld, int row0, int col0, int lane, float mul = 1.f) {
+  const int m = sig<HM>(lane & 15), kq = lane >> 4;
+  f32x4 f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = sig<HK>(4 * kq + s);
+    f[s] = mul * (TRANS ? W[(long)(col0 + k) * ld + row0 + m] : W[(long)(row0 + m) * ld + col0 + k]);
+  }
+  return f;
+}
+// bias / vector in TL: element r = v[base + S(4kq + r)]
+template <int HS>
+__device__ __forceinline__ f32x4 vfrag(const float* __restrict__ v, int base, int lane, float mul = 1.f) {
+  const int kq = lane >> 4;
+  return f32x4{mul * v[base + sig<HS>(4 * kq)], mul * v[base + sig<HS>(4 * kq + 1)], mul * v[base + sig<HS>(4 * kq + 2)],
+               mul * v[base + sig<HS>(4 * kq + 3)]};
+}
+
+// sum over the channels of a token held in TL: in-lane partial -> lanes kq = 0..3 (xor 16, 32)
+__device__ __forceinline__ float chan_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float chan_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+template <int CT>
+__device__ __forceinline__ void layer_norm_tl(const f32x4 (&x)[CT][MT], f32x4 (&xn)[CT][MT], float (&rstd)[MT], const bool (&keep)[MT]) {
+  constexpr float invC = 1.f / (16 * CT);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) s += x[c][m][0] + x[c][m][1] + x[c][m][2] + x[c][m][3];
+    const float mean = chan_sum(s) * invC;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = x[c][m][r] - mean; v = fmaf(d, d, v); }
+    rstd[m] = rsqrtf(chan_sum(v) * invC + kLnEps);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xn[c][m][r] = keep[m] ? (x[c][m][r] - mean) * rstd[m] : 0.f;
+  }
+}
+
+// Y[OT][MT] += W X   with fragments wf[OT][KT] (4 k-steps each) and X[KT][MT] in TL
+template <int OT, int KT>
+__device__ __forceinline__ void mm(f32x4 (&Y)[OT][MT], const f32x4 (&wf)[OT][KT], const f32x4 (&X)[KT][MT]) {
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) Y[o][m] = MFMA(wf[o][k][s], X[k][m][s], Y[o][m]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int C, int NH, int NW, bool SAVE_H>
+__global__ __launch_bounds__(256) void swin_fwd_mfma_kernel(
+    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ hsave, const float* __restrict__ qkv_w,
+    const float* __restrict__ qkv_b, const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+    const float* __restrict__ fc1_w, const float* __restrict__ fc1_b, const float* __restrict__ fc2_w,
+    const float* __restrict__ fc2_b, const float* __restrict__ rel_bias, Geom g) {
+  constexpr int CT = C / 16, HID = 4 * C, HT = HID / 16, HD = C / NH;
+  static_assert(C % 16 == 0 && HD <= 16 && 16 % HD == 0, "head_dim must divide 16");
+  constexpr int HPC = 16 / HD;             // heads per 16-channel chunk
+  constexpr int SP = 4 / HPC;              // k-steps per head inside a chunk
+  constexpr int TPW = NW >= 16 ? NW / 16 : 1;   // column blocks per window group
+  constexpr int NG = MT / TPW;             // window groups per wave
+    __shared__ __attribute__((aligned(16))) float s_vt[4][C * VS];
+  __shared__ __attribute__((aligned(16))) int s_rid[4][64];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, v = b % g.V;
+  qkv_w += (long)v * 3 * C * C;  qkv_b += v * 3 * C;
+  proj_w += (long)v * C * C;     proj_b += v * C;
+  fc1_w += (long)v * HID * C;    fc1_b += v * HID;
+  fc2_w += (long)v * C * HID;    fc2_b += v * C;
+  rel_bias += (long)v * NH * NW * NW;
+
+  // ---- resident weight fragments ----
+  f32x4 wq[3 * CT][CT], bq[3 * CT], wp[CT][CT], bp[CT], w1[HT][CT], b1[HT], w2[CT][HT], b2[CT];
+#pragma unroll
+  for (int o = 0; o < 3 * CT; ++o) {
+    const float mul = o < CT ? g.scale : 1.f;   // q pre-scaled (Swin_3D.py:155)
+    bq[o] = vfrag<HPC>(qkv_b, 16 * o, lane, mul);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) wq[o][k] = wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul);
+  }
+#pragma unroll
+  for (int o = 0; o < CT; ++o) {
+    bp[o] = vfrag<1>(proj_b, 16 * o, lane);
+    b2[o] = vfrag<1>(fc2_b, 16 * o, lane);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) wp[o][k] = wfrag<false, 1, HPC>(proj_w, C, 16 * o, 16 * k, lane);
+#pragma unroll
+    for (int k = 0; k < HT; ++k) w2[o][k] = wfrag<false, 1, 1>(fc2_w, HID, 16 * o, 16 * k, lane);
+  }
+#pragma unroll
+  for (int o = 0; o < HT; ++o) {
+    b1[o] = vfrag<1>(fc1_b, 16 * o, lane);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) w1[o][k] = wfrag<false, 1, 1>(fc1_w, C, 16 * o, 16 * k, lane);
+  }
+  // relative-position bias per (head, key block, query block): rows = keys 4kq+r, col = query j;
+  // for NW < 16 the cross-window entries of a column block are masked here once and for all
+  f32x4 rb[NH][TPW][TPW];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
+          const bool same = (key / NW) == (qry / NW);
+          rb[h][kt][qt][r] = same ? rel_bias[(h * NW + qry % NW) * NW + key % NW] : -1e30f;
+        }
+
+  float* vt = s_vt[wave];
+  int* rid_l = s_rid[wave];
+
+  for (int it0 = blockIdx.x * 4; it0 < g.items; it0 += gridDim.x * 4) {
+    Tok t[MT];
+    bool keep[MT];
+    f32x4 X[CT][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      t[m] = locate<NW>(g, b, it0 + wave, 16 * m + j, C);
+      keep[m] = t[m].valid;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) X[c][m] = t[m].valid ? ld4(x + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 XN[CT][MT];
+    float rstd[MT];
+    layer_norm_tl<CT>(X, XN, rstd, keep);   // zero padding is applied AFTER norm1 (Swin_3D.py:229-238)
+
+    f32x4 QKV[3 * CT][MT];
+#pragma unroll
+    for (int o = 0; o < 3 * CT; ++o)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) QKV[o][m] = bq[o];
+    mm<3 * CT, CT>(QKV, wq, XN);
+
+    __syncthreads();   // previous iteration's readers of vt / rid are done
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vt[(16 * c + sig<HPC>(4 * kq + r)) * VS + 16 * m + j] = QKV[2 * CT + c][m][r];
+    if (kq == 0)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) rid_l[16 * m + j] = t[m].rid;
+    __syncthreads();
+
+    f32x4 O[CT][MT];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int c = h / HPC, s0 = (h % HPC) * SP;
+        f32x4 S[TPW][TPW];
+#pragma unroll
+        for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) {
+            f32x4 acc = rb[h][kt][qt];
+#pragma unroll
+            for (int s = 0; s < SP; ++s)
+              acc = MFMA(QKV[CT + c][grp * TPW + kt][s0 + s], QKV[c][grp * TPW + qt][s0 + s], acc);
+            if (g.shifted) {
+              const int4 rk = *reinterpret_cast<const int4*>(rid_l + 16 * (grp * TPW + kt) + 4 * kq);
+              const int rq = t[grp * TPW + qt].rid;
+              acc[0] += rk.x != rq ? -100.f : 0.f; acc[1] += rk.y != rq ? -100.f : 0.f;
+              acc[2] += rk.z != rq ? -100.f : 0.f; acc[3] += rk.w != rq ? -100.f : 0.f;
+            }
+            S[kt][qt] = acc;
+          }
+        // softmax over keys (rows) for each query column
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt) {
+          float mx = -3.0e38f;
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(S[kt][qt][0], S[kt][qt][1]), fmaxf(S[kt][qt][2], S[kt][qt][3])));
+          mx = chan_max(mx);
+          float l = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { S[kt][qt][r] = __expf(S[kt][qt][r] - mx); l += S[kt][qt][r]; }
+          const float inv = 1.f / chan_sum(l);
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) S[kt][qt] *= inv;
+        }
+        // O[chan][query] = sum_keys V^T[chan][key] P[key][query]; keep this head's rows
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const f32x4 vf = ld4(vt + (16 * c + sig<HPC>(lane & 15)) * VS + 16 * (grp * TPW + kt) + 4 * kq);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = MFMA(vf[s], S[kt][qt][s], acc);
+          }
+#pragma unroll
+          for (int r = 0; r < SP; ++r) O[c][grp * TPW + qt][s0 + r] = acc[s0 + r];
+        }
+      }
+    }
+
+    // proj + shortcut
+    f32x4 Hs[CT][MT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) Hs[c][m] = X[c][m] + bp[c];
+    mm<CT, CT>(Hs, wp, O);
+    if (SAVE_H) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (t[m].valid)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) st4(hsave + t[m].off + 16 * c + 4 * kq, Hs[c][m]);
+    }
+    f32x4 HN[CT][MT];
+    float rstd2[MT];
+    bool all[MT] = {true, true, true, true};
+    layer_norm_tl<CT>(Hs, HN, rstd2, all);
+    f32x4 A1[HT][MT];
+#pragma unroll
+    for (int o = 0; o < HT; ++o)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) A1[o][m] = b1[o];
+    mm<HT, CT>(A1, w1, HN);
+#pragma unroll
+    for (int o = 0; o < HT; ++o)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A1[o][m][r] = gelu(A1[o][m][r]);
+    f32x4 Y[CT][MT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) Y[c][m] = Hs[c][m] + b2[c];
+    mm<CT, HT>(Y, w2, A1);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (t[m].valid)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) st4(y + t[m].off + 16 * c + 4 * kq, Y[c][m]);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// backward helpers: token-reduction GEMMs (weight gradients) through LDS images [channel][token]
+// ---------------------------------------------------------------------------------------------
+
+// TL tile -> image rows in REAL channel order (permutation HS undone on the way out)
+template <int HS>
+__device__ __forceinline__ void put_img(float* img, const f32x4 (&T)[MT], int lane) {
+  const int j = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) img[sig<HS>(4 * kq + r) * VS + 16 * m + j] = T[m][r];
+}
+// acc[m][n] += sum_tok A[m][tok] B[n][tok]   over the wave's 64 tokens
+__device__ __forceinline__ void gemm_tok(f32x4& acc, const float* A, const float* B, int lane) {
+  const int row = (lane & 15) * VS + 4 * (lane >> 4);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const f32x4 fa = ld4(A + row + 16 * m), fb = ld4(B + row + 16 * m);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = MFMA(fa[s], fb[s], acc);
+  }
+}
+// D layout: rows 4kq+r, col j -> dst[(row0 + 4kq + r) * ld + col0 + j]
+__device__ __forceinline__ void flush_acc(float* dst, int ld, const f32x4& acc, int lane) {
+  const int j = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) atomicAdd(dst + (long)(r0 + r) * ld + j, acc[r]);
+}
+// per-lane partial sums over tokens of a TL vector: reduce over the 16 token lanes, add at channel HS(4kq+r)
+template <int HS>
+__device__ __forceinline__ void flush_vec(float* dst, f32x4 part, int lane) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    part[0] += __shfl_xor(part[0], o, 64); part[1] += __shfl_xor(part[1], o, 64);
+    part[2] += __shfl_xor(part[2], o, 64); part[3] += __shfl_xor(part[3], o, 64);
+  }
+  if ((lane & 15) == 0) {
+    const int kq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dst + sig<HS>(4 * kq + r), part[r]);
+  }
+}
+
+// dx = rstd * (dxn - mean(dxn) - xn * mean(dxn * xn)) + add, per token in TL
+template <int CT>
+__device__ __forceinline__ void layer_norm_bwd_tl(const f32x4 (&dxn)[CT][MT], const f32x4 (&xn)[CT][MT], const float (&rstd)[MT],
+                                                  const f32x4 (&add)[CT][MT], f32x4 (&dx)[CT][MT]) {
+  constexpr float invC = 1.f / (16 * CT);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a += dxn[c][m][r]; b = fmaf(dxn[c][m][r], xn[c][m][r], b); }
+    a = chan_sum(a) * invC;
+    b = chan_sum(b) * invC;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dx[c][m][r] = rstd[m] * (dxn[c][m][r] - a - xn[c][m][r] * b) + add[c][m][r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 1: MLP + norm2 (pure per-token; tokens in memory order)
+//   in: h (block state before the MLP, saved by the forward), dy.  out: dh = dL/dh, MLP weight grads.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
+    const float* __restrict__ hs, const float* __restrict__ dy, float* __restrict__ dh, const float* __restrict__ fc1_w,
+    const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float* __restrict__ g_fc1_w,
+    float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L) {
+  constexpr int CT = C / 16, HID = 4 * C, HT = HID / 16;
+  __shared__ __attribute__((aligned(16))) float s_img[4][(2 * CT + 2) * 16 * VS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, v = b % V;
+  fc1_w += (long)v * HID * C;  fc1_b += v * HID;  fc2_w += (long)v * C * HID;
+  g_fc1_w += (long)v * HID * C;  g_fc1_b += v * HID;  g_fc2_w += (long)v * C * HID;  g_fc2_b += v * C;
+  hs += (long)b * L * C;  dy += (long)b * L * C;  dh += (long)b * L * C;
+
+  f32x4 w1[HT][CT], b1[HT], w2t[HT][CT], w1t[CT][HT];
+#pragma unroll
+  for (int o = 0; o < HT; ++o) {
+    b1[o] = vfrag<1>(fc1_b, 16 * o, lane);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) {
+      w1[o][k] = wfrag<false, 1, 1>(fc1_w, C, 16 * o, 16 * k, lane);
+      w2t[o][k] = wfrag<true, 1, 1>(fc2_w, HID, 16 * o, 16 * k, lane);    // [hid][c] = fc2_w[c][hid]
+      w1t[k][o] = wfrag<true, 1, 1>(fc1_w, C, 16 * k, 16 * o, lane);      // [c][hid] = fc1_w[hid][c]
+    }
+  }
+  f32x4 aW1[HT][CT], aW2[CT][HT], pb1[HT], pb2[CT];
+#pragma unroll
+  for (int o = 0; o < HT; ++o) {
+    pb1[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CT; ++k) { aW1[o][k] = f32x4{0.f, 0.f, 0.f, 0.f}; aW2[k][o] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+#pragma unroll
+  for (int k = 0; k < CT; ++k) pb2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float* img = s_img[wave];
+  float* imgHN = img;                       // CT images
+  float* imgDY = img + CT * 16 * VS;        // CT images
+  float* imgA = img + 2 * CT * 16 * VS;     // dA1 tile
+  float* imgB = imgA + 16 * VS;             // gelu tile
+  const long items = (L + 63) / 64;
+
+  for (long it0 = (long)blockIdx.x * 4; it0 < items; it0 += (long)gridDim.x * 4) {
+    const long base = (it0 + wave) * 64;
+    bool valid[MT];
+    f32x4 Hs[CT][MT], DY[CT][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const long tok = base + 16 * m + j;
+      valid[m] = tok < L;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        Hs[c][m] = valid[m] ? ld4(hs + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        DY[c][m] = valid[m] ? ld4(dy + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    f32x4 HN[CT][MT];
+    float rstd2[MT];
+    bool all[MT] = {true, true, true, true};
+    layer_norm_tl<CT>(Hs, HN, rstd2, all);
+    f32x4 A1[HT][MT], dG[HT][MT];
+#pragma unroll
+    for (int o = 0; o < HT; ++o)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { A1[o][m] = b1[o]; dG[o][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    mm<HT, CT>(A1, w1, HN);
+    mm<HT, CT>(dG, w2t, DY);
+#pragma unroll
+    for (int o = 0; o < HT; ++o)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = A1[o][m][r];
+          dG[o][m][r] *= gelu_grad(a);      // dG now holds dA1
+          A1[o][m][r] = gelu(a);            // A1 now holds gelu(A1)
+        }
+        pb1[o] += dG[o][m];
+      }
+    f32x4 dHN[CT][MT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { dHN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pb2[c] += DY[c][m]; }
+    mm<CT, HT>(dHN, w1t, dG);
+    f32x4 dH[CT][MT];
+    layer_norm_bwd_tl<CT>(dHN, HN, rstd2, DY, dH);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (valid[m])
+#pragma unroll
+        for (int c = 0; c < CT; ++c) st4(dh + (base + 16 * m + j) * C + 16 * c + 4 * kq, dH[c][m]);
+
+    // weight gradients: dW1[hid][c] += dA1 . HN^T ; dW2[c][hid] += DY . G^T  (K = tokens)
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { put_img<1>(imgHN + c * 16 * VS, HN[c], lane); put_img<1>(imgDY + c * 16 * VS, DY[c], lane); }
+#pragma unroll
+    for (int o = 0; o < HT; ++o) {
+      if (o) __syncthreads();
+      put_img<1>(imgA, dG[o], lane);
+      put_img<1>(imgB, A1[o], lane);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        gemm_tok(aW1[o][c], imgA, imgHN + c * 16 * VS, lane);
+        gemm_tok(aW2[c][o], imgDY + c * 16 * VS, imgB, lane);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < HT; ++o) {
+    flush_vec<1>(g_fc1_b + 16 * o, pb1[o], lane);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      flush_acc(g_fc1_w + (long)(16 * o) * C + 16 * c, C, aW1[o][c], lane);
+      flush_acc(g_fc2_w + (long)(16 * c) * HID + 16 * o, HID, aW2[c][o], lane);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) flush_vec<1>(g_fc2_b + 16 * c, pb2[c], lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 2: attention + norm1.  in: x (block input), dh (from part 1).  out: dx and the
+// gradients of qkv / proj / relative-position bias.  Everything is recomputed from x.
+// ---------------------------------------------------------------------------------------------
+template <int C, int NH, int NW, int WPB>
+__global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ dh, float* __restrict__ dx, const float* __restrict__ qkv_w,
+    const float* __restrict__ qkv_b, const float* __restrict__ proj_w, const float* __restrict__ rel_bias,
+    float* __restrict__ g_qkv_w, float* __restrict__ g_qkv_b, float* __restrict__ g_proj_w, float* __restrict__ g_proj_b,
+    float* __restrict__ g_rel_bias, Geom g) {
+  constexpr int CT = C / 16, HD = C / NH;
+  static_assert(C % 16 == 0 && HD <= 16 && 16 % HD == 0, "head_dim must divide 16");
+  constexpr int HPC = 16 / HD, SP = 4 / HPC;
+  constexpr int TPW = NW >= 16 ? NW / 16 : 1, NG = MT / TPW;
+  constexpr int IMG = 16 * VS;
+  // per wave, images [channel][token]: [0,CT) K  [CT,2CT) Q  [2CT,3CT) V  [3CT,4CT) dO  [4CT,5CT) scratch B  [5CT] scratch A
+  __shared__ __attribute__((aligned(16))) float s_img[WPB][(5 * CT + 1) * IMG];
+  __shared__ __attribute__((aligned(16))) int s_rid[WPB][64];
+  __shared__ __attribute__((aligned(16))) float s_stat[WPB][3][64];   // per query: max, 1/l, D  (current group/head)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, v = b % g.V;
+  qkv_w += (long)v * 3 * C * C;  qkv_b += v * 3 * C;  proj_w += (long)v * C * C;
+  rel_bias += (long)v * NH * NW * NW;
+  g_qkv_w += (long)v * 3 * C * C;  g_qkv_b += v * 3 * C;  g_proj_w += (long)v * C * C;  g_proj_b += v * C;
+  g_rel_bias += (long)v * NH * NW * NW;
+
+  f32x4 wq[3 * CT][CT], bq[3 * CT], wpt[CT][CT], wqt[CT][3 * CT];
+#pragma unroll
+  for (int o = 0; o < 3 * CT; ++o) {
+    const float mul = o < CT ? g.scale : 1.f;
+    bq[o] = vfrag<HPC>(qkv_b, 16 * o, lane, mul);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) {
+      wq[o][k] = wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul);
+      wqt[k][o] = wfrag<true, 1, HPC>(qkv_w, C, 16 * k, 16 * o, lane, mul);   // [c][o] = qkv_w[o][c] (q rows carry the scale)
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CT; ++o)
+#pragma unroll
+    for (int k = 0; k < CT; ++k) wpt[o][k] = wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane);   // [c'][c] = proj_w[c][c']
+
+  // bias in both orientations: rb rows = keys, col = query ; rbT rows = queries, col = key
+  f32x4 rb[NH][TPW][TPW], rbT[NH][TPW][TPW], dB[NH][TPW][TPW];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < TPW; ++qt) {
+        dB[h][kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
+          rb[h][kt][qt][r] = (key / NW) == (qry / NW) ? rel_bias[(h * NW + qry % NW) * NW + key % NW] : -1e30f;
+          const int qry2 = 16 * qt + 4 * kq + r, key2 = 16 * kt + j;
+          rbT[h][kt][qt][r] = (key2 / NW) == (qry2 / NW) ? rel_bias[(h * NW + qry2 % NW) * NW + key2 % NW] : -1e30f;
+        }
+      }
+  f32x4 aWq[3 * CT][CT], aWp[CT][CT], pbq[3 * CT], pbp[CT];
+#pragma unroll
+  for (int o = 0; o < 3 * CT; ++o) {
+    pbq[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CT; ++k) aWq[o][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int o = 0; o < CT; ++o) {
+    pbp[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CT; ++k) aWp[o][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  float* img = s_img[wave];
+  float* imgK = img;
+  float* imgQ = img + CT * IMG;
+  float* imgV = img + 2 * CT * IMG;
+  float* imgDO = img + 3 * CT * IMG;
+  float* imgB = img + 4 * CT * IMG;
+  float* imgA = img + 5 * CT * IMG;
+  int* rid_l = s_rid[wave];
+  float* st_m = s_stat[wave][0];
+  float* st_il = s_stat[wave][1];
+  float* st_D = s_stat[wave][2];
+
+  for (int it0 = blockIdx.x * WPB; it0 < g.items; it0 += gridDim.x * WPB) {
+    Tok t[MT];
+    bool keep[MT];
+    f32x4 X[CT][MT], DH[CT][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      t[m] = locate<NW>(g, b, it0 + wave, 16 * m + j, C);
+      keep[m] = t[m].valid;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        X[c][m] = t[m].valid ? ld4(x + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        DH[c][m] = t[m].valid ? ld4(dh + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    f32x4 XN[CT][MT];
+    float rstd[MT];
+    layer_norm_tl<CT>(X, XN, rstd, keep);
+    f32x4 QKV[3 * CT][MT];
+#pragma unroll
+    for (int o = 0; o < 3 * CT; ++o)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) QKV[o][m] = bq[o];
+    mm<3 * CT, CT>(QKV, wq, XN);
+    // dO = proj_w^T dH  (TL with the head permutation, like V and O)
+    f32x4 DO[CT][MT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pbp[c] += DH[c][m]; }
+    mm<CT, CT>(DO, wpt, DH);
+
+    __syncthreads();   // previous iteration's image readers are done
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      put_img<HPC>(imgQ + c * IMG, QKV[c], lane);
+      put_img<HPC>(imgK + c * IMG, QKV[CT + c], lane);
+      put_img<HPC>(imgV + c * IMG, QKV[2 * CT + c], lane);
+      put_img<HPC>(imgDO + c * IMG, DO[c], lane);
+    }
+    if (kq == 0)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) rid_l[16 * m + j] = t[m].rid;
+    __syncthreads();
+
+    f32x4 O[CT][MT], DQ[CT][MT], DK[CT][MT], DV[CT][MT];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int c = h / HPC, s0 = (h % HPC) * SP;
+        const int hrow = (16 * c + sig<HPC>(lane & 15)) * VS + 4 * kq;   // image row of this lane's A-operand channel
+        // ---- row pass: S, P, dP with keys on rows, query on the column ----
+        f32x4 P[TPW][TPW], dP[TPW][TPW];
+#pragma unroll
+        for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) {
+            f32x4 acc = rb[h][kt][qt], accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < SP; ++s) {
+              acc = MFMA(QKV[CT + c][grp * TPW + kt][s0 + s], QKV[c][grp * TPW + qt][s0 + s], acc);
+              accd = MFMA(QKV[2 * CT + c][grp * TPW + kt][s0 + s], DO[c][grp * TPW + qt][s0 + s], accd);
+            }
+            if (g.shifted) {
+              const int4 rk = *reinterpret_cast<const int4*>(rid_l + 16 * (grp * TPW + kt) + 4 * kq);
+              const int rq = t[grp * TPW + qt].rid;
+              acc[0] += rk.x != rq ? -100.f : 0.f; acc[1] += rk.y != rq ? -100.f : 0.f;
+              acc[2] += rk.z != rq ? -100.f : 0.f; acc[3] += rk.w != rq ? -100.f : 0.f;
+            }
+            P[kt][qt] = acc; dP[kt][qt] = accd;
+          }
+        __syncthreads();   // stats of the previous (group, head) fully consumed
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt) {
+          float mx = -3.0e38f;
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(P[kt][qt][0], P[kt][qt][1]), fmaxf(P[kt][qt][2], P[kt][qt][3])));
+          mx = chan_max(mx);
+          float l = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { P[kt][qt][r] = __expf(P[kt][qt][r] - mx); l += P[kt][qt][r]; }
+          const float inv = 1.f / chan_sum(l);
+          float D = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            P[kt][qt] *= inv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D = fmaf(P[kt][qt][r], dP[kt][qt][r], D);
+          }
+          D = chan_sum(D);
+          if (kq == 0) { const int q = 16 * (grp * TPW + qt) + j; st_m[q] = mx; st_il[q] = inv; st_D[q] = D; }
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dP[kt][qt][r] = P[kt][qt][r] * (dP[kt][qt][r] - D);   // dP now holds dS
+            dB[h][kt][qt] += dP[kt][qt];
+          }
+        }
+        // O (for dproj_w) and dQ : A operands are channel-major images of V and K
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt) {
+          f32x4 acco = {0.f, 0.f, 0.f, 0.f}, accq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const f32x4 vf = ld4(imgV + hrow + 16 * (grp * TPW + kt)), kf = ld4(imgK + hrow + 16 * (grp * TPW + kt));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              acco = MFMA(vf[s], P[kt][qt][s], acco);
+              accq = MFMA(kf[s], dP[kt][qt][s], accq);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < SP; ++r) { O[c][grp * TPW + qt][s0 + r] = acco[s0 + r]; DQ[c][grp * TPW + qt][s0 + r] = accq[s0 + r]; }
+        }
+        __syncthreads();   // stats visible
+        // ---- column pass: S^T, P^T, dS^T with queries on rows, key on the column ----
+        f32x4 PT[TPW][TPW], dST[TPW][TPW];   // [qt][kt]
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            f32x4 acc = rbT[h][kt][qt], accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < SP; ++s) {
+              acc = MFMA(QKV[c][grp * TPW + qt][s0 + s], QKV[CT + c][grp * TPW + kt][s0 + s], acc);
+              accd = MFMA(DO[c][grp * TPW + qt][s0 + s], QKV[2 * CT + c][grp * TPW + kt][s0 + s], accd);
+            }
+            const int q0 = 16 * (grp * TPW + qt) + 4 * kq;
+            if (g.shifted) {
+              const int4 rq = *reinterpret_cast<const int4*>(rid_l + q0);
+              const int rk = t[grp * TPW + kt].rid;
+              acc[0] += rq.x != rk ? -100.f : 0.f; acc[1] += rq.y != rk ? -100.f : 0.f;
+              acc[2] += rq.z != rk ? -100.f : 0.f; acc[3] += rq.w != rk ? -100.f : 0.f;
+            }
+            const f32x4 m4 = ld4(st_m + q0), il4 = ld4(st_il + q0), D4 = ld4(st_D + q0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = __expf(acc[r] - m4[r]) * il4[r];
+              PT[qt][kt][r] = p;
+              dST[qt][kt][r] = p * (accd[r] - D4[r]);
+            }
+          }
+#pragma unroll
+        for (int kt = 0; kt < TPW; ++kt) {
+          f32x4 acck = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) {
+            const f32x4 qf = ld4(imgQ + hrow + 16 * (grp * TPW + qt)), df = ld4(imgDO + hrow + 16 * (grp * TPW + qt));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              acck = MFMA(qf[s], dST[qt][kt][s], acck);
+              accv = MFMA(df[s], PT[qt][kt][s], accv);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < SP; ++r) { DK[c][grp * TPW + kt][s0 + r] = acck[s0 + r]; DV[c][grp * TPW + kt][s0 + r] = accv[s0 + r]; }
+        }
+      }
+    }
+    // ---- proj / qkv weight gradients and dxn ----
+    // dproj_w[c][c'] += dH[c] O[c'] ; dqkv_w[o][c] += dQKV[o] XN[c] ; K = tokens
+    f32x4 dXN[CT][MT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) dXN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the q gradient refers to the pre-scaled q: fold the scale into wqt (done) and into dWq / dbq here
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        pbq[c] += DQ[c][m] * g.scale; pbq[CT + c] += DK[c][m]; pbq[2 * CT + c] += DV[c][m];
+      }
+    // dxn = Wqkv^T dQKV
+#pragma unroll
+    for (int oc = 0; oc < CT; ++oc)
+#pragma unroll
+      for (int k = 0; k < CT; ++k)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            dXN[oc][m] = MFMA(wqt[oc][k][s], DQ[k][m][s], dXN[oc][m]);
+            dXN[oc][m] = MFMA(wqt[oc][CT + k][s], DK[k][m][s], dXN[oc][m]);
+            dXN[oc][m] = MFMA(wqt[oc][2 * CT + k][s], DV[k][m][s], dXN[oc][m]);
+          }
+    f32x4 DX[CT][MT];
+    layer_norm_bwd_tl<CT>(dXN, XN, rstd, DH, DX);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (t[m].valid)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) st4(dx + t[m].off + 16 * c + 4 * kq, DX[c][m]);
+
+    // token-reduction GEMMs through the scratch images
+#pragma unroll
+    for (int ca = 0; ca < CT; ++ca) {        // dproj_w rows (c) from dH, cols (c') from O
+      __syncthreads();
+      put_img<1>(imgA, DH[ca], lane);
+      if (ca == 0)
+#pragma unroll
+        for (int cb = 0; cb < CT; ++cb) put_img<HPC>(imgB + cb * IMG, O[cb], lane);
+      __syncthreads();
+#pragma unroll
+      for (int cb = 0; cb < CT; ++cb) gemm_tok(aWp[ca][cb], imgA, imgB + cb * IMG, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < CT; ++cb) put_img<1>(imgB + cb * IMG, XN[cb], lane);
+#pragma unroll
+    for (int o = 0; o < 3 * CT; ++o) {
+      __syncthreads();
+      if (o < CT) {
+        f32x4 tmp[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) tmp[m] = DQ[o][m] * g.scale;
+        put_img<HPC>(imgA, tmp, lane);
+      } else if (o < 2 * CT) put_img<HPC>(imgA, DK[o - CT], lane);
+      else put_img<HPC>(imgA, DV[o - 2 * CT], lane);
+      __syncthreads();
+#pragma unroll
+      for (int cb = 0; cb < CT; ++cb) gemm_tok(aWq[o][cb], imgA, imgB + cb * IMG, lane);
+    }
+  }
+
+  // ---- flush ----
+#pragma unroll
+  for (int o = 0; o < 3 * CT; ++o) {
+    flush_vec<HPC>(g_qkv_b + 16 * o, pbq[o], lane);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) flush_acc(g_qkv_w + (long)(16 * o) * C + 16 * k, C, aWq[o][k], lane);
+  }
+#pragma unroll
+  for (int o = 0; o < CT; ++o) {
+    flush_vec<1>(g_proj_b + 16 * o, pbp[o], lane);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) flush_acc(g_proj_w + (long)(16 * o) * C + 16 * k, C, aWp[o][k], lane);
+  }
+  // d rel-bias: dB[h][kt][qt][r] is d/d bias[h][query = 16qt + j][key = 16kt + 4kq + r] (summed over groups)
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
+          if ((key / NW) == (qry / NW)) atomicAdd(g_rel_bias + (h * NW + qry % NW) * NW + key % NW, dB[h][kt][qt][r]);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// relative-position bias: table (V, L, NH) gathered through index (NW, NW) -> dense (V, NH, NW, NW)
+// (Swin_3D.py:158-162) and its scatter-add backward.
+// ---------------------------------------------------------------------------------------------
+__global__ void relpos_gather_kernel(const float* __restrict__ table, const long long* __restrict__ index,
+                                     float* __restrict__ dense, int V, int L, int NH, int NW) {
+  const int total = V * NH * NW * NW;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int ij = e % (NW * NW), h = (e / (NW * NW)) % NH, v = e / (NW * NW * NH);
+    dense[e] = table[((long)v * L + index[ij]) * NH + h];
+  }
+}
+__global__ void relpos_scatter_kernel(const float* __restrict__ ddense, const long long* __restrict__ index,
+                                      float* __restrict__ dtable, int V, int L, int NH, int NW) {
+  const int total = V * NH * NW * NW;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int ij = e % (NW * NW), h = (e / (NW * NW)) % NH, v = e / (NW * NW * NH);
+    atomicAdd(dtable + ((long)v * L + index[ij]) * NH + h, ddense[e]);
+  }
+}
+
+int make_geom(const idee_swin_geom* s, Geom& g, int& NW) {
+  IDEE_CHECK_ARG(s->N > 0 && s->V > 0 && s->D > 0 && s->H > 0 && s->W > 0, "swin: empty tensor");
+  IDEE_CHECK_ARG(s->wd > 0 && s->wh > 0 && s->ww > 0, "swin: bad window");
+  IDEE_CHECK_ARG(s->sd >= 0 && s->sd < s->wd && s->sh >= 0 && s->sh < s->wh && s->sw >= 0 && s->sw < s->ww,
+                 "swin: shift must lie in [0, window)");
+  IDEE_CHECK_ARG(s->hidden == 4 * s->C, "swin: only mlp_ratio 4 is built (hidden %d, C %d)", s->hidden, s->C);
+  NW = s->wd * s->wh * s->ww;
+  g.V = s->V; g.D = s->D; g.H = s->H; g.W = s->W;
+  g.wd = s->wd; g.wh = s->wh; g.ww = s->ww; g.sd = s->sd; g.sh = s->sh; g.sw = s->sw;
+  g.Dp = cdiv(s->D, s->wd) * s->wd; g.Hp = cdiv(s->H, s->wh) * s->wh; g.Wp = cdiv(s->W, s->ww) * s->ww;
+  g.nWh = g.Hp / s->wh; g.nWw = g.Wp / s->ww;
+  g.nWin = (g.Dp / s->wd) * g.nWh * g.nWw;
+  g.shifted = (s->sd | s->sh | s->sw) != 0;
+  g.scale = s->scale;
+  if (NW != 8 && NW != 16 && NW != 32 && NW != 64)
+    return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: window volume %d not in {8,16,32,64}", NW);
+  g.items = cdiv(g.nWin, 64 / NW);
+  return IDEE_OK;
+}
+
+dim3 swin_grid(const Geom& g, int B, int wg_per_cu) {
+  int gx = imin(cdiv(g.items, 4), cdiv((long)kCUs * wg_per_cu, B));
+  if (gx < 1) gx = 1;
+  return dim3(gx, B, 1);
+}
+
+}  // namespace
+
+#define SWIN_DISPATCH(KERNEL_CALL)                                                              \
+  if (C == 16 && NH == 2 && NW == 32) { KERNEL_CALL(16, 2, 32); }                               \
+  else if (C == 16 && NH == 2 && NW == 8) { KERNEL_CALL(16, 2, 8); }                            \
+  else if (C == 16 && NH == 2 && NW == 16) { KERNEL_CALL(16, 2, 16); }                          \
+  else if (C == 32 && NH == 2 && NW == 32) { KERNEL_CALL(32, 2, 32); }                          \
+  else if (C == 32 && NH == 2 && NW == 8) { KERNEL_CALL(32, 2, 8); }                            \
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: (C=%d, heads=%d, window volume=%d) is not built", C, NH, NW);
+
+extern "C" int idee_swin_block_fwd(const float* x, float* y, float* h_save, const idee_swin_params* p,
+                                   const idee_swin_geom* s, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && y && p && s, "swin_block_fwd: null argument");
+  Geom g; int NW;
+  if (int rc = make_geom(s, g, NW)) return rc;
+  const int C = s->C, NH = s->heads, B = s->N * s->V;
+  const dim3 grid = swin_grid(g, B, 4);
+#define CALL(C_, NH_, NW_)                                                                                   \
+  if (h_save)                                                                                                \
+    hipLaunchKernelGGL((swin_fwd_mfma_kernel<C_, NH_, NW_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
+                       p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
+  else                                                                                                       \
+    hipLaunchKernelGGL((swin_fwd_mfma_kernel<C_, NH_, NW_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
+                       p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g)
+  SWIN_DISPATCH(CALL)
+#undef CALL
+  IDEE_LAUNCH_CHECK("swin_block_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const float* dy, float* dx, float* dh_workspace,
+                                   const idee_swin_params* p, const idee_swin_grads* d, const idee_swin_geom* s,
+                                   idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && h_saved && dy && dx && dh_workspace && p && d && s, "swin_block_bwd: null argument");
+  Geom g; int NW;
+  if (int rc = make_geom(s, g, NW)) return rc;
+  const int C = s->C, NH = s->heads, B = s->N * s->V;
+  const long L = (long)s->D * s->H * s->W;
+  hipStream_t st = (hipStream_t)stream;
+  {   // part 1: MLP + norm2 (token order)
+    int gx = imin(cdiv(cdiv(L, 64), 4), cdiv((long)kCUs * 3, B));
+    if (gx < 1) gx = 1;
+    const dim3 grid(gx, B);
+    if (C == 16)
+      hipLaunchKernelGGL((swin_mlp_bwd_kernel<16>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
+                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
+    else if (C == 32)
+      hipLaunchKernelGGL((swin_mlp_bwd_kernel<32>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
+                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
+    else return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: C=%d is not built", C);
+  }
+  const int WPB = C == 16 ? 4 : 2;   // waves per workgroup (LDS images: 26 KB per wave at C=16, 48 KB at C=32)
+  int gx = imin(cdiv(g.items, WPB), cdiv((long)kCUs * (C == 16 ? 1 : 2) * 2, B));
+  if (gx < 1) gx = 1;
+  const dim3 grid(gx, B);
+#define CALL(C_, NH_, NW_)                                                                                           \
+  hipLaunchKernelGGL((swin_attn_bwd_kernel<C_, NH_, NW_, (C_ == 16 ? 4 : 2)>), grid, dim3(64 * (C_ == 16 ? 4 : 2)), 0, st, x, \
+                     dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,    \
+                     d->proj_b, d->rel_bias, g)
+  SWIN_DISPATCH(CALL)
+#undef CALL
+  IDEE_LAUNCH_CHECK("swin_block_bwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_relpos_bias_gather(const float* table, const int64_t* index, float* dense, int V, int table_len,
+                                       int heads, int Nw, idee_stream_t stream) {
+  IDEE_CHECK_ARG(table && index && dense && V > 0 && table_len > 0 && heads > 0 && Nw > 0, "relpos_gather: bad argument");
+  const int total = V * heads * Nw * Nw;
+  hipLaunchKernelGGL(relpos_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, table,
+                     (const long long*)index, dense, V, table_len, heads, Nw);
+  IDEE_LAUNCH_CHECK("relpos_bias_gather");
+  return IDEE_OK;
+}
+
+extern "C" int idee_relpos_bias_scatter(const float* ddense, const int64_t* index, float* dtable, int V, int table_len,
+                                        int heads, int Nw, idee_stream_t stream) {
+  IDEE_CHECK_ARG(ddense && index && dtable && V > 0 && table_len > 0 && heads > 0 && Nw > 0, "relpos_scatter: bad argument");
+  const int total = V * heads * Nw * Nw;
+  hipLaunchKernelGGL(relpos_scatter_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, ddense,
+                     (const long long*)index, dtable, V, table_len, heads, Nw);
+  IDEE_LAUNCH_CHECK("relpos_bias_scatter");
+  return IDEE_OK;
+}

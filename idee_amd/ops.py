@@ -84,24 +84,29 @@ class SwinBlock(torch.autograd.Function):
         dense = torch.empty((V, heads, Nw, Nw), device=x.device, dtype=torch.float32)
         L.call("idee_relpos_bias_gather", ptr(table), ptr(idx), ptr(dense), V, table.shape[1], heads, Nw, L.stream())
         y = torch.empty_like(x)
+        need_bwd = any(ctx.needs_input_grad)
+        hs = torch.empty_like(x) if need_bwd else None      # block state before the MLP, for the backward
         sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense))
-        L.call("idee_swin_block_fwd", ptr(x), ptr(y), C.byref(sp), C.byref(geom), L.stream())
-        ctx.save_for_backward(x, *params, table, idx, dense)
+        L.call("idee_swin_block_fwd", ptr(x), ptr(y), ptr(hs), C.byref(sp), C.byref(geom), L.stream())
+        if need_bwd:
+            ctx.save_for_backward(x, *params, table, idx, dense, hs)
         ctx.geom = geom
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, *rest = ctx.saved_tensors
-        params, table, idx, dense = rest[:8], rest[8], rest[9], rest[10]
+        params, table, idx, dense, hs = rest[:8], rest[8], rest[9], rest[10], rest[11]
         geom = ctx.geom
         dy = _f32c(dy)
         dx = torch.empty_like(x)
+        dh = torch.empty_like(x)
         grads = [torch.zeros_like(t) for t in params]
         ddense = torch.zeros_like(dense)
         sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense))
         sg = L.SwinGrads(*[ptr(t) for t in grads], ptr(ddense))
-        L.call("idee_swin_block_bwd", ptr(x), ptr(dy), ptr(dx), C.byref(sp), C.byref(sg), C.byref(geom), L.stream())
+        L.call("idee_swin_block_bwd", ptr(x), ptr(hs), ptr(dy), ptr(dx), ptr(dh), C.byref(sp), C.byref(sg), C.byref(geom),
+               L.stream())
         dtable = torch.zeros_like(table)
         V, heads, Nw, _ = dense.shape
         L.call("idee_relpos_bias_scatter", ptr(ddense), ptr(idx), ptr(dtable), V, table.shape[1], heads, Nw, L.stream())

@@ -57,7 +57,7 @@ int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, cons
  * with relative-position bias and shift mask, window reverse, un-shift, crop, residual, norm2,
  * MLP with erf-GELU, residual).  Replaces SwinTransformerBlock3D.forward, Swin_3D.py:224-287,
  * WindowAttention3D.forward :145-178, window_partition/reverse :45-74, compute_mask :340-352,
- * Mlp.forward :36-42.  Backward recomputes from x (nothing else is saved).
+ * Mlp.forward :36-42.  Backward recomputes the block from x and the saved pre-MLP state h.
  *   x, y, dy, dx: (N, V, D, H, W, C)
  * Window and shift are the values AFTER get_window_size clamping (Swin_3D.py:77-90).
  * ---------------------------------------------------------------------------------------- */
@@ -82,10 +82,13 @@ typedef struct { /* all accumulate */
   float *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *rel_bias;
 } idee_swin_grads;
 
-int idee_swin_block_fwd(const float* x, float* y, const idee_swin_params* p, const idee_swin_geom* g,
+/* h_save (same shape as x) | NULL: the block state before the MLP (x + attention), which the backward needs. */
+int idee_swin_block_fwd(const float* x, float* y, float* h_save, const idee_swin_params* p, const idee_swin_geom* g,
                         idee_stream_t stream);
-int idee_swin_block_bwd(const float* x, const float* dy, float* dx, const idee_swin_params* p, const idee_swin_grads* d,
-                        const idee_swin_geom* g, idee_stream_t stream);
+/* two launches: MLP + norm2 (h_saved, dy -> dh_workspace), then attention + norm1 (x, dh_workspace -> dx).
+ * dh_workspace: same shape as x. */
+int idee_swin_block_bwd(const float* x, const float* h_saved, const float* dy, float* dx, float* dh_workspace,
+                        const idee_swin_params* p, const idee_swin_grads* d, const idee_swin_geom* g, idee_stream_t stream);
 
 /* relative_position_bias_table[relative_position_index] (Swin_3D.py:158-162):
  * table (V, table_len, heads), index (Nw, Nw) int64 -> dense (V, heads, Nw, Nw);
