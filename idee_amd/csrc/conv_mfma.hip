@@ -318,6 +318,128 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// weight gradient of the 16 -> 16 convolutions, LDS-staged.
+// A workgroup walks a run of output rows (fixed batch item and t).  Per row it keeps in LDS the
+// source rows of x it needs — a ring of 3 h-rows for each of the 2-3 t-slots, with a one-pixel halo
+// so replicate / zero padding is resolved at staging time — plus the dy row.  Moving to the next
+// row stages only the one new h-row per t-slot.  The taps are dealt round-robin to the waves; a
+// k-step (4 pixels) costs each wave one conflict-free 4-byte LDS read per operand fragment.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSegMax = 200;   // widest row segment held in LDS (129 KB for the 3x3x3 mode)
+
+template <int MODE /*FWD_REP or FWD_S2*/, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, int seg, int nseg, int hrun, int nhrun) {
+  constexpr int NTAPS = MODE == FWD_REP ? 27 : 18;
+  constexpr int TSL = MODE == FWD_REP ? 3 : 2;
+  constexpr int TPWV = (NTAPS + WAVES - 1) / WAVES;
+  __shared__ __attribute__((aligned(16))) float s_x[TSL * 3 * (kSegMax + 2) * 16];
+  __shared__ __attribute__((aligned(16))) float s_dy[kSegMax * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  const int rowlen = seg + 2;                 // staged pixels per source row
+  const int segp = (seg + 3) & ~3;
+
+  f32x4 acc[TPWV];
+  float bsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < TPWV; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nb = a.B / a.wsets;
+  const long nchunks = (long)nb * a.To * nhrun * nseg;
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    long r = ch;
+    const int sg = (int)(r % nseg); r /= nseg;
+    const int hr = (int)(r % nhrun); r /= nhrun;
+    const int t = (int)(r % a.To);
+    const int b = (int)(r / a.To) * a.wsets + wset;
+    const int w0 = sg * seg;
+    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;     // source h-row resident in ring slot 0/1/2
+    const float* x_b = a.x + (long)b * a.x_sB;
+    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
+
+    for (int h = h0; h < h1; ++h) {
+      __syncthreads();   // previous row's readers are done
+      int slot_of[3];
+      bool ok_h[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        int hs = h + oh - 1;
+        if (MODE == FWD_REP) { hs = min(max(hs, 0), a.H - 1); ok_h[oh] = true; }
+        else ok_h[oh] = hs >= 0 && hs < a.H;
+        const int slot = ((hs % 3) + 3) % 3;
+        slot_of[oh] = slot;
+        if (!ok_h[oh]) continue;
+        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+        if (cur == hs) continue;
+        if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
+        // stage source row hs of every t-slot: pixels w0-1 .. w0+seg, 4 x 16-byte units each
+#pragma unroll
+        for (int ts = 0; ts < TSL; ++ts) {
+          const int tsrc = MODE == FWD_REP ? min(max(t + ts - 1, 0), a.T - 1) : 2 * t + ts;
+          const float* src = x_b + (long)tsrc * a.x_sT + (long)hs * a.x_sH;
+          float* dst = s_x + (long)(ts * 3 + slot) * rowlen * 16;
+          for (int u = tid; u < rowlen * 4; u += 64 * WAVES) {
+            const int px = u >> 2, q4 = u & 3;
+            int w = w0 + px - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == FWD_REP) { w = min(max(w, 0), a.W - 1); v = ld4(src + (long)w * a.x_sW + 4 * q4); }
+            else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * q4);
+            st4(dst + px * 16 + 4 * q4, v);
+          }
+        }
+      }
+      {   // dy row (zeros past the end of the row so the tail k-steps contribute nothing)
+        const float* src = dy_b + (long)h * a.y_sH;
+        for (int u = tid; u < segp * 4; u += 64 * WAVES) {
+          const int px = u >> 2, q4 = u & 3;
+          const int w = w0 + px;
+          const bool in = px < seg && w < a.W;
+          st4(s_dy + px * 16 + 4 * q4, in ? ld4(src + (long)w * a.y_sW + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+      }
+      __syncthreads();
+
+      int base[TPWV];
+      bool okt[TPWV];
+#pragma unroll
+      for (int k = 0; k < TPWV; ++k) {
+        const int tap = wave + k * WAVES;
+        const int ot = tap / 9, oh = (tap / 3) % 3, ow = tap % 3;
+        okt[k] = tap < NTAPS && ok_h[oh % 3];
+        base[k] = ((ot * 3 + slot_of[oh % 3]) * rowlen + ow + kq) * 16 + r16;
+      }
+      const int steps = segp >> 2;
+      for (int s = 0; s < steps; ++s) {
+        const float bf = s_dy[(4 * s + kq) * 16 + r16];
+        bsum += bf;
+#pragma unroll
+        for (int k = 0; k < TPWV; ++k) {
+          if (!okt[k]) continue;
+          acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_x[base[k] + s * 64], bf, acc[k], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* dw = a.dwp + (long)wset * NTAPS * 16 * 16;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int k = 0; k < TPWV; ++k) {
+    const int tap = wave + k * WAVES;
+    if (tap >= NTAPS) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tap * 16 + r0 + r) * 16 + col, acc[k][r]);
+  }
+  if (a.dbias && wave == 0) {
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 16) atomicAdd(a.dbias + (long)wset * 16 + lane, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight packing (reference layout (wsets, Cout, Cin, kt, kh, kw) -> MFMA fragment order)
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int wsets,
@@ -506,7 +628,20 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     a.row_chunks = gx;                                                                                       \
     hipLaunchKernelGGL((wgrad_kernel<MODE_, TPW_, NTA_, NTB_>), dim3(gx, gy, d->wsets), dim3(256), 0, st, a); \
   } while (0)
-  if (Ga == 1 && Gb == 1) { if (rep) LW(FWD_REP, 27, 1, 1); else LW(FWD_S2, 18, 1, 1); }
+  if (Ga == 1 && Gb == 1 && d->Cout == 16) {
+    // LDS-staged kernel: row segments of <= kSegMax pixels, runs of hrun rows per (b, t)
+    const int nseg = cdiv(d->W, kSegMax);
+    const int seg = ((cdiv(d->W, nseg) + 3) / 4) * 4 > kSegMax ? kSegMax : ((cdiv(d->W, nseg) + 3) / 4) * 4;
+    const long bt = (long)(d->B / d->wsets) * a.To;
+    int hrun = d->H;                       // shrink the run until the chip is covered ~3 times
+    while (hrun > 8 && bt * cdiv(d->H, hrun) * nseg * d->wsets < 3L * kCUs) hrun = (hrun + 1) / 2;
+    const int nhrun = cdiv(d->H, hrun);
+    const long nchunks = bt * nhrun * nseg;
+    const dim3 grid(imin(nchunks, cdiv((long)kCUs * 2, d->wsets) > 0 ? cdiv((long)kCUs * 2, d->wsets) : 1), d->wsets);
+    if (rep) hipLaunchKernelGGL((wgrad16_lds_kernel<FWD_REP, 8>), grid, dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
+    else hipLaunchKernelGGL((wgrad16_lds_kernel<FWD_S2, 8>), grid, dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
+  }
+  else if (Ga == 1 && Gb == 1) { if (rep) LW(FWD_REP, 27, 1, 1); else LW(FWD_S2, 18, 1, 1); }
   else {
     const int na = pick_nt(Ga), nb = pick_nt(Gb);
     // one tap per wave; channel blocks up to 6x6
