@@ -496,6 +496,21 @@ inline int out_T(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REP
 inline int n_taps(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REPLICATE ? 27 : 18; }
 inline int pick_nt(int G) { return G % 6 == 0 ? 6 : G % 3 == 0 ? 3 : G % 2 == 0 ? 2 : 1; }
 
+// resident workgroups per CU of a kernel (occupancy API; advisory, only steers the grid size)
+template <class K>
+int wg_per_cu(K kernel, int block) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+// grid.x such that gx * others fills the chip in whole rounds of resident workgroups
+inline int one_round(long work_items, long others, int per_cu) {
+  long gx = ((long)kCUs * per_cu) / (others > 0 ? others : 1);
+  if (gx < 1) gx = 1;
+  if (gx > work_items) gx = work_items;
+  return (int)gx;
+}
+
 void split_tiles(ConvArgs& a, int Wframe) {
   a.nsub = cdiv(Wframe, 16);
   a.wtiles = cdiv(a.nsub, 4);
@@ -509,11 +524,14 @@ template <int MODE>
 int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   const int NT = pick_nt(a.GnTot);
   const bool wlds = (a.GnTot == 1 && a.Gk == 1 && !cin1);
-  int gx = imin(a.tiles, cdiv((long)kCUs * 4, (long)a.B * (a.GnTot / NT)));
-  if (wlds) gx = imin(a.tiles, cdiv((long)kCUs * 3, a.B));
-  if (gx < 1) gx = 1;
-  const dim3 grid(gx, a.B, a.GnTot / NT), block(256);
-#define LC(NT_, WL_, C1_) hipLaunchKernelGGL((conv_kernel<MODE, NT_, WL_, C1_>), grid, block, 0, stream, a)
+  const int gz = a.GnTot / NT;
+  const dim3 block(256);
+#define LC(NT_, WL_, C1_)                                                                                     \
+  do {                                                                                                        \
+    auto kern = conv_kernel<MODE, NT_, WL_, C1_>;                                                             \
+    const dim3 grid(one_round(a.tiles, (long)a.B * gz, wg_per_cu(kern, 256)), a.B, gz);                       \
+    hipLaunchKernelGGL(kern, grid, block, 0, stream, a);                                                      \
+  } while (0)
   if (cin1) { if (NT == 1) LC(1, false, true); else if (NT == 2) LC(2, false, true); else if (NT == 3) LC(3, false, true); else LC(6, false, true); }
   else if (wlds) LC(1, true, false);
   else if (NT == 1) LC(1, false, false);
@@ -634,10 +652,10 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const int seg = ((cdiv(d->W, nseg) + 3) / 4) * 4 > kSegMax ? kSegMax : ((cdiv(d->W, nseg) + 3) / 4) * 4;
     const long bt = (long)(d->B / d->wsets) * a.To;
     int hrun = d->H;                       // shrink the run until the chip is covered ~3 times
-    while (hrun > 8 && bt * cdiv(d->H, hrun) * nseg * d->wsets < 3L * kCUs) hrun = (hrun + 1) / 2;
+    while (hrun > 8 && bt * cdiv(d->H, hrun) * nseg * d->wsets < 4L * kCUs) hrun = (hrun + 1) / 2;
     const int nhrun = cdiv(d->H, hrun);
     const long nchunks = bt * nhrun * nseg;
-    const dim3 grid(imin(nchunks, cdiv((long)kCUs * 2, d->wsets) > 0 ? cdiv((long)kCUs * 2, d->wsets) : 1), d->wsets);
+    const dim3 grid(one_round(nchunks, d->wsets, 1), d->wsets);   // 129 KB of LDS: one workgroup per CU
     if (rep) hipLaunchKernelGGL((wgrad16_lds_kernel<FWD_REP, 8>), grid, dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
     else hipLaunchKernelGGL((wgrad16_lds_kernel<FWD_S2, 8>), grid, dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
   }
