@@ -440,6 +440,137 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// weight gradient of the wide (2,3,3)-stride-2 convolutions (joint classifier head: 16*GA -> 16*GB
+// channels), LDS-staged.  A workgroup owns one (batch item, t_out, kt) and a run of rows of one row
+// segment; LDS holds a ring of 3 source rows of x (one-pixel zero halo) and the dy row.  The 9*GA
+// (tap, input-channel-block) A fragments are dealt round-robin to the 8 waves; every wave forms all GB
+// output-channel blocks for its fragments: 7 x 6 MFMAs per 13 four-byte LDS reads at GA = GB = 6.
+// ---------------------------------------------------------------------------------------------
+template <int GA, int GB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a, int seg, int nseg, int hrun, int nhrun) {
+  constexpr int CI = 16 * GA, CO = 16 * GB;
+  constexpr int PSX = CI + ((48 - CI % 32) % 32);   // pixel stride == 16 (mod 32) floats: conflict-free 4-byte reads
+  constexpr int PSY = CO + ((48 - CO % 32) % 32);
+  constexpr int NFRAG = 9 * GA;
+  constexpr int FPW = (NFRAG + WAVES - 1) / WAVES;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  const int rowlen = seg + 2, segp = (seg + 3) & ~3;
+  float* s_x = s_dyn;                               // [3][rowlen][PSX]
+  float* s_dy = s_dyn + 3 * rowlen * PSX;           // [segp][PSY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+
+  f32x4 acc[FPW][GB];
+  float bsum[GB];
+#pragma unroll
+  for (int f = 0; f < FPW; ++f)
+#pragma unroll
+    for (int n = 0; n < GB; ++n) acc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < GB; ++n) bsum[n] = 0.f;
+
+  // every workgroup keeps ONE kt for its whole life (so its accumulators belong to 9 fixed taps)
+  const int kt = blockIdx.z;
+  const int nb = a.B / a.wsets;
+  const long nchunks = (long)nb * a.To * nhrun * nseg;
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    long r = ch;
+    const int sg = (int)(r % nseg); r /= nseg;
+    const int hr = (int)(r % nhrun); r /= nhrun;
+    const int t = (int)(r % a.To);
+    const int b = (int)(r / a.To) * a.wsets + wset;
+    const int w0 = sg * seg;
+    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;
+    const float* x_bt = a.x + (long)b * a.x_sB + (long)(2 * t + kt) * a.x_sT;
+    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
+
+    for (int h = h0; h < h1; ++h) {
+      __syncthreads();
+      int slot_of[3];
+      bool ok_h[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const int hs = h + oh - 1;
+        ok_h[oh] = hs >= 0 && hs < a.H;
+        const int slot = ((hs % 3) + 3) % 3;
+        slot_of[oh] = slot;
+        if (!ok_h[oh]) continue;
+        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+        if (cur == hs) continue;
+        if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
+        const float* src = x_bt + (long)hs * a.x_sH;
+        float* dst = s_x + (long)slot * rowlen * PSX;
+        for (int u = tid; u < rowlen * (CI / 4); u += 64 * WAVES) {
+          const int px = u / (CI / 4), q = u % (CI / 4);       // q: 16-byte unit inside the pixel's channels
+          const int w = w0 + px - 1;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + (long)(q >> 2) * a.x_sG + 4 * (q & 3));
+          st4(dst + px * PSX + 4 * q, v);
+        }
+      }
+      {
+        const float* src = dy_b + (long)h * a.y_sH;
+        for (int u = tid; u < segp * (CO / 4); u += 64 * WAVES) {
+          const int px = u / (CO / 4), q = u % (CO / 4);
+          const int w = w0 + px;
+          const bool in = px < seg && w < a.W;
+          st4(s_dy + px * PSY + 4 * q, in ? ld4(src + (long)w * a.y_sW + (long)(q >> 2) * a.y_sG + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+      }
+      __syncthreads();
+
+      int base[FPW];
+      bool okf[FPW];
+#pragma unroll
+      for (int f = 0; f < FPW; ++f) {
+        const int fr = wave + f * WAVES;            // fragment id = tap9 * GA + ga
+        const int tap9 = fr / GA, ga = fr % GA;
+        const int oh = (tap9 / 3) % 3, ow = tap9 % 3;
+        okf[f] = fr < NFRAG && ok_h[oh];
+        base[f] = (slot_of[oh] * rowlen + ow + kq) * PSX + 16 * ga + r16;
+      }
+      const int steps = segp >> 2;
+      for (int s = 0; s < steps; ++s) {
+        float bf[GB];
+#pragma unroll
+        for (int n = 0; n < GB; ++n) { bf[n] = s_dy[(4 * s + kq) * PSY + 16 * n + r16]; bsum[n] += bf[n]; }
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+          if (!okf[f]) continue;
+          const float af = s_x[base[f] + s * 4 * PSX];
+#pragma unroll
+          for (int n = 0; n < GB; ++n) acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[f][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* dw = a.dwp + (long)wset * a.ntaps * CI * CO;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int f = 0; f < FPW; ++f) {
+    const int fr = wave + f * WAVES;
+    if (fr >= NFRAG) continue;
+    const int tap = kt * 9 + fr / GA, ga = fr % GA;
+#pragma unroll
+    for (int n = 0; n < GB; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(dw + ((long)tap * CI + 16 * ga + r0 + r) * CO + 16 * n + col, acc[f][n][r]);
+  }
+  if (a.dbias && wave == 0 && kt == 0) {
+#pragma unroll
+    for (int n = 0; n < GB; ++n) {
+      float v = bsum[n];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) atomicAdd(a.dbias + (long)wset * CO + 16 * n + lane, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight packing (reference layout (wsets, Cout, Cin, kt, kh, kw) -> MFMA fragment order)
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int wsets,
@@ -658,6 +789,31 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const dim3 grid(one_round(nchunks, d->wsets, 1), d->wsets);   // 129 KB of LDS: one workgroup per CU
     if (rep) hipLaunchKernelGGL((wgrad16_lds_kernel<FWD_REP, 8>), grid, dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
     else hipLaunchKernelGGL((wgrad16_lds_kernel<FWD_S2, 8>), grid, dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
+  }
+  else if (!rep && Ga == Gb && (Ga == 6 || Ga == 3 || Ga == 2)) {
+    // wide LDS-staged kernel: segment width from the LDS budget (ring of 3 x rows + dy row, padded pixel strides)
+    const int PSX = d->Cin + ((48 - d->Cin % 32) % 32), PSY = a.CoutPad + ((48 - a.CoutPad % 32) % 32);
+    const long budget = 150 * 1024 / 4;                                   // floats
+    int segmax = (int)((budget - 6L * PSX) / (3L * PSX + PSY)) & ~3;
+    if (segmax > 256) segmax = 256;
+    const int nseg = cdiv(d->W, segmax);
+    const int seg = ((cdiv(d->W, nseg) + 3) / 4) * 4;
+    const long btk = (long)(d->B / d->wsets) * a.To * 2;
+    int hrun = d->H;
+    while (hrun > 8 && btk * cdiv(d->H, hrun) * nseg * d->wsets < 3L * kCUs) hrun = (hrun + 1) / 2;
+    const int nhrun = cdiv(d->H, hrun);
+    const long nchunks = (long)(d->B / d->wsets) * a.To * nhrun * nseg;
+    const size_t lds = (size_t)(3L * (seg + 2) * PSX + (long)((seg + 3) & ~3) * PSY) * 4;
+    const dim3 grid(one_round(nchunks, 2L * d->wsets, 1), d->wsets, 2);
+#define LWW(G_)                                                                                                       \
+  do {                                                                                                                \
+    auto kern = wgrad_wide_lds_kernel<G_, G_, 8>;                                                                     \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
+      return idee::fail(IDEE_ERR_LAUNCH, "conv_wgrad: cannot reserve %zu bytes of LDS", lds);                          \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, seg, nseg, hrun, nhrun);                                    \
+  } while (0)
+    if (Ga == 6) LWW(6); else if (Ga == 3) LWW(3); else LWW(2);
+#undef LWW
   }
   else if (Ga == 1 && Gb == 1) { if (rep) LW(FWD_REP, 27, 1, 1); else LW(FWD_S2, 18, 1, 1); }
   else {
