@@ -316,7 +316,21 @@ def main():
     fx_e2e("swin_v2_14x18", ref_cfg(in_channels_dynamic=2), N=2, T=8, H=14, W=18, seed=500)
     fx_e2e("cnn_v2_12x16", ref_cfg(in_channels_dynamic=2, encoder="CNN_3D"), N=2, T=8, H=12, W=16, seed=600)
     fx_e2e("swin_v6_8x8_c2", ref_cfg(in_channels=2), N=1, T=8, H=8, W=8, seed=700, with_grads=False)
+    fx_config_defaults()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--config-only" not in sys.argv:
     main()
+
+
+def fx_config_defaults():
+    """Names and defaults of the reference's flag surface (config.py:18-189) as data."""
+    import json
+    cfg = vars(ref_config.add_all_arguments(argparse.ArgumentParser()).parse_args([]))
+    with open(os.path.join(HERE, "config_defaults.json"), "w") as f:
+        json.dump(cfg, f, indent=1, sort_keys=True, default=list)
+    print("config_defaults.json", len(cfg), "flags")
+
+
+if __name__ == "__main__" and "--config-only" in sys.argv:
+    fx_config_defaults()

@@ -1,0 +1,86 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares (no compute calls), the flag surface and the state-dict keys equal the reference's
+(golden data), and the product path refuses to run without a GPU instead of falling back."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from idee_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "idee_hip.h")).read()
+    declared = set(re.findall(r"\b(idee_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.idee_version().decode().startswith("idee_hip")
+    assert _lib.last_error() == ""
+
+
+def test_config_surface_equals_reference():
+    import argparse
+    from idee_amd import config
+    ref = json.load(open(os.path.join(GOLDEN, "config_defaults.json")))
+    mine = json.loads(json.dumps(vars(config.add_all_arguments(argparse.ArgumentParser()).parse_args([])), default=list))
+    assert mine == ref
+    c = config.read_arguments(train=False, argv=[])
+    assert c.phase == "test" and c.encoder == "Mamba"
+
+
+@pytest.mark.parametrize("tag,enc", [("swin_v6_8x8_c2", "Swin_3D"), ("swin_v2_14x18", "Swin_3D")])
+def test_state_dict_keys_shapes_roundtrip(tag, enc):
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    a, sd, _ = load_golden("e2e_" + tag)
+    m = VQ_model(default_config(encoder=enc, in_channels=int(a["cfg_C"]), in_channels_dynamic=int(a["cfg_V"])))
+    msd = m.state_dict()
+    assert list(msd) and set(msd) == set(sd)
+    assert all(tuple(msd[k].shape) == tuple(sd[k].shape) and msd[k].dtype == sd[k].dtype for k in sd)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert all(torch.equal(v, sd[k]) for k, v in m.state_dict().items())
+    bad = dict(sd); bad["encoder.bogus"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+    # the reference's count_parameters(model.encoder / .cls / .vq) sums (train_synthetic.py:108-111)
+    n = lambda mod: sum(p.numel() for p in mod.parameters() if p.requires_grad)
+    assert n(m) == sum(v.numel() for k, v in sd.items() if v.is_floating_point())
+
+
+def test_unknown_encoder_and_mamba_rejected():
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    with pytest.raises(NotImplementedError):
+        VQ_model(default_config())               # reference default 'Mamba' is outside the path
+    with pytest.raises(NotImplementedError):
+        VQ_model(default_config(encoder="Nope"))
+
+
+def test_no_cpu_fallback():
+    """A CPU tensor must raise (there is no CPU/eager path), and nothing under idee_amd imports the oracle."""
+    from idee_amd import _lib
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    m = VQ_model(default_config(encoder="Swin_3D", in_channels=1, in_channels_dynamic=2))
+    with pytest.raises(_lib.IdeeHipError):
+        m(torch.randn(1, 2, 1, 8, 8, 8))
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "idee_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_window_clamp_matches_oracle():
+    from idee_amd.ops import clamp_window
+    from oracle import idee_oracle as O
+    for ext in [(8, 200, 200), (8, 3, 5), (16, 4, 6), (1, 1, 1)]:
+        for w, s in [((2, 4, 4), (1, 2, 2)), ((8, 1, 1), (4, 0, 0))]:
+            assert clamp_window(ext, w, s) == O.get_window_size(ext, w, s)
