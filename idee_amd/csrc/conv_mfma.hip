@@ -741,7 +741,6 @@ extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const f
   const bool cin1 = d->Cout == 1;
   if (d->mode == IDEE_CONV_K333_REPLICATE) {
     IDEE_CHECK_ARG(!cin1, "conv_dgrad: Cout == 1 is only built for the (2,3,3) mode");
-    IDEE_CHECK_ARG(!accumulate, "conv_dgrad: accumulate is not built for the replicate mode (dx is zero-initialised)");
     split_tiles(a, a.Wo + 2);
     launch_conv<DGRAD_REP>(a, false, (hipStream_t)stream);
   } else {

@@ -62,8 +62,11 @@ class VQ_model(nn.Module):
                     getattr(mod, n).normal_(0.02, gain)
                 for n in bs:
                     getattr(mod, n).zero_()
-                for n in getattr(mod, "norm_names", lambda: ([], []))()[0]:
+                norm_w, norm_b = getattr(mod, "norm_names", lambda: ([], []))()
+                for n in norm_w:
                     getattr(mod, n).fill_(1.0)
+                for n in norm_b:
+                    getattr(mod, n).zero_()
             for lin in (self.vq.project_in, self.vq.project_out):
                 lin.weight.normal_(0.02, gain)
                 lin.bias.zero_()

@@ -391,3 +391,41 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
     """In-place torch.optim.Adam update of the flat buffers (train_synthetic.py:127-129)."""
     L.call("idee_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, int(step),
            grad_scale, L.stream())
+
+
+class ConvLNUnit(torch.autograd.Function):
+    """One unit of the CNN_3D encoder's conv_block: y = x + ReLU(LayerNorm_affine(conv3x3x3_replicate(x))),
+    per variable, conv without bias.  x (N,V,T,H,W,C); w (V,C,C,3,3,3); gamma, beta (V,C).
+    Reference: conv_block.forward, models/encoder/CNN_3D.py:131-142."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta):
+        x, w, gamma, beta = (_f32c(t) for t in (x, w, gamma, beta))
+        N, V, T, H, W, Cc = x.shape
+        s = _cl_strides(T, H, W, Cc)
+        conv = ConvLayer(L.CONV_K333_REPLICATE, N * V, V, T, H, W, Cc, Cc, s, s, False)
+        pf, pd = conv.pack(w)
+        c = torch.empty_like(x)
+        conv.fwd(x, pf, None, c)
+        y = torch.empty_like(x)
+        L.call("idee_ln_relu_res_fwd", ptr(c), ptr(gamma), ptr(beta), ptr(x), ptr(y), N * V, V, T * H * W, Cc, L.stream())
+        ctx.save_for_backward(x, c, w, gamma, beta, pd)
+        ctx.conv = conv
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, c, w, gamma, beta, pd = ctx.saved_tensors
+        conv = ctx.conv
+        N, V, T, H, W, Cc = x.shape
+        dy = _f32c(dy)
+        dc = torch.empty_like(c)
+        dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(beta)
+        L.call("idee_ln_relu_res_bwd", ptr(c), ptr(gamma), ptr(beta), ptr(dy), ptr(dc), ptr(dgamma), ptr(dbeta), N * V, V,
+               T * H * W, Cc, L.stream())
+        dw, _ = conv.wgrad(x, dc, w, want_bias=False)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = dy.clone()                      # the shortcut's gradient; the conv's data gradient is added to it
+            conv.dgrad(dc, pd, None, dx, accumulate=True)
+        return dx, dw, dgamma, dbeta

@@ -132,8 +132,8 @@ int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, float* packe
 int idee_conv_fwd(const idee_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
                   idee_stream_t stream);
 /* dx = conv^T(dy) [* (relu_ref > 0) if relu_ref != NULL; same layout as x]; accumulate != 0: dx += ...
- * REPLICATE mode: dx must be zero-initialised (edge columns are accumulated with atomics) and
- * accumulate must be 0. */
+ * REPLICATE mode: the two edge columns are accumulated with atomics, so dx must be initialised by the caller:
+ * zeros with accumulate == 0, or any addend (e.g. a residual gradient) with accumulate != 0. */
 int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
                     float* dx, int accumulate, idee_stream_t stream);
 /* dw_packed (wsets, taps, Cin, CoutPad) and dbias (wsets, CoutPad) | NULL accumulate */
@@ -141,6 +141,17 @@ int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const float* dy, fl
                     idee_stream_t stream);
 /* packed weight gradient -> reference layout (wsets, Cout, Cin, kt, kh, kw) (overwrites) */
 int idee_conv_unpack_wgrad(const idee_conv_desc* d, const float* dw_packed, float* dw, idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tail of the CNN_3D encoder's conv_block unit: y = shortcut + ReLU(LayerNorm_affine(c)), c = conv output.
+ * Replaces conv_block.forward, models/encoder/CNN_3D.py:131-142 (the permute/view pairs disappear).
+ *   c, shortcut, y, dy, dc: (B, L, E) channels-last; gamma, beta: (V, E); item b uses set b % V
+ * bwd: dc overwritten; dgamma, dbeta accumulate; d(shortcut) = dy is the caller's.
+ * ---------------------------------------------------------------------------------------- */
+int idee_ln_relu_res_fwd(const float* c, const float* gamma, const float* beta, const float* shortcut, float* y, int B,
+                         int V, long L, int E, idee_stream_t stream);
+int idee_ln_relu_res_bwd(const float* c, const float* gamma, const float* beta, const float* dy, float* dc, float* dgamma,
+                         float* dbeta, int B, int V, long L, int E, idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Lookup-free quantisation with projections (dim -> log2 K -> dim), straight-through gradient,

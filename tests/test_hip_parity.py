@@ -149,6 +149,32 @@ def test_proj_var_golden():
         gclose("d" + k, p.grad[0], grads[k])
 
 
+@pytest.mark.parametrize("tag,cin", [("1_16", 1), ("16_16", 16)])
+def test_conv_block_golden(tag, cin):
+    """CNN_3D encoder block: [PatchEmbed+LN] -> 2 x (x + ReLU(LN_affine(conv3^3 replicate(x))))."""
+    ops = _ops()
+    a, sd, grads = load_golden("conv_block_" + tag)
+    leaf = lambda t: dev(t).unsqueeze(0).contiguous().requires_grad_()
+    ps = {k: leaf(sd[k]) for k in ("conv1.weight", "norm1.weight", "norm1.bias", "conv2.weight", "norm2.weight", "norm2.bias")}
+    if cin == 16:
+        x = dev(a["x"]).permute(0, 2, 3, 4, 1).unsqueeze(1).contiguous().requires_grad_()
+        t = x
+    else:
+        x = dev(a["x"]).unsqueeze(1).contiguous()
+        ps["downsample.proj.weight"] = dev(sd["downsample.proj.weight"]).flatten(1).unsqueeze(0).contiguous().requires_grad_()
+        t = ops.PatchEmbedLN.apply(x, ps["downsample.proj.weight"], None)
+    t = ops.ConvLNUnit.apply(t, ps["conv1.weight"], ps["norm1.weight"], ps["norm1.bias"])
+    t = ops.ConvLNUnit.apply(t, ps["conv2.weight"], ps["norm2.weight"], ps["norm2.bias"])
+    y = t[:, 0].permute(0, 4, 1, 2, 3)
+    close("y", y, a["y"])
+    (y * dev(a["r"])).sum().backward()
+    if cin == 16:
+        gclose_relu("dx", x.grad[:, 0].permute(0, 4, 1, 2, 3), a["dx"])
+    for k, p in ps.items():
+        gref = grads[k].flatten(1) if k == "downsample.proj.weight" else grads[k]
+        gclose_relu("d" + k, p.grad[0], gref)
+
+
 @pytest.mark.parametrize("T,H,W", [(8, 9, 72), (3, 5, 200), (1, 1, 1), (2, 2, 17)])
 def test_proj_var_vs_oracle(T, H, W):
     """Multi-tile widths (72 = 3+2 column blocks, 200 = 4+3+3+3), thin extents (clamp-everything cases)."""
@@ -323,7 +349,7 @@ def _safe_tokens(a, sd, cfg):
     return (s.abs() > 1e-5).all(-1)                                                                  # (N,V,T,H,W)
 
 
-@pytest.mark.parametrize("tag", ["swin_v2_14x18", "swin_v6_8x8_c2"])
+@pytest.mark.parametrize("tag", ["swin_v2_14x18", "swin_v6_8x8_c2", "cnn_v2_12x16"])
 def test_e2e_eval_forward_golden(tag):
     from idee_amd.models.build import VQ_model
     a, sd, _ = load_golden("e2e_" + tag)
@@ -344,12 +370,13 @@ def test_e2e_eval_forward_golden(tag):
     assert zq.shape == a["eval/z_q"].shape and an.dtype == torch.int64
 
 
-def test_e2e_train_steps_golden():
+@pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16"])
+def test_e2e_train_steps_golden(tag):
     """3 full steps of the train_synthetic.py sequence (fused step object) vs the reference's
     outputs, losses, all gradients and the parameters after 3 Adam steps."""
     from idee_amd.models.build import VQ_model
     from idee_amd.train import SyntheticTrainStep
-    a, sd, grads = load_golden("e2e_swin_v2_14x18")
+    a, sd, grads = load_golden("e2e_" + tag)
     cfg = _cfg_from(a)
     m = VQ_model(cfg)
     m.load_state_dict(sd, strict=True)
