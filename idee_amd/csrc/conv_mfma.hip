@@ -82,7 +82,7 @@ __device__ __forceinline__ int src_w(int o, int p, int Wi, bool& ok) {
 }
 
 template <int MODE, int NT, bool WLDS, bool CIN1>
-__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, NT >= 6 ? 2 : 1) void conv_kernel(ConvArgs a) {
   constexpr int MT = 4;
   __shared__ __attribute__((aligned(16))) float s_w[WLDS ? 27 * 256 : 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -433,11 +433,13 @@ __device__ __forceinline__ void layer_norm_bwd_tl(const f32x4 (&dxn)[CT][MT], co
 //   in: h (block state before the MLP, saved by the forward), dy.  out: dh = dL/dh, MLP weight grads.
 // ---------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_kernel(
+__global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
     const float* __restrict__ hs, const float* __restrict__ dy, float* __restrict__ dh, const float* __restrict__ fc1_w,
     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float* __restrict__ g_fc1_w,
     float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L) {
   constexpr int CT = C / 16, HID = 4 * C, HT = HID / 16;
+  constexpr int HP = 2;                 // hidden 16-blocks per pass (keeps the live set within 256 registers)
+  static_assert(HT % HP == 0, "hidden blocks per pass");
   __shared__ __attribute__((aligned(16))) float s_img[4][(2 * CT + 2) * 16 * VS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -446,17 +448,6 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_kernel(
   g_fc1_w += (long)v * HID * C;  g_fc1_b += v * HID;  g_fc2_w += (long)v * C * HID;  g_fc2_b += v * C;
   hs += (long)b * L * C;  dy += (long)b * L * C;  dh += (long)b * L * C;
 
-  f32x4 w1[HT][CT], b1[HT], w2t[HT][CT], w1t[CT][HT];
-#pragma unroll
-  for (int o = 0; o < HT; ++o) {
-    b1[o] = vfrag<1>(fc1_b, 16 * o, lane);
-#pragma unroll
-    for (int k = 0; k < CT; ++k) {
-      w1[o][k] = wfrag<false, 1, 1>(fc1_w, C, 16 * o, 16 * k, lane);
-      w2t[o][k] = wfrag<true, 1, 1>(fc2_w, HID, 16 * o, 16 * k, lane);    // [hid][c] = fc2_w[c][hid]
-      w1t[k][o] = wfrag<true, 1, 1>(fc1_w, C, 16 * k, 16 * o, lane);      // [c][hid] = fc1_w[hid][c]
-    }
-  }
   f32x4 aW1[HT][CT], aW2[CT][HT], pb1[HT], pb2[CT];
 #pragma unroll
   for (int o = 0; o < HT; ++o) {
@@ -477,46 +468,88 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_kernel(
   for (long it0 = (long)blockIdx.x * 4; it0 < items; it0 += (long)gridDim.x * 4) {
     const long base = (it0 + wave) * 64;
     bool valid[MT];
-    f32x4 Hs[CT][MT], DY[CT][MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const long tok = base + 16 * m + j;
-      valid[m] = tok < L;
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        Hs[c][m] = valid[m] ? ld4(hs + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
-        DY[c][m] = valid[m] ? ld4(dy + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    f32x4 HN[CT][MT];
+    f32x4 HN[CT][MT], DY[CT][MT];
     float rstd2[MT];
-    bool all[MT] = {true, true, true, true};
-    layer_norm_tl<CT>(Hs, HN, rstd2, all);
-    f32x4 A1[HT][MT], dG[HT][MT];
-#pragma unroll
-    for (int o = 0; o < HT; ++o)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) { A1[o][m] = b1[o]; dG[o][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    mm<HT, CT>(A1, w1, HN);
-    mm<HT, CT>(dG, w2t, DY);
-#pragma unroll
-    for (int o = 0; o < HT; ++o)
+    {
+      f32x4 Hs[CT][MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
+        const long tok = base + 16 * m + j;
+        valid[m] = tok < L;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = A1[o][m][r];
-          dG[o][m][r] *= gelu_grad(a);      // dG now holds dA1
-          A1[o][m][r] = gelu(a);            // A1 now holds gelu(A1)
+        for (int c = 0; c < CT; ++c) {
+          Hs[c][m] = valid[m] ? ld4(hs + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+          DY[c][m] = valid[m] ? ld4(dy + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        pb1[o] += dG[o][m];
       }
+      bool all[MT] = {true, true, true, true};
+      layer_norm_tl<CT>(Hs, HN, rstd2, all);
+    }
+    __syncthreads();   // previous iteration's image readers are done
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      put_img<1>(imgHN + c * 16 * VS, HN[c], lane);
+      put_img<1>(imgDY + c * 16 * VS, DY[c], lane);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) pb2[c] += DY[c][m];
+    }
     f32x4 dHN[CT][MT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) { dHN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pb2[c] += DY[c][m]; }
-    mm<CT, HT>(dHN, w1t, dG);
+      for (int m = 0; m < MT; ++m) dHN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int hp = 0; hp < HT / HP; ++hp) {
+      // fragments of this pass (L1/L2-resident; re-read each pass instead of pinning 48 registers)
+      f32x4 w1[HP][CT], w2t[HP][CT], w1t[CT][HP], A1[HP][MT], dG[HP][MT];
+      int oz;   // opaque zero: pins this pass's fragment loads inside the pass (no hoisting across passes)
+      asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+      const float* fc1_w_ = fc1_w + oz;
+      const float* fc2_w_ = fc2_w + oz;
+#pragma unroll
+      for (int o = 0; o < HP; ++o) {
+        const int ho = hp * HP + o;
+        const f32x4 b1 = vfrag<1>(fc1_b + oz, 16 * ho, lane);
+#pragma unroll
+        for (int k = 0; k < CT; ++k) {
+          w1[o][k] = wfrag<false, 1, 1>(fc1_w_, C, 16 * ho, 16 * k, lane);
+          w2t[o][k] = wfrag<true, 1, 1>(fc2_w_, HID, 16 * ho, 16 * k, lane);   // [hid][c] = fc2_w[c][hid]
+          w1t[k][o] = wfrag<true, 1, 1>(fc1_w_, C, 16 * k, 16 * ho, lane);     // [c][hid] = fc1_w[hid][c]
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { A1[o][m] = b1; dG[o][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+      mm<HP, CT>(A1, w1, HN);
+      mm<HP, CT>(dG, w2t, DY);
+#pragma unroll
+      for (int o = 0; o < HP; ++o)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = A1[o][m][r];
+            dG[o][m][r] *= gelu_grad(a);      // dG now holds dA1
+            A1[o][m][r] = gelu(a);            // A1 now holds gelu(A1)
+          }
+          pb1[hp * HP + o] += dG[o][m];
+        }
+      mm<CT, HP>(dHN, w1t, dG);
+      // weight gradients of this pass: dW1[hid][c] += dA1 . HN^T ; dW2[c][hid] += DY . G^T  (K = tokens)
+#pragma unroll
+      for (int o = 0; o < HP; ++o) {
+        const int ho = hp * HP + o;
+        if (hp + o) __syncthreads();
+        put_img<1>(imgA, dG[o], lane);
+        put_img<1>(imgB, A1[o], lane);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          gemm_tok(aW1[ho][c], imgA, imgHN + c * 16 * VS, lane);
+          gemm_tok(aW2[c][ho], imgDY + c * 16 * VS, imgB, lane);
+        }
+      }
+    }
     f32x4 dH[CT][MT];
     layer_norm_bwd_tl<CT>(dHN, HN, rstd2, DY, dH);
 #pragma unroll
@@ -524,23 +557,6 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_kernel(
       if (valid[m])
 #pragma unroll
         for (int c = 0; c < CT; ++c) st4(dh + (base + 16 * m + j) * C + 16 * c + 4 * kq, dH[c][m]);
-
-    // weight gradients: dW1[hid][c] += dA1 . HN^T ; dW2[c][hid] += DY . G^T  (K = tokens)
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CT; ++c) { put_img<1>(imgHN + c * 16 * VS, HN[c], lane); put_img<1>(imgDY + c * 16 * VS, DY[c], lane); }
-#pragma unroll
-    for (int o = 0; o < HT; ++o) {
-      if (o) __syncthreads();
-      put_img<1>(imgA, dG[o], lane);
-      put_img<1>(imgB, A1[o], lane);
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        gemm_tok(aW1[o][c], imgA, imgHN + c * 16 * VS, lane);
-        gemm_tok(aW2[c][o], imgDY + c * 16 * VS, imgB, lane);
-      }
-    }
   }
 #pragma unroll
   for (int o = 0; o < HT; ++o) {
@@ -986,7 +1002,7 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
   const long L = (long)s->D * s->H * s->W;
   hipStream_t st = (hipStream_t)stream;
   {   // part 1: MLP + norm2 (token order)
-    const dim3 grid = swin_grid(cdiv(cdiv(L, 64), 4), B, C == 16 ? 2 : 1);
+    const dim3 grid = swin_grid(cdiv(cdiv(L, 64), 4), B, 1);
     if (C == 16)
       hipLaunchKernelGGL((swin_mlp_bwd_kernel<16>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
                          p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
