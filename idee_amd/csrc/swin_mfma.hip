@@ -52,6 +52,29 @@ __device__ __forceinline__ float gelu_grad(float a) {
   return 0.5f * (1.f + erf_fast(a * 0.70710678118654752f)) + a * 0.39894228040143268f * __expf(-0.5f * a * a);
 }
 
+// gelu(a) and d gelu / da with ONE exp: exp(-a^2/2) serves both the erf tail and the Gaussian density
+__device__ __forceinline__ void gelu_both(float a, float& gl, float& dgl) {
+  const float x = a * 0.70710678118654752f, ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float E = __expf(-0.5f * a * a);
+  const float phi = 0.5f * (1.f + copysignf(1.f - p * t * E, x));   // Phi(a)
+  gl = a * phi;
+  dgl = fmaf(a * 0.39894228040143268f, E, phi);
+}
+
+// All LDS in these kernels is private to a wave (indexed by the wave id), and the LDS unit executes one wave's
+// DS instructions in order, so exchanging data between the lanes of a wave needs no s_barrier: only the compiler
+// must be kept from moving LDS accesses across the hand-off point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // channel permutation inside a 16-chunk: position i = 4*kq + r  ->  channel.  HPC heads per chunk.
 template <int HPC>
 __device__ __forceinline__ int sig(int i) {
@@ -251,7 +274,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
       for (int m = 0; m < MT; ++m) QKV[o][m] = bq[o];
     mm<3 * CT, CT>(QKV, wq, XN);
 
-    __syncthreads();   // previous iteration's readers of vt / rid are done
+    wave_sync();   // previous iteration's readers of vt / rid are done
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
     if (kq == 0)
 #pragma unroll
       for (int m = 0; m < MT; ++m) rid_l[16 * m + j] = t[m].rid;
-    __syncthreads();
+    wave_sync();
 
     f32x4 O[CT][MT];
 #pragma unroll
@@ -485,7 +508,7 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
       bool all[MT] = {true, true, true, true};
       layer_norm_tl<CT>(Hs, HN, rstd2, all);
     }
-    __syncthreads();   // previous iteration's image readers are done
+    wave_sync();   // previous iteration's image readers are done
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       put_img<1>(imgHN + c * 16 * VS, HN[c], lane);
@@ -528,9 +551,10 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float a = A1[o][m][r];
-            dG[o][m][r] *= gelu_grad(a);      // dG now holds dA1
-            A1[o][m][r] = gelu(a);            // A1 now holds gelu(A1)
+            float gl, dgl;
+            gelu_both(A1[o][m][r], gl, dgl);
+            dG[o][m][r] *= dgl;               // dG now holds dA1
+            A1[o][m][r] = gl;                 // A1 now holds gelu(A1)
           }
           pb1[hp * HP + o] += dG[o][m];
         }
@@ -539,10 +563,10 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
 #pragma unroll
       for (int o = 0; o < HP; ++o) {
         const int ho = hp * HP + o;
-        if (hp + o) __syncthreads();
+        if (hp + o) wave_sync();
         put_img<1>(imgA, dG[o], lane);
         put_img<1>(imgB, A1[o], lane);
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           gemm_tok(aW1[ho][c], imgA, imgHN + c * 16 * VS, lane);
@@ -689,7 +713,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
       for (int m = 0; m < MT; ++m) { DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pbp[c] += DH[c][m]; }
     mm<CT, CT>(DO, wpt, DH);
 
-    __syncthreads();   // previous iteration's image readers are done
+    wave_sync();   // previous iteration's image readers are done
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       put_img<HPC>(imgQ + c * IMG, QKV[c], lane);
@@ -700,7 +724,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
     if (kq == 0)
 #pragma unroll
       for (int m = 0; m < MT; ++m) rid_l[16 * m + j] = t[m].rid;
-    __syncthreads();
+    wave_sync();
 
     f32x4 O[CT][MT], DQ[CT][MT], DK[CT][MT], DV[CT][MT];
 #pragma unroll
@@ -729,7 +753,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
             }
             P[kt][qt] = acc; dP[kt][qt] = accd;
           }
-        __syncthreads();   // stats of the previous (group, head) fully consumed
+        wave_sync();   // stats of the previous (group, head) fully consumed
 #pragma unroll
         for (int qt = 0; qt < TPW; ++qt) {
           float mx = -3.0e38f;
@@ -774,7 +798,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
           for (int r = 0; r < SP; ++r) { O[c][grp * TPW + qt][s0 + r] = acco[s0 + r]; DQ[c][grp * TPW + qt][s0 + r] = accq[s0 + r]; }
         }
-        __syncthreads();   // stats visible
+        wave_sync();   // stats visible
         // ---- column pass: S^T, P^T, dS^T with queries on rows, key on the column ----
         f32x4 PT[TPW][TPW], dST[TPW][TPW];   // [qt][kt]
 #pragma unroll
@@ -857,21 +881,21 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
     // token-reduction GEMMs through the scratch images
 #pragma unroll
     for (int ca = 0; ca < CT; ++ca) {        // dproj_w rows (c) from dH, cols (c') from O
-      __syncthreads();
+      wave_sync();
       put_img<1>(imgA, DH[ca], lane);
       if (ca == 0)
 #pragma unroll
         for (int cb = 0; cb < CT; ++cb) put_img<HPC>(imgB + cb * IMG, O[cb], lane);
-      __syncthreads();
+      wave_sync();
 #pragma unroll
       for (int cb = 0; cb < CT; ++cb) gemm_tok(aWp[ca][cb], imgA, imgB + cb * IMG, lane);
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int cb = 0; cb < CT; ++cb) put_img<1>(imgB + cb * IMG, XN[cb], lane);
 #pragma unroll
     for (int o = 0; o < 3 * CT; ++o) {
-      __syncthreads();
+      wave_sync();
       if (o < CT) {
         f32x4 tmp[MT];
 #pragma unroll
@@ -879,7 +903,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
         put_img<HPC>(imgA, tmp, lane);
       } else if (o < 2 * CT) put_img<HPC>(imgA, DK[o - CT], lane);
       else put_img<HPC>(imgA, DV[o - 2 * CT], lane);
-      __syncthreads();
+      wave_sync();
 #pragma unroll
       for (int cb = 0; cb < CT; ++cb) gemm_tok(aWq[o][cb], imgA, imgB + cb * IMG, lane);
     }
