@@ -613,6 +613,194 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The single-class output convs (Cout == 1, (2,3,3) stride 2 over T = 2: classifier conv3,
+// classifier/CNN_3D.py:40,85).  They are memory-bound dot products, not GEMMs: streaming kernels, lanes
+// of a pixel own 4 channels each (16-byte accesses), weights read from the packed fragment buffers.
+// ---------------------------------------------------------------------------------------------
+struct C1Args {
+  const float* x;      // (B, 2, H, W, C) by strides
+  const float* w;      // packed fragments (fwd or dgrad order)
+  const float* bias;   // (wsets) or null
+  const float* dy;     // (B, H, W)
+  const float* relu_ref;
+  float* y;            // fwd: (B, H, W)
+  float* dx;           // dgrad: like x
+  float* dwp;          // wgrad: (wsets, 18, C, 16)
+  float* dbias;        // (wsets, 16) or null
+  int B, wsets, H, W, C;
+  long x_sB, x_sT, x_sH, x_sW, x_sG;
+  int accumulate;
+};
+// weight of (tap, cin) for cout 0 in the packed buffers
+__device__ __forceinline__ f32x4 c1_w4_fwd(const float* wp, int Gi, int tap, int c4 /* cin = 4*c4 .. +3 */) {
+  const int cin = 4 * c4;
+  return ld4(wp + ((long)(tap * Gi + cin / 16) * 64 + ((cin % 16) / 4) * 16) * 4);
+}
+__device__ __forceinline__ float c1_w_dgrad(const float* wp, int Gi, int tap, int cin) {
+  return wp[((long)(tap * Gi + cin / 16) * 64 + cin % 16) * 4];
+}
+
+// LPP lanes per pixel (power of two >= C/4); lanes q >= C/4 idle
+template <int LPP>
+__global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
+  const int QC = a.C / 4, Gi = a.C / 16;
+  const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
+  const long npix = (long)a.B * a.H * a.W;
+  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
+    const long p = p0 + pl;
+    float acc = 0.f;
+    int b = 0;
+    if (p < npix && q < QC) {
+      const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H);
+      b = (int)(p / ((long)a.W * a.H));
+      const float* wp = a.w + (long)(b % a.wsets) * 18 * Gi * 256;
+      const float* xb = a.x + (long)b * a.x_sB + (long)(q / 4) * a.x_sG + 4 * (q % 4);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int oh = 0; oh < 3; ++oh) {
+          const int hs = h + oh - 1;
+          if (hs < 0 || hs >= a.H) continue;
+#pragma unroll
+          for (int ow = 0; ow < 3; ++ow) {
+            const int ws = w + ow - 1;
+            if (ws < 0 || ws >= a.W) continue;
+            const f32x4 xv = ld4(xb + (long)kt * a.x_sT + (long)hs * a.x_sH + (long)ws * a.x_sW);
+            const f32x4 wv = c1_w4_fwd(wp, Gi, (kt * 3 + oh) * 3 + ow, q);
+            acc = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc))));
+          }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LPP; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (p < npix && q == 0) a.y[p] = acc + (a.bias ? a.bias[b % a.wsets] : 0.f);
+  }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
+  const int QC = a.C / 4, Gi = a.C / 16;
+  const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
+  const long npix = (long)a.B * 2 * a.H * a.W;       // input pixels (b, kt, h, w)
+  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
+    const long p = p0 + pl;
+    if (p >= npix || q >= QC) continue;
+    const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H), kt = (int)((p / ((long)a.W * a.H)) % 2);
+    const int b = (int)(p / ((long)a.W * a.H * 2));
+    const float* wp = a.w + (long)(b % a.wsets) * 18 * Gi * 256;
+    const float* dyb = a.dy + (long)b * a.H * a.W;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int oh = 0; oh < 3; ++oh) {
+      const int hq = h - (oh - 1);
+      if (hq < 0 || hq >= a.H) continue;
+#pragma unroll
+      for (int ow = 0; ow < 3; ++ow) {
+        const int wq = w - (ow - 1);
+        if (wq < 0 || wq >= a.W) continue;
+        const float g = dyb[(long)hq * a.W + wq];
+        const int tap = (kt * 3 + oh) * 3 + ow;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fmaf(g, c1_w_dgrad(wp, Gi, tap, 4 * q + u), acc[u]);
+      }
+    }
+    const long off = (long)b * a.x_sB + (long)kt * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + (long)(q / 4) * a.x_sG + 4 * (q % 4);
+    if (a.relu_ref) {
+      const f32x4 rr = ld4(a.relu_ref + off);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = rr[u] > 0.f ? acc[u] : 0.f;
+    }
+    if (a.accumulate) acc += ld4(a.dx + off);
+    st4(a.dx + off, acc);
+  }
+}
+
+// dW[tap][c] = sum_{b,h,w} x[b][kt][h+oh-1][w+ow-1][c] dy[b][h][w]: every x value is read once and spread over its 9 taps
+template <int LPP>
+__global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
+  __shared__ float s_red[256 / LPP][LPP][4];
+  const int QC = a.C / 4;
+  const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
+  const int wset = blockIdx.y;
+  const int nb = a.B / a.wsets;
+  const long npix = (long)nb * a.H * a.W;            // source pixels per kt for this weight set
+  f32x4 acc[2][9];
+  float bsum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
+    const long p = p0 + pl;
+    if (p >= npix || q >= QC) continue;
+    const int ws = (int)(p % a.W), hs = (int)((p / a.W) % a.H);
+    const int b = (int)(p / ((long)a.W * a.H)) * a.wsets + wset;
+    const float* dyb = a.dy + (long)b * a.H * a.W;
+    float g[9];
+#pragma unroll
+    for (int oh = 0; oh < 3; ++oh)
+#pragma unroll
+      for (int ow = 0; ow < 3; ++ow) {
+        const int h = hs - (oh - 1), w = ws - (ow - 1);      // output pixel this source feeds through tap (oh, ow)
+        g[oh * 3 + ow] = (h >= 0 && h < a.H && w >= 0 && w < a.W) ? dyb[(long)h * a.W + w] : 0.f;
+      }
+    if (q == 0) bsum += g[4];
+    const float* xb = a.x + (long)b * a.x_sB + (long)hs * a.x_sH + (long)ws * a.x_sW + (long)(q / 4) * a.x_sG + 4 * (q % 4);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const f32x4 xv = ld4(xb + (long)kt * a.x_sT);
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] += xv * g[t9];
+    }
+  }
+  // reduce over the pixel lanes of the block, then one atomic per (tap, channel)
+  float* dw = a.dwp + (long)wset * 18 * a.C * 16;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s_red[pl][q][u] = acc[kt][t9][u];
+      __syncthreads();
+      if (pl == 0 && q < QC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float s = 0.f;
+          for (int i = 0; i < PPB; ++i) s += s_red[i][q][u];
+          atomicAdd(dw + ((long)(kt * 9 + t9) * a.C + 4 * q + u) * 16, s);
+        }
+      }
+    }
+  if (a.dbias) {
+    bsum = wave_sum(bsum);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.dbias + (long)wset * 16, bsum);
+  }
+}
+
+int launch_c1(int which, C1Args& a, hipStream_t st) {
+  const int QC = a.C / 4;
+  const int LPP = QC <= 4 ? 4 : QC <= 8 ? 8 : QC <= 16 ? 16 : QC <= 32 ? 32 : 64;
+  if (QC > 64) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): Cin %d > 256 is not built", a.C);
+  const int PPB = 256 / LPP;
+  const long npix = which == 1 ? (long)a.B * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * a.W : (long)(a.B / a.wsets) * a.H * a.W);
+  const int gx = imin(cdiv(npix, PPB), kCUs * (which == 2 ? 4 : 8));
+  const dim3 grid(gx, which == 2 ? a.wsets : 1);
+#define C1(K) do { if (LPP == 4) hipLaunchKernelGGL((K<4>), grid, dim3(256), 0, st, a); else if (LPP == 8) hipLaunchKernelGGL((K<8>), grid, dim3(256), 0, st, a); \
+  else if (LPP == 16) hipLaunchKernelGGL((K<16>), grid, dim3(256), 0, st, a); else if (LPP == 32) hipLaunchKernelGGL((K<32>), grid, dim3(256), 0, st, a); \
+  else hipLaunchKernelGGL((K<64>), grid, dim3(256), 0, st, a); } while (0)
+  if (which == 0) C1(c1_fwd_kernel); else if (which == 1) C1(c1_dgrad_kernel); else C1(c1_wgrad_kernel);
+#undef C1
+  return IDEE_OK;
+}
+bool is_c1(const idee_conv_desc* d) { return d->Cout == 1 && d->mode == IDEE_CONV_K233_S2_ZERO && d->T == 2; }
+void fill_c1(C1Args& a, const idee_conv_desc* d) {
+  memset(&a, 0, sizeof(a));
+  a.B = d->B; a.wsets = d->wsets; a.H = d->H; a.W = d->W; a.C = d->Cin;
+  a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;
+}
+
 int check_desc(const idee_conv_desc* d) {
   IDEE_CHECK_ARG(d, "conv: null descriptor");
   IDEE_CHECK_ARG(d->mode == IDEE_CONV_K333_REPLICATE || d->mode == IDEE_CONV_K233_S2_ZERO, "conv: bad mode %d", d->mode);
@@ -709,6 +897,13 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const float* x, const floa
                              idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   IDEE_CHECK_ARG(x && w_packed && y, "conv_fwd: null argument");
+  if (is_c1(d) && d->y_sW == 1 && d->y_sH == d->W && d->y_sB == (long)d->H * d->W) {
+    C1Args c; fill_c1(c, d);
+    c.x = x; c.w = w_packed; c.bias = bias; c.y = y;
+    if (int rc = launch_c1(0, c, (hipStream_t)stream)) return rc;
+    IDEE_LAUNCH_CHECK("conv_fwd");
+    return IDEE_OK;
+  }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = x; a.wp = w_packed; a.bias = bias; a.relu_ref = nullptr; a.out = y;
@@ -729,6 +924,13 @@ extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const f
                                float* dx, int accumulate, idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   IDEE_CHECK_ARG(dy && w_packed_dgrad && dx, "conv_dgrad: null argument");
+  if (is_c1(d) && d->y_sW == 1 && d->y_sH == d->W && d->y_sB == (long)d->H * d->W) {
+    C1Args c; fill_c1(c, d);
+    c.dy = dy; c.w = w_packed_dgrad; c.relu_ref = relu_ref; c.dx = dx; c.accumulate = accumulate;
+    if (int rc = launch_c1(1, c, (hipStream_t)stream)) return rc;
+    IDEE_LAUNCH_CHECK("conv_dgrad");
+    return IDEE_OK;
+  }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = dy; a.wp = w_packed_dgrad; a.bias = nullptr; a.relu_ref = relu_ref; a.out = dx; a.accumulate = accumulate;
@@ -755,6 +957,13 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
                                idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   IDEE_CHECK_ARG(x && dy && dw_packed, "conv_wgrad: null argument");
+  if (is_c1(d) && d->y_sW == 1 && d->y_sH == d->W && d->y_sB == (long)d->H * d->W) {
+    C1Args c; fill_c1(c, d);
+    c.x = x; c.dy = dy; c.dwp = dw_packed; c.dbias = dbias;
+    if (int rc = launch_c1(2, c, (hipStream_t)stream)) return rc;
+    IDEE_LAUNCH_CHECK("conv_wgrad");
+    return IDEE_OK;
+  }
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.dy = dy; a.dwp = dw_packed; a.dbias = dbias;
