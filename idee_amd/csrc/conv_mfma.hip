@@ -683,26 +683,35 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
   const int QC = a.C / 4, Gi = a.C / 16;
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
   const long npix = (long)a.B * 2 * a.H * a.W;       // input pixels (b, kt, h, w)
-  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
+  // this lane's 4 channels of all 18 taps, once (requires one weight set per launch column: blockIdx.y = wset)
+  const int wset = blockIdx.y;
+  f32x4 wr[18];
+  if (q < QC) {
+    const float* wp = a.w + (long)wset * 18 * Gi * 256;
+#pragma unroll
+    for (int tap = 0; tap < 18; ++tap)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wr[tap][u] = c1_w_dgrad(wp, Gi, tap, 4 * q + u);
+  }
+  const int nb = a.B / a.wsets;
+  const long npw = (long)nb * 2 * a.H * a.W;
+  (void)npix;
+  for (long p0 = (long)blockIdx.x * PPB; p0 < npw; p0 += (long)gridDim.x * PPB) {
     const long p = p0 + pl;
-    if (p >= npix || q >= QC) continue;
+    if (p >= npw || q >= QC) continue;
     const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H), kt = (int)((p / ((long)a.W * a.H)) % 2);
-    const int b = (int)(p / ((long)a.W * a.H * 2));
-    const float* wp = a.w + (long)(b % a.wsets) * 18 * Gi * 256;
+    const int b = (int)(p / ((long)a.W * a.H * 2)) * a.wsets + wset;
     const float* dyb = a.dy + (long)b * a.H * a.W;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int oh = 0; oh < 3; ++oh) {
       const int hq = h - (oh - 1);
-      if (hq < 0 || hq >= a.H) continue;
 #pragma unroll
       for (int ow = 0; ow < 3; ++ow) {
         const int wq = w - (ow - 1);
-        if (wq < 0 || wq >= a.W) continue;
-        const float g = dyb[(long)hq * a.W + wq];
-        const int tap = (kt * 3 + oh) * 3 + ow;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = fmaf(g, c1_w_dgrad(wp, Gi, tap, 4 * q + u), acc[u]);
+        const bool ok = hq >= 0 && hq < a.H && wq >= 0 && wq < a.W;
+        const float g = ok ? dyb[(long)hq * a.W + wq] : 0.f;
+        acc += (kt == 0 ? wr[oh * 3 + ow] : wr[9 + oh * 3 + ow]) * g;
       }
     }
     const long off = (long)b * a.x_sB + (long)kt * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + (long)(q / 4) * a.x_sG + 4 * (q % 4);
@@ -754,22 +763,30 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
       for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] += xv * g[t9];
     }
   }
-  // reduce over the pixel lanes of the block, then one atomic per (tap, channel)
+  // reduce over the lanes of a wave that own the same channels, then over the 4 waves, then one atomic per value
   float* dw = a.dwp + (long)wset * 18 * a.C * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* red = &s_red[0][0][0];            // reused as [4 waves][LPP][4]
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) {
-      __syncthreads();
+      f32x4 v = acc[kt][t9];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s_red[pl][q][u] = acc[kt][t9][u];
+      for (int o = LPP; o < 64; o <<= 1) {
+        v[0] += __shfl_xor(v[0], o, 64); v[1] += __shfl_xor(v[1], o, 64);
+        v[2] += __shfl_xor(v[2], o, 64); v[3] += __shfl_xor(v[3], o, 64);
+      }
       __syncthreads();
-      if (pl == 0 && q < QC) {
+      if (lane < LPP)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) red[(wave * LPP + lane) * 4 + u] = v[u];
+      __syncthreads();
+      if (threadIdx.x < LPP && q < QC) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          float s = 0.f;
-          for (int i = 0; i < PPB; ++i) s += s_red[i][q][u];
-          atomicAdd(dw + ((long)(kt * 9 + t9) * a.C + 4 * q + u) * 16, s);
+          const float sum = red[(0 * LPP + q) * 4 + u] + red[(1 * LPP + q) * 4 + u] + red[(2 * LPP + q) * 4 + u] + red[(3 * LPP + q) * 4 + u];
+          atomicAdd(dw + ((long)(kt * 9 + t9) * a.C + 4 * q + u) * 16, sum);
         }
       }
     }
@@ -784,9 +801,11 @@ int launch_c1(int which, C1Args& a, hipStream_t st) {
   const int LPP = QC <= 4 ? 4 : QC <= 8 ? 8 : QC <= 16 ? 16 : QC <= 32 ? 32 : 64;
   if (QC > 64) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): Cin %d > 256 is not built", a.C);
   const int PPB = 256 / LPP;
-  const long npix = which == 1 ? (long)a.B * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * a.W : (long)(a.B / a.wsets) * a.H * a.W);
-  const int gx = imin(cdiv(npix, PPB), kCUs * (which == 2 ? 4 : 8));
-  const dim3 grid(gx, which == 2 ? a.wsets : 1);
+  const long nbw = a.B / a.wsets;
+  const long npix = which == 1 ? nbw * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * a.W : nbw * a.H * a.W);
+  const int per = which == 0 ? 1 : a.wsets;                       // dgrad / wgrad: one weight set per grid column
+  const int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : 8), per));
+  const dim3 grid(gx < 1 ? 1 : gx, per);
 #define C1(K) do { if (LPP == 4) hipLaunchKernelGGL((K<4>), grid, dim3(256), 0, st, a); else if (LPP == 8) hipLaunchKernelGGL((K<8>), grid, dim3(256), 0, st, a); \
   else if (LPP == 16) hipLaunchKernelGGL((K<16>), grid, dim3(256), 0, st, a); else if (LPP == 32) hipLaunchKernelGGL((K<32>), grid, dim3(256), 0, st, a); \
   else hipLaunchKernelGGL((K<64>), grid, dim3(256), 0, st, a); } while (0)

@@ -156,52 +156,59 @@ __device__ __forceinline__ void lfq_probs(const float (&s)[D], float (&p)[1 << D
   for (int k = 0; k < K; ++k) p[k] *= inv;
 }
 
+// sum over the QE = E/4 adjacent lanes that share a token
+template <int QE>
+__device__ __forceinline__ float tok_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < QE; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// E/4 adjacent lanes per token, each owning 4 channels: every access is a 16-byte piece of a contiguous stream
 template <int E, int D>
 __global__ __launch_bounds__(256) void lfq_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w_in,
                                                       const float* __restrict__ b_in, const float* __restrict__ w_out,
                                                       const float* __restrict__ b_out, float* __restrict__ zq,
                                                       long long* __restrict__ indices, float* __restrict__ partials,
                                                       long M, int training) {
-  constexpr int K = 1 << D, R = 2 + K;
+  constexpr int K = 1 << D, R = 2 + K, QE = E / 4;
   __shared__ float smem[R * 4];
   float acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
-    float zi[E];
+  const int q = threadIdx.x % QE;
+  f32x4 wi[D], wo[D], bo;
 #pragma unroll
-    for (int e = 0; e < E; e += 4) { const f32x4 t = ld4(z + tok * E + e); zi[e] = t[0]; zi[e + 1] = t[1]; zi[e + 2] = t[2]; zi[e + 3] = t[3]; }
-    float s[D], q[D];
+  for (int i = 0; i < D; ++i) {
+    wi[i] = ld4(w_in + i * E + 4 * q);
+    wo[i] = f32x4{w_out[(4 * q) * D + i], w_out[(4 * q + 1) * D + i], w_out[(4 * q + 2) * D + i], w_out[(4 * q + 3) * D + i]};
+  }
+  bo = ld4(b_out + 4 * q);
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const f32x4 zi = ld4(z + tok * E + 4 * q);
+    float s[D], qv[D];
     long long idx = 0;
+    f32x4 o = bo;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      float a = b_in[i];
-#pragma unroll
-      for (int e = 0; e < E; ++e) a = fmaf(w_in[i * E + e], zi[e], a);
+      const float a = tok_sum<QE>(zi[0] * wi[i][0] + zi[1] * wi[i][1] + zi[2] * wi[i][2] + zi[3] * wi[i][3]) + b_in[i];
       s[i] = a;
-      q[i] = a > 0.f ? 1.f : -1.f;                 // strict > (LFQ.py:222,234)
+      qv[i] = a > 0.f ? 1.f : -1.f;                // strict > (LFQ.py:222,234)
       idx |= (long long)(a > 0.f) << (D - 1 - i);
+      o += wo[i] * qv[i];
     }
-    indices[tok] = idx;
+    st4(zq + tok * E + 4 * q, o);
+    if (q == 0) {
+      indices[tok] = idx;
+      if (training) {
+        float p[K];
+        lfq_probs<D>(s, p);
 #pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      f32x4 o;
+        for (int k = 0; k < K; ++k) { acc[0] -= p[k] * __logf(fmaxf(p[k], kLogEps)); acc[2 + k] += p[k]; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float a = b_out[e + u];
-#pragma unroll
-        for (int i = 0; i < D; ++i) a = fmaf(w_out[(e + u) * D + i], q[i], a);
-        o[u] = a;
+        for (int i = 0; i < D; ++i) { const float d = s[i] - qv[i]; acc[1] = fmaf(d, d, acc[1]); }
       }
-      st4(zq + tok * E + e, o);
-    }
-    if (training) {
-      float p[K];
-      lfq_probs<D>(s, p);
-#pragma unroll
-      for (int k = 0; k < K; ++k) { acc[0] -= p[k] * __logf(fmaxf(p[k], kLogEps)); acc[2 + k] += p[k]; }
-#pragma unroll
-      for (int i = 0; i < D; ++i) { const float d = s[i] - q[i]; acc[1] = fmaf(d, d, acc[1]); }
     }
   }
   if (training) {
@@ -250,92 +257,81 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ dw_in, float* __restrict__ db_in,
                                                       float* __restrict__ dw_out, float* __restrict__ db_out, long M,
                                                       float w_ent, float gamma, float w_commit) {
-  constexpr int K = 1 << D;
+  constexpr int K = 1 << D, QE = E / 4;
   const float g = gscal[0];
   const float invM = 1.f / (float)M;
   float ub[K];   // d Hbatch / d a_k
 #pragma unroll
   for (int k = 0; k < K; ++k) { const float a = stats[4 + k]; ub[k] = -(logf(fmaxf(a, kLogEps)) + (a >= kLogEps ? 1.f : 0.f)); }
-  float gwi[D][E], gbi[D], gwo[E][D], gbo[E];
+  const int q = threadIdx.x % QE;
+  f32x4 wi[D], wo[D], gwi[D], gwo[D], gbo = {0.f, 0.f, 0.f, 0.f};
+  float gbi[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) { gbi[i] = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) { gwi[i][e] = 0.f; gwo[e][i] = 0.f; } }
-#pragma unroll
-  for (int e = 0; e < E; ++e) gbo[e] = 0.f;
-
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
-    float zi[E], go[E];
-#pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      const f32x4 t = ld4(z + tok * E + e), u = ld4(dzq + tok * E + e);
-      zi[e] = t[0]; zi[e + 1] = t[1]; zi[e + 2] = t[2]; zi[e + 3] = t[3];
-      go[e] = u[0]; go[e + 1] = u[1]; go[e + 2] = u[2]; go[e + 3] = u[3];
-    }
-    float s[D], q[D], ds[D];
+  for (int i = 0; i < D; ++i) {
+    wi[i] = ld4(w_in + i * E + 4 * q);
+    wo[i] = f32x4{w_out[(4 * q) * D + i], w_out[(4 * q + 1) * D + i], w_out[(4 * q + 2) * D + i], w_out[(4 * q + 3) * D + i]};
+    gwi[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gwo[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gbi[i] = 0.f;
+  }
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const f32x4 zi = ld4(z + tok * E + 4 * q), go = ld4(dzq + tok * E + 4 * q);
+    float s[D], qv[D], ds[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      float a = b_in[i];
-#pragma unroll
-      for (int e = 0; e < E; ++e) a = fmaf(w_in[i * E + e], zi[e], a);
-      s[i] = a; q[i] = a > 0.f ? 1.f : -1.f;
-      float d = 0.f;                               // straight-through: d x_ste = W_out^T dz_q
-#pragma unroll
-      for (int e = 0; e < E; ++e) d = fmaf(go[e], w_out[e * D + i], d);
-      ds[i] = d + g * w_commit * 2.f * (s[i] - q[i]) * invM * (1.f / D);
+      const float a = tok_sum<QE>(zi[0] * wi[i][0] + zi[1] * wi[i][1] + zi[2] * wi[i][2] + zi[3] * wi[i][3]) + b_in[i];
+      s[i] = a; qv[i] = a > 0.f ? 1.f : -1.f;
+      // straight-through: d x_ste = W_out^T dz_q
+      const float d = tok_sum<QE>(go[0] * wo[i][0] + go[1] * wo[i][1] + go[2] * wo[i][2] + go[3] * wo[i][3]);
+      ds[i] = d + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
     }
     float p[K];
     lfq_probs<D>(s, p);
-    float us = 0.f, ubs = 0.f, u[K];
+    float us = 0.f, ubs = 0.f, uu[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      u[k] = -(__logf(fmaxf(p[k], kLogEps)) + (p[k] >= kLogEps ? 1.f : 0.f));
-      us = fmaf(u[k], p[k], us);
+      uu[k] = -(__logf(fmaxf(p[k], kLogEps)) + (p[k] >= kLogEps ? 1.f : 0.f));
+      us = fmaf(uu[k], p[k], us);
       ubs = fmaf(ub[k], p[k], ubs);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       // d/dlogit_k of (w_ent * H_i / M - gamma * Hbatch)
-      const float dl = p[k] * (w_ent * (u[k] - us) - gamma * (ub[k] - ubs)) * invM * g * kInvTemp2;
+      const float dl = p[k] * (w_ent * (uu[k] - us) - gamma * (ub[k] - ubs)) * invM * g * kInvTemp2;
 #pragma unroll
       for (int i = 0; i < D; ++i) ds[i] += ((k >> (D - 1 - i)) & 1) ? dl : -dl;
     }
-#pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      f32x4 o;
-#pragma unroll
-      for (int uu = 0; uu < 4; ++uu) {
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < D; ++i) a = fmaf(ds[i], w_in[i * E + e + uu], a);
-        o[uu] = a;
-      }
-      st4(dz + tok * E + e, o);
-    }
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      gbi[i] += ds[i];
-#pragma unroll
-      for (int e = 0; e < E; ++e) { gwi[i][e] = fmaf(ds[i], zi[e], gwi[i][e]); gwo[e][i] = fmaf(go[e], q[i], gwo[e][i]); }
+      o += wi[i] * ds[i];
+      gwi[i] += zi * ds[i];
+      gwo[i] += go * qv[i];
+      if (q == 0) gbi[i] += ds[i];
     }
-#pragma unroll
-    for (int e = 0; e < E; ++e) gbo[e] += go[e];
+    gbo += go;
+    st4(dz + tok * E + 4 * q, o);
   }
+  // lanes with equal q hold partials of the same 4 channels: reduce over them, lanes 0..QE-1 publish
+  auto same_q_sum = [](float v) {
+#pragma unroll
+    for (int o = QE; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    const float a = wave_sum(gbi[i]);
-    if (lane == 0) atomicAdd(db_in + i, a);
+    const float bi = same_q_sum(gbi[i]);
+    if (lane == 0) atomicAdd(db_in + i, bi);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const float b = wave_sum(gwi[i][e]), c = wave_sum(gwo[e][i]);
-      if (lane == 0) { atomicAdd(dw_in + i * E + e, b); atomicAdd(dw_out + e * D + i, c); }
+    for (int c = 0; c < 4; ++c) {
+      const float a = same_q_sum(gwi[i][c]), b2 = same_q_sum(gwo[i][c]);
+      if (lane < QE) { atomicAdd(dw_in + i * E + 4 * q + c, a); atomicAdd(dw_out + (4 * q + c) * D + i, b2); }
     }
   }
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const float a = wave_sum(gbo[e]);
-    if (lane == 0) atomicAdd(db_out + e, a);
+  for (int c = 0; c < 4; ++c) {
+    const float a = same_q_sum(gbo[c]);
+    if (lane < QE) atomicAdd(db_out + 4 * q + c, a);
   }
 }
 
@@ -404,17 +400,24 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) partials[(long)blockIdx.x * (P + 1) + p] = acc[0];
   }
 }
-// out[p] = sum_blocks partial[p] / sum_blocks partial[P]   (P+1 columns, fixed order)
+// out[p] = sum_blocks partial[p] / sum_blocks partial[P]   (P+1 columns; 64 threads, fixed summation order)
 __global__ void ratio_finalize_kernel(const float* __restrict__ partials, int nblocks, int P, float* __restrict__ out) {
-  if (threadIdx.x != 0) return;
-  double den = 0.0;
-  for (int b = 0; b < nblocks; ++b) den += (double)partials[(long)b * (P + 1) + P];
-  for (int p = 0; p < P; ++p) {
+  __shared__ double sm[64];
+  __shared__ double den_s;
+  const int t = threadIdx.x;
+  for (int p = P; p >= 0; --p) {
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partials[(long)b * (P + 1) + p];
-    out[p] = (float)(s / den);
+    for (int b = t; b < nblocks; b += 64) s += (double)partials[(long)b * (P + 1) + p];
+    sm[t] = s;
+    __syncthreads();
+    if (t == 0) {
+      double tot = 0.0;
+      for (int i = 0; i < 64; ++i) tot += sm[i];
+      if (p == P) { den_s = tot; out[P] = (float)tot; }
+      else out[p] = (float)(tot / den_s);
+    }
+    __syncthreads();
   }
-  out[P] = (float)den;
 }
 // dpred[p,i] = gout[p] * w[t_i] * valid_i * (sigmoid(x) - t) / denom
 __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
@@ -443,28 +446,24 @@ template <int E>
 __global__ __launch_bounds__(256) void anomaly_fwd_kernel(const float* __restrict__ zq, const float* __restrict__ mask,
                                                           const float* __restrict__ mvalid, const float* __restrict__ vq0,
                                                           float* __restrict__ partials, int N, int V, int T, long HW) {
+  constexpr int QE = E / 4;
   __shared__ float smem[8];
-  float c[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) c[e] = vq0[e];
+  const int q = threadIdx.x % QE;
+  const f32x4 c = ld4(vq0 + 4 * q);
   float acc[2] = {0.f, 0.f};
   const long M = (long)N * V * T * HW;
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
     const long hw = tok % HW; long r = tok / HW;
     const int t = (int)(r % T); r /= T;
     const int n = (int)(r / V);
     float m = mask[(long)n * HW + hw];
     if (mvalid) m = fminf(m + mvalid[((long)n * T + t) * HW + hw], 1.f);
     const float wgt = 1.f - m;
-    acc[1] += wgt * E;
+    acc[1] += wgt * 4.f;
     if (m == 1.f) continue;   // target := prediction there (losses.py:162): exactly zero contribution
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      const f32x4 v = ld4(zq + tok * E + e);
-      s += fabsf(v[0] - c[e]) + fabsf(v[1] - c[e + 1]) + fabsf(v[2] - c[e + 2]) + fabsf(v[3] - c[e + 3]);
-    }
-    acc[0] = fmaf(s, wgt, acc[0]);
+    const f32x4 v = ld4(zq + tok * E + 4 * q);
+    acc[0] = fmaf(fabsf(v[0] - c[0]) + fabsf(v[1] - c[1]) + fabsf(v[2] - c[2]) + fabsf(v[3] - c[3]), wgt, acc[0]);
   }
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) { partials[(long)blockIdx.x * 2] = acc[0]; partials[(long)blockIdx.x * 2 + 1] = acc[1]; }
@@ -474,28 +473,26 @@ __global__ __launch_bounds__(256) void anomaly_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mvalid, const float* __restrict__ vq0,
                                                           const float* __restrict__ gout, const float* __restrict__ denom,
                                                           float* __restrict__ dzq, int N, int V, int T, long HW) {
-  float c[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) c[e] = vq0[e];
+  constexpr int QE = E / 4;
+  const int q = threadIdx.x % QE;
+  const f32x4 c = ld4(vq0 + 4 * q);
   const float sc = gout[0] / denom[0];
   const long M = (long)N * V * T * HW;
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
     const long hw = tok % HW; long r = tok / HW;
     const int t = (int)(r % T); r /= T;
     const int n = (int)(r / V);
     float m = mask[(long)n * HW + hw];
     if (mvalid) m = fminf(m + mvalid[((long)n * T + t) * HW + hw], 1.f);
     const float k = sc * (1.f - m);
+    f32x4 v = ld4(zq + tok * E + 4 * q);
 #pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      f32x4 v = ld4(zq + tok * E + e);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float d = v[u] - c[e + u];
-        v[u] = (m == 1.f) ? 0.f : (d > 0.f ? k : (d < 0.f ? -k : 0.f));
-      }
-      st4(dzq + tok * E + e, v);
+    for (int uu = 0; uu < 4; ++uu) {
+      const float d = v[uu] - c[uu];
+      v[uu] = (m == 1.f) ? 0.f : (d > 0.f ? k : (d < 0.f ? -k : 0.f));
     }
+    st4(dzq + tok * E + 4 * q, v);
   }
 }
 
@@ -633,7 +630,7 @@ extern "C" int idee_patch_embed_ln_bwd(const float* x, const float* w, const flo
 }
 
 extern "C" long idee_lfq_workspace_floats(long M, int codebook_size) {
-  return (long)stream_grid(M) * (2 + codebook_size);
+  return (long)stream_grid(M * 4) * (2 + codebook_size);
 }
 
 #define LFQ_DISPATCH(CALL)                                                                             \
@@ -651,7 +648,7 @@ extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in
   IDEE_CHECK_ARG(!training || (stats && workspace), "lfq_fwd: training needs stats and workspace");
   const int D = log2i(codebook_size);
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
-  const int nb = stream_grid(M);
+  const int nb = stream_grid(M * 4);
   hipStream_t st = (hipStream_t)stream;
 #define CALL(E_, D_)                                                                                           \
   hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, st, z, w_in, b_in, w_out, b_out, zq,     \
@@ -672,7 +669,7 @@ extern "C" int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in,
                  "lfq_bwd: bad argument");
   const int D = log2i(codebook_size);
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
-  const int nb = imin(cdiv(M, 256), kCUs * 4);
+  const int nb = imin(cdiv(M * 4, 256), kCUs * 8);
 #define CALL(E_, D_)                                                                                               \
   hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in, w_out, \
                      stats, gloss, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
@@ -710,14 +707,14 @@ extern "C" int idee_bce_weighted_bwd(const float* pred, const float* target, con
   return IDEE_OK;
 }
 
-extern "C" long idee_anomaly_workspace_floats(long tokens) { return (long)stream_grid(tokens) * 2; }
+extern "C" long idee_anomaly_workspace_floats(long tokens) { return (long)stream_grid(tokens * 4) * 2; }
 
 extern "C" int idee_anomaly_l1_fwd(const float* zq, const float* mask_extreme, const float* mask_valid, const float* vq0,
                                    float* out /* [loss, denom] */, float* workspace, int N, int V, int T, long HW, int E,
                                    idee_stream_t stream) {
   IDEE_CHECK_ARG(zq && mask_extreme && vq0 && out && workspace && N > 0 && V > 0 && T > 0 && HW > 0, "anomaly_l1_fwd: bad argument");
   const long M = (long)N * V * T * HW;
-  const int nb = stream_grid(M);
+  const int nb = stream_grid(M * 4);
   hipStream_t st = (hipStream_t)stream;
   if (E == 16) hipLaunchKernelGGL((anomaly_fwd_kernel<16>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, workspace, N, V, T, HW);
   else if (E == 32) hipLaunchKernelGGL((anomaly_fwd_kernel<32>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, workspace, N, V, T, HW);
@@ -732,7 +729,7 @@ extern "C" int idee_anomaly_l1_bwd(const float* zq, const float* mask_extreme, c
                                    idee_stream_t stream) {
   IDEE_CHECK_ARG(zq && mask_extreme && vq0 && gout && denom && dzq && N > 0 && V > 0 && T > 0 && HW > 0, "anomaly_l1_bwd: bad argument");
   const long M = (long)N * V * T * HW;
-  const int nb = stream_grid(M);
+  const int nb = stream_grid(M * 4);
   hipStream_t st = (hipStream_t)stream;
   if (E == 16) hipLaunchKernelGGL((anomaly_bwd_kernel<16>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, gout, denom, dzq, N, V, T, HW);
   else if (E == 32) hipLaunchKernelGGL((anomaly_bwd_kernel<32>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, gout, denom, dzq, N, V, T, HW);
