@@ -61,6 +61,9 @@ _SIGS = {
     "idee_lfq_workspace_floats": (_L, [_L, _I]),
     "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P]),
     "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _P]),
+    "idee_vq_workspace_floats": (_L, [_L]),
+    "idee_vq_nn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
+    "idee_vq_nn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "idee_bce_class_counts": (_I, [_P, _P, _L, _P, _P]),
     "idee_bce_workspace_floats": (_L, [_I, _L]),
     "idee_bce_weighted_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P]),

@@ -598,6 +598,82 @@ __global__ __launch_bounds__(256) void ln_relu_res_bwd_kernel(const float* __res
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// Euclidean nearest-neighbour vector quantisation (models/codebook/VQ.py: cdist :44-48, argmax of -dist
+// in EuclideanCodebook.forward :477-555, straight-through :986, commitment mse :1056), reference defaults:
+// learnable codebook, no EMA, no projections, one head.   x (M, E) tokens, embed (K, E).
+// -------------------------------------------------------------------------------------------
+constexpr int kVqMaxFloats = 8192;   // codebook floats kept in LDS
+
+template <int E>
+__global__ __launch_bounds__(256) void vq_nn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ embed,
+                                                        float* __restrict__ q, long long* __restrict__ indices,
+                                                        float* __restrict__ partials, long M, int K, int training) {
+  constexpr int QE = E / 4;
+  __shared__ __attribute__((aligned(16))) float s_e[kVqMaxFloats];
+  __shared__ float s_e2[kVqMaxFloats / E];
+  __shared__ float smem[4];
+  for (int i = threadIdx.x; i < K * E; i += 256) s_e[i] = embed[i];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float a = 0.f;
+    for (int e = 0; e < E; ++e) a = fmaf(s_e[k * E + e], s_e[k * E + e], a);
+    s_e2[k] = a;
+  }
+  __syncthreads();
+  const int qq = threadIdx.x % QE;
+  float acc[1] = {0.f};
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const f32x4 xv = ld4(x + tok * E + 4 * qq);
+    const float x2 = tok_sum<QE>(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3]);
+    float best = -3.4e38f;
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+      const f32x4 ev = ld4(s_e + k * E + 4 * qq);
+      const float xe = tok_sum<QE>(xv[0] * ev[0] + xv[1] * ev[1] + xv[2] * ev[2] + xv[3] * ev[3]);
+      const float d = -sqrtf(fmaxf(x2 + s_e2[k] - 2.f * xe, 0.f));   // -cdist
+      if (d > best) { best = d; bi = k; }                               // first maximum wins (argmax)
+    }
+    const f32x4 ev = ld4(s_e + bi * E + 4 * qq);
+    st4(q + tok * E + 4 * qq, ev);      // value of x + (q - x).detach() is q
+    if (qq == 0) indices[tok] = bi;
+    if (training) {
+      const f32x4 d4 = ev - xv;
+      acc[0] += d4[0] * d4[0] + d4[1] * d4[1] + d4[2] * d4[2] + d4[3] * d4[3];
+    }
+  }
+  if (training) {
+    block_sum<1>(acc, smem);
+    if (threadIdx.x == 0) { partials[(long)blockIdx.x * 2] = acc[0]; partials[(long)blockIdx.x * 2 + 1] = 1.f; }
+  }
+}
+
+// dx = dq (straight-through) + g * 2 (x - q) / (M E) ; dembed[k] += g * sum_{idx = k} 2 (q - x) / (M E)
+template <int E>
+__global__ __launch_bounds__(256) void vq_nn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ embed,
+                                                        const long long* __restrict__ indices, const float* __restrict__ dq,
+                                                        const float* __restrict__ gloss, float* __restrict__ dx,
+                                                        float* __restrict__ dembed, long M, int K, float w_commit) {
+  constexpr int QE = E / 4;
+  __shared__ float s_g[kVqMaxFloats];
+  for (int i = threadIdx.x; i < K * E; i += 256) s_g[i] = 0.f;
+  __syncthreads();
+  const int qq = threadIdx.x % QE;
+  const float c = gloss[0] * w_commit * 2.f / ((float)M * E);
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const int k = (int)indices[tok];
+    const f32x4 xv = ld4(x + tok * E + 4 * qq), ev = ld4(embed + (long)k * E + 4 * qq), gq = ld4(dq + tok * E + 4 * qq);
+    const f32x4 d = (xv - ev) * c;
+    st4(dx + tok * E + 4 * qq, gq + d);
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) atomicAdd(&s_g[k * E + 4 * qq + uu], -d[uu]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * E; i += 256) atomicAdd(dembed + i, s_g[i]);
+}
+
 int stream_grid(long items) { return imin(cdiv(items, 256), kCUs * 8); }
 
 }  // namespace
@@ -768,5 +844,38 @@ extern "C" int idee_ln_relu_res_bwd(const float* c, const float* gamma, const fl
   else if (E == 32) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "ln_relu_res: E=%d not built", E);
   IDEE_LAUNCH_CHECK("ln_relu_res_bwd");
+  return IDEE_OK;
+}
+
+extern "C" long idee_vq_workspace_floats(long M) { return (long)stream_grid(M * 4) * 2; }
+
+extern "C" int idee_vq_nn_fwd(const float* x, const float* embed, float* q, int64_t* indices, float* loss, float* workspace,
+                              long M, int E, int K, int training, float w_commit, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && embed && q && indices && M > 0 && K > 0, "vq_nn_fwd: bad argument");
+  IDEE_CHECK_ARG(!training || (loss && workspace), "vq_nn_fwd: training needs loss and workspace");
+  if ((long)K * E > kVqMaxFloats) return idee::fail(IDEE_ERR_UNSUPPORTED, "vq_nn: codebook %d x %d exceeds %d floats", K, E, kVqMaxFloats);
+  const int nb = stream_grid(M * 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 16) hipLaunchKernelGGL((vq_nn_fwd_kernel<16>), dim3(nb), dim3(256), 0, st, x, embed, q, (long long*)indices, workspace, M, K, training);
+  else if (E == 32) hipLaunchKernelGGL((vq_nn_fwd_kernel<32>), dim3(nb), dim3(256), 0, st, x, embed, q, (long long*)indices, workspace, M, K, training);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "vq_nn: dim %d not built", E);
+  if (training) {
+    // loss[0] = w_commit * sum / (M * E): reuse the ratio finaliser with denominator column = 1 per block, then scale
+    hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, nb, 1, loss);
+  }
+  IDEE_LAUNCH_CHECK("vq_nn_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_vq_nn_bwd(const float* x, const float* embed, const int64_t* indices, const float* dq, const float* gloss,
+                              float* dx, float* dembed, long M, int E, int K, float w_commit, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && embed && indices && dq && gloss && dx && dembed && M > 0 && K > 0, "vq_nn_bwd: bad argument");
+  if ((long)K * E > kVqMaxFloats) return idee::fail(IDEE_ERR_UNSUPPORTED, "vq_nn: codebook %d x %d exceeds %d floats", K, E, kVqMaxFloats);
+  const int nb = imin(cdiv(M * 4, 256), kCUs * 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 16) hipLaunchKernelGGL((vq_nn_bwd_kernel<16>), dim3(nb), dim3(256), 0, st, x, embed, (const long long*)indices, dq, gloss, dx, dembed, M, K, w_commit);
+  else if (E == 32) hipLaunchKernelGGL((vq_nn_bwd_kernel<32>), dim3(nb), dim3(256), 0, st, x, embed, (const long long*)indices, dq, gloss, dx, dembed, M, K, w_commit);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "vq_nn: dim %d not built", E);
+  IDEE_LAUNCH_CHECK("vq_nn_bwd");
   return IDEE_OK;
 }

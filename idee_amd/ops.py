@@ -429,3 +429,41 @@ class ConvLNUnit(torch.autograd.Function):
             dx = dy.clone()                      # the shortcut's gradient; the conv's data gradient is added to it
             conv.dgrad(dc, pd, None, dx, accumulate=True)
         return dx, dw, dgamma, dbeta
+
+
+class VQNearest(torch.autograd.Function):
+    """Euclidean nearest-neighbour quantiser with straight-through gradient and commitment loss.
+    x (..., E), embed (K, E) -> (quantised (..., E), indices int64 (...), loss (1,)).
+    Reference: models/codebook/VQ.py:44-48, :477-555, :986, :1056 (defaults: learnable codebook, no EMA)."""
+
+    @staticmethod
+    def forward(ctx, x, embed, training, w_commit):
+        x, embed = _f32c(x), _f32c(embed)
+        E = x.shape[-1]
+        M = x.numel() // E
+        K = embed.shape[0]
+        dev = x.device
+        q = torch.empty_like(x)
+        idx = torch.empty(x.shape[:-1], device=dev, dtype=torch.int64)
+        out = torch.zeros(2, device=dev, dtype=torch.float32)
+        ws = torch.empty(max(L.load().idee_vq_workspace_floats(M), 2), device=dev, dtype=torch.float32)
+        L.call("idee_vq_nn_fwd", ptr(x), ptr(embed), ptr(q), ptr(idx), ptr(out), ptr(ws), M, E, K, int(training), w_commit,
+               L.stream())
+        # out[0] = sum / (number of blocks) after the ratio finaliser; undo the block count, apply the mean and the weight
+        loss = (out[0] * out[1] * (w_commit / (M * E))).reshape(1) if training else torch.zeros(1, device=dev)
+        ctx.save_for_backward(x, embed, idx)
+        ctx.cfg = (M, E, K, w_commit)
+        ctx.mark_non_differentiable(idx)
+        return q, idx, loss
+
+    @staticmethod
+    def backward(ctx, dq, _didx, dloss):
+        x, embed, idx = ctx.saved_tensors
+        M, E, K, w_commit = ctx.cfg
+        dq = _f32c(dq) if dq is not None else torch.zeros_like(x)
+        gl = _f32c(dloss).reshape(1) if dloss is not None else torch.zeros(1, device=x.device)
+        dx = torch.empty_like(x)
+        dembed = torch.zeros_like(embed)
+        L.call("idee_vq_nn_bwd", ptr(x), ptr(embed), ptr(idx), ptr(dq), ptr(gl), ptr(dx), ptr(dembed), M, E, K, w_commit,
+               L.stream())
+        return dx, dembed, None, None

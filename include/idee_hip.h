@@ -172,6 +172,20 @@ int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const floa
                  idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Euclidean nearest-neighbour vector quantisation with straight-through gradient and commitment loss — the
+ * reference VQ's default path: cdist + argmax (models/codebook/VQ.py:44-48, :477-555), STE (:986), commit mse
+ * (:1056).  (EMA / k-means / code expiry / gumbel / multi-head are outside the path: build.py:87 wires LFQ.)
+ *   x, q, dq, dx: (M, E); embed, dembed: (K, E) with K*E <= 8192; indices int64 (M)
+ *   loss (2): [sum (q-x)^2 over all elements (the caller scales by w_commit / (M*E)), block count];
+ *   workspace idee_vq_workspace_floats(M).   bwd: dx overwritten; dembed accumulates; gloss: d/d(loss value).
+ * ---------------------------------------------------------------------------------------- */
+long idee_vq_workspace_floats(long M);
+int idee_vq_nn_fwd(const float* x, const float* embed, float* q, int64_t* indices, float* loss, float* workspace, long M,
+                   int E, int K, int training, float w_commit, idee_stream_t stream);
+int idee_vq_nn_bwd(const float* x, const float* embed, const int64_t* indices, const float* dq, const float* gloss, float* dx,
+                   float* dembed, long M, int E, int K, float w_commit, idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Losses (models/losses.py).
  * BCE with logits weighted by log(1.1 + class_freq^-0.5), class counts from torch.histc(bins=2)
  * semantics: BCE_loss_synthetic :98-124 (valid == NULL) and BCE_loss :64-95 (valid mask).

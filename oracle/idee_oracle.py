@@ -396,16 +396,18 @@ def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
 
 
 def vq_nearest(x, embed, training, commitment_weight=1.0):
-    """Euclidean nearest-neighbour quantise + straight-through + commitment loss.
-    VQ.py:44-48 (cdist), :477-555 (EuclideanCodebook.forward, argmax of -dist), :986 (STE),
-    :1056 (commit mse).  x (b,n,d); embed (K,d).  Returns quantised (b,n,d), idx (b,n), loss."""
+    """Euclidean nearest-neighbour quantise + straight-through + commitment loss, at the reference VQ's defaults
+    (learnable codebook, no EMA, no projections, one head).  VQ.py:44-48 (cdist), :477-555
+    (EuclideanCodebook.forward: argmax of -dist, one-hot x embed), :986 (straight-through),
+    :1056 (commit = mse(quantize, x), quantize NOT detached because the codebook is learnable), :1083 (loss (1,)).
+    x (b,n,d); embed (K,d).  Returns quantised (b,n,d), idx (b,n), loss (1,)."""
     x2 = (x * x).sum(-1, keepdim=True)
     e2 = (embed * embed).sum(-1)
-    d2 = (x2 + e2[None, None] - 2 * x @ embed.t()).clamp(min=0)
-    idx = (-d2.sqrt()).argmax(-1)
+    dist = -(x2 + e2[None, None] - 2 * x @ embed.t()).clamp(min=0).sqrt()
+    idx = dist.argmax(-1)
     q = embed[idx]
-    loss = torch.zeros(())
+    loss = torch.zeros(1)
     if training:
-        loss = F.mse_loss(q.detach(), x) * commitment_weight
+        loss = loss + F.mse_loss(q, x) * commitment_weight
         q = x + (q - x).detach()
     return q, idx, loss

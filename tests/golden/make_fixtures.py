@@ -319,10 +319,6 @@ def main():
     fx_config_defaults()
 
 
-if __name__ == "__main__" and "--config-only" not in sys.argv:
-    main()
-
-
 def fx_config_defaults():
     """Names and defaults of the reference's flag surface (config.py:18-189) as data."""
     import json
@@ -334,3 +330,39 @@ def fx_config_defaults():
 
 if __name__ == "__main__" and "--config-only" in sys.argv:
     fx_config_defaults()
+
+
+def fx_vq(tag, K, training, seed):
+    """Nearest-neighbour VQ at the reference's defaults (Euclidean codebook, learnable, no EMA, STE, commitment mse):
+    models/codebook/VQ.py, class VQ called directly (build.py does not wire it)."""
+    from models.codebook.VQ import VQ as RefVQ
+    torch.manual_seed(seed)
+    q = RefVQ(dim=16, codebook_size=K, codebook_dim=16)
+    with torch.no_grad():
+        q._codebook.embed.copy_(torch.randn(q._codebook.embed.shape, generator=torch.Generator().manual_seed(seed)) * 0.7)
+    q.train(training)
+    x = rand((2, 300, 16), seed + 1).requires_grad_()
+    zq, idx, loss = q(x)
+    r = rand(zq.shape, seed + 2)
+    out = dict(x=x.detach(), z_q=zq.detach(), indices=idx, loss=loss.detach(), r=r, K=np.array(K), training=np.array(int(training)))
+    if training:
+        ((zq * r).sum() + 1.7 * loss.sum()).backward()
+        out["dx"] = x.grad
+        out.update({"grad/" + k: p.grad for k, p in q.named_parameters()})
+    out.update(sd_arrays(q))
+    save("vq_" + tag, **out)
+
+
+if __name__ == "__main__" and "--vq-only" in sys.argv:
+    fx_vq("k2_train", 2, True, 800)
+    fx_vq("k2_eval", 2, False, 810)
+    fx_vq("k8_train", 8, True, 820)
+
+
+if __name__ == "__main__" and "--config-only" not in sys.argv and "--vq-only" not in sys.argv:
+    main()
+    fx_vq("k2_train", 2, True, 800)
+    fx_vq("k2_eval", 2, False, 810)
+    fx_vq("k8_train", 8, True, 820)
+
+

@@ -450,3 +450,23 @@ def test_drop_in_modules_match_fused_step():
         * cfg.lambda_anomaly + sum(crit(p, tgt) for p in pred_y) + loss_z_q
     close("total", loss.reshape(()), total.reshape(()), atol=1e-5, rtol=1e-5)
     close("ref total", loss.reshape(()), a["train/loss"].reshape(()), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["k2_train", "k2_eval", "k8_train"])
+def test_vq_nearest_golden(tag):
+    from idee_amd.models.codebook.VQ import VQ
+    a, sd, grads = load_golden("vq_" + tag)
+    K, training = int(a["K"]), bool(int(a["training"]))
+    q = VQ(dim=16, codebook_size=K, codebook_dim=16)
+    q.load_state_dict(sd, strict=True)
+    q = q.to(DEV)
+    q.train(training)
+    x = dev(a["x"]).requires_grad_()
+    zq, idx, loss = q(x)
+    assert torch.equal(idx.cpu(), a["indices"].long())
+    close("z_q", zq, a["z_q"])
+    close("loss", loss, a["loss"], atol=1e-6, rtol=1e-4)
+    if training:
+        ((zq * dev(a["r"])).sum() + 1.7 * loss.sum()).backward()
+        gclose("dx", x.grad, a["dx"])
+        gclose("dembed", q._codebook.embed.grad, grads["_codebook.embed"])

@@ -189,3 +189,19 @@ def test_e2e_train_steps(tag):
                                rtol=1e-3, atol=1e-4)
     for k in names:
         close(sd[k].detach(), a["sd_after3/" + k], atol=5e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["k2_train", "k2_eval", "k8_train"])
+def test_vq_nearest(tag):
+    a, sd, grads = load_golden("vq_" + tag)
+    training = bool(int(a["training"]))
+    emb = sd["_codebook.embed"][0].clone().requires_grad_()
+    x = a["x"].clone().requires_grad_()
+    zq, idx, loss = O.vq_nearest(x, emb, training)
+    close(zq, a["z_q"])
+    assert torch.equal(idx, a["indices"].long())
+    close(loss, a["loss"])
+    if training:
+        ((zq * a["r"]).sum() + 1.7 * loss.sum()).backward()
+        close(x.grad, a["dx"], 1e-6, 1e-3)
+        close(emb.grad, grads["_codebook.embed"][0], 1e-6, 1e-3)
