@@ -94,10 +94,25 @@ def pmc_traffic(key):
     return None
 
 
+def host_cores():
+    """CPU cores this process may actually use: min(affinity, cgroup cpu.max quota) — the GPU box exposes 256 logical
+    CPUs but grants a 16-CPU quota, and 128 torch threads on 16 CPUs run ~5x slower than 16 threads."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
 def cpu_baseline(cfg, model, T, H, W):
     """The oracle (CPU restatement, pinned to the reference by tests/golden) on ONE clip of the
     same workload: forward + losses + backward + Adam, 1 warm-up + 2 timed steps."""
     from oracle import idee_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
     ocfg = O.default_cfg(encoder=cfg.encoder, in_channels_dynamic=cfg.in_channels_dynamic, in_channels=cfg.in_channels)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     names = [k for k, v in sd.items() if v.is_floating_point()]
@@ -119,7 +134,7 @@ def cpu_baseline(cfg, model, T, H, W):
                 sd[k] = p
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / len(times[1:])
-    return dict(value=round(1.0 / t, 4), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=round(1.0 / t, 4), unit="samples/s", cores=cores, kind="port",
                 sample=f"1 clip V={cfg.in_channels_dynamic} T={T} {H}x{W}: oracle fwd+losses+bwd+Adam, 1 warm-up + 2 timed steps")
 
 

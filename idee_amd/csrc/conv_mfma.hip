@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // row stages only the one new h-row per t-slot.  The taps are dealt round-robin to the waves; a
 // k-step (4 pixels) costs each wave one conflict-free 4-byte LDS read per operand fragment.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSegMax = 200;   // widest row segment held in LDS (129 KB for the 3x3x3 mode)
+constexpr int kSegMax = 100;   // widest row segment held in LDS (65 KB for the 3x3x3 mode: two workgroups per CU,
+                               // so one stages rows while the other computes)
 
 template <int MODE /*FWD_REP or FWD_S2*/, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, int seg, int nseg, int hrun, int nhrun) {
@@ -411,13 +412,41 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, in
         base[k] = ((ot * 3 + slot_of[oh % 3]) * rowlen + ow + kq) * 16 + r16;
       }
       const int steps = segp >> 2;
-      for (int s = 0; s < steps; ++s) {
-        const float bf = s_dy[(4 * s + kq) * 16 + r16];
-        bsum += bf;
+      // branch-free inner loops when this wave's taps are all live (always in the replicate mode, interior rows otherwise)
+      int nlive = 0;
+      bool prefix = true;
 #pragma unroll
-        for (int k = 0; k < TPWV; ++k) {
-          if (!okt[k]) continue;
-          acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_x[base[k] + s * 64], bf, acc[k], 0, 0, 0);
+      for (int k = 0; k < TPWV; ++k) {
+        const bool in_range = wave + k * WAVES < NTAPS;
+        if (in_range && !okt[k]) prefix = false;
+        if (in_range) nlive = k + 1;
+      }
+      const float* dyp = s_dy + kq * 16 + r16;
+      if (prefix && nlive == TPWV) {
+#pragma unroll 2
+        for (int s = 0; s < steps; ++s) {
+          const float bf = dyp[s * 64];
+          bsum += bf;
+#pragma unroll
+          for (int k = 0; k < TPWV; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_x[base[k] + s * 64], bf, acc[k], 0, 0, 0);
+        }
+      } else if (prefix && nlive == TPWV - 1) {
+#pragma unroll 2
+        for (int s = 0; s < steps; ++s) {
+          const float bf = dyp[s * 64];
+          bsum += bf;
+#pragma unroll
+          for (int k = 0; k < TPWV - 1; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_x[base[k] + s * 64], bf, acc[k], 0, 0, 0);
+        }
+      } else {
+        for (int s = 0; s < steps; ++s) {
+          const float bf = dyp[s * 64];
+          bsum += bf;
+#pragma unroll
+          for (int k = 0; k < TPWV; ++k) {
+            if (!okt[k]) continue;
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_x[base[k] + s * 64], bf, acc[k], 0, 0, 0);
+          }
         }
       }
     }
@@ -532,6 +561,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
         base[f] = (slot_of[oh] * rowlen + ow + kq) * PSX + 16 * ga + r16;
       }
       const int steps = segp >> 2;
+#pragma unroll 2
       for (int s = 0; s < steps; ++s) {
         float bf[GB];
 #pragma unroll
@@ -1010,12 +1040,16 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const int seg = ((cdiv(d->W, nseg) + 3) / 4) * 4 > kSegMax ? kSegMax : ((cdiv(d->W, nseg) + 3) / 4) * 4;
     const long bt = (long)(d->B / d->wsets) * a.To;
     int hrun = d->H;                       // shrink the run until the chip is covered ~3 times
-    while (hrun > 8 && bt * cdiv(d->H, hrun) * nseg * d->wsets < 4L * kCUs) hrun = (hrun + 1) / 2;
+    while (hrun > 8 && bt * cdiv(d->H, hrun) * nseg * d->wsets < 6L * kCUs) hrun = (hrun + 1) / 2;
     const int nhrun = cdiv(d->H, hrun);
     const long nchunks = bt * nhrun * nseg;
-    const dim3 grid(one_round(nchunks, d->wsets, 1), d->wsets);   // 129 KB of LDS: one workgroup per CU
-    if (rep) hipLaunchKernelGGL((wgrad16_lds_kernel<FWD_REP, 8>), grid, dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
-    else hipLaunchKernelGGL((wgrad16_lds_kernel<FWD_S2, 8>), grid, dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
+    if (rep) {
+      auto kern = wgrad16_lds_kernel<FWD_REP, 8>;
+      hipLaunchKernelGGL(kern, dim3(one_round(nchunks, d->wsets, wg_per_cu(kern, 512)), d->wsets), dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
+    } else {
+      auto kern = wgrad16_lds_kernel<FWD_S2, 8>;
+      hipLaunchKernelGGL(kern, dim3(one_round(nchunks, d->wsets, wg_per_cu(kern, 512)), d->wsets), dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
+    }
   }
   else if (!rep && Ga == Gb && (Ga == 6 || Ga == 3 || Ga == 2)) {
     // wide LDS-staged kernel: segment width from the LDS budget (ring of 3 x rows + dy row, padded pixel strides)
