@@ -318,6 +318,131 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wide (2,3,3)-stride-2 convolutions (joint classifier head, all NT = Cout/16 output blocks per wave), forward
+// and data gradient, with the weights of ONE tap at a time staged through LDS and shared by the 8 waves of the
+// workgroup (8 rows x 64 pixels).  The 36.9 KB tap slab (6x6 blocks) is double-buffered: while a tap is
+// multiplied, the next slab travels global -> registers -> LDS.  Weight traffic from L2 drops 8x against the
+// per-wave fragment loads of conv_kernel; activations still come straight from L1/L2.
+// ---------------------------------------------------------------------------------------------
+template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT>
+__global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
+  constexpr int MT = 4, WAVES = 8;
+  extern __shared__ __attribute__((aligned(16))) float s_wd[];   // [2][Gk * NT * 256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  const int wset = b % a.wsets;
+  const int slab = a.Gk * NT * 256;                       // floats per tap
+  const float* wp = a.wp + (long)wset * a.ntaps * slab;
+  const int slab4 = slab / 4;
+  const int NOT = (MODE == FWD_S2) ? 2 : 1;               // T-slots
+
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    const int wt = tile % a.wtiles, r = tile / a.wtiles;
+    const int hg = r % a.hgroups, t = r / a.hgroups;
+    const int h = hg * WAVES + wave;
+    const bool row_ok = h < a.Ho;
+    const int my_mt = a.sub_base + (wt < a.sub_rem ? 1 : 0);
+    const int w0 = 16 * (wt * a.sub_base + min(wt, a.sub_rem));
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* in_b = a.in + (long)b * a.i_sB;
+
+    // first slab
+    const int ntap_it = NOT * 9;
+    auto tap_of = [&](int it) {                            // iteration -> weight tap index
+      const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
+      const int tt = (MODE == FWD_S2) ? ot : (t & 1);
+      return (tt * 3 + oh) * 3 + ow;
+    };
+    __syncthreads();                                       // previous tile's readers done
+    for (int u = tid; u < slab4; u += 512) st4(s_wd + 4 * u, ld4(wp + (long)tap_of(0) * slab + 4 * u));
+    __syncthreads();
+
+    for (int it = 0; it < ntap_it; ++it) {
+      const float* wcur = s_wd + (it & 1) * slab;
+      float* wnext = s_wd + ((it + 1) & 1) * slab;
+      // prefetch the next slab into registers (up to 5 x 16 bytes per thread for a 6x6 slab)
+      f32x4 pre[5];
+      const bool more = it + 1 < ntap_it;
+      if (more) {
+        const float* src = wp + (long)tap_of(it + 1) * slab;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) pre[q] = ld4(src + 4 * u); }
+      }
+      const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
+      const Slot st = slot_t<MODE>(ot, t, a.Ti);
+      const Slot sh = slot_h<MODE>(oh, h, a.Hi);
+      if (row_ok && st.ok && sh.ok) {
+        const float* rowp = in_b + (long)st.src * a.i_sT + (long)sh.src * a.i_sH + 4 * kq;
+        long off[MT];
+        bool okm[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int p = w0 + m * 16 + j;
+          bool ok;
+          const int q = src_w<MODE>(ow, p, a.Wi, ok);
+          okm[m] = ok && (p < a.Wo) && (m < my_mt);
+          off[m] = (long)q * a.i_sW;
+        }
+        f32x4 xc[MT], xn[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xc[m] = okm[m] ? ld4(rowp + off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < a.Gk; ++g) {
+          if (g + 1 < a.Gk) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xn[m] = okm[m] ? ld4(rowp + off[m] + (long)(g + 1) * a.i_sG) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const f32x4 wf = ld4(wcur + (g * NT + n) * 256 + lane * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
+          }
+#pragma unroll
+          for (int m = 0; m < MT; ++m) xc[m] = xn[m];
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) st4(wnext + 4 * u, pre[q]); }
+      }
+      __syncthreads();
+    }
+
+    if (!row_ok) continue;
+    float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+    const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m >= my_mt) continue;
+      const int p = w0 + m * 16 + j;
+      if (p >= a.Wo) continue;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 v = acc[m][n];
+        if (a.bias) v += ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq);
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const long o = (long)p * a.o_sW + (long)n * a.o_sG + 4 * kq;
+        if (ref_r) {
+          const f32x4 rr = ld4(ref_r + o);
+          v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+          v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+        }
+        if (a.accumulate) v += ld4(out_r + o);
+        st4(out_r + o, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient of the 16 -> 16 convolutions, LDS-staged.
 // A workgroup walks a run of output rows (fixed batch item and t).  Per row it keeps in LDS the
 // source rows of x it needs — a ring of 3 h-rows for each of the 2-3 t-slots, with a one-pixel halo
@@ -894,6 +1019,24 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   const bool wlds = (a.GnTot == 1 && a.Gk == 1 && !cin1);
   const int gz = a.GnTot / NT;
   const dim3 block(256);
+  if constexpr (MODE == FWD_S2 || MODE == DGRAD_S2) {
+    const long slab_bytes = (long)a.Gk * NT * 256 * 4;
+    if (!cin1 && gz == 1 && NT >= 2 && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
+      a.hgroups = cdiv(a.Ho, 8);
+      a.tiles = a.To * a.hgroups * a.wtiles;
+#define LCW(NT_)                                                                                               \
+  do {                                                                                                         \
+    auto kern = conv_wide_kernel<MODE, NT_>;                                                                   \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * slab_bytes)) != hipSuccess) \
+      return idee::fail(IDEE_ERR_LAUNCH, "conv: cannot reserve %ld bytes of LDS", 2 * slab_bytes);               \
+    const dim3 grid(one_round(a.tiles, a.B, 1), a.B);                                                          \
+    hipLaunchKernelGGL(kern, grid, dim3(512), 2 * slab_bytes, stream, a);                                      \
+  } while (0)
+      if (NT == 6) LCW(6); else if (NT == 3) LCW(3); else LCW(2);
+#undef LCW
+      return IDEE_OK;
+    }
+  }
 #define LC(NT_, WL_, C1_)                                                                                     \
   do {                                                                                                        \
     auto kern = conv_kernel<MODE, NT_, WL_, C1_>;                                                             \
