@@ -443,6 +443,150 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 16 -> 16 3x3x3 replicate convolution, forward and data gradient, activations staged through LDS.
+// A workgroup (4 waves) walks a run of output rows of one row segment (<= 7 column blocks of 16 pixels) for a
+// fixed (batch item, t).  LDS holds, for each of the 3 T-slots, a ring of 3 source rows with a one-pixel halo
+// (replicate clamp resp. zero padding resolved while staging): moving down one row stages 3 new rows.  The 27
+// weight fragments live in registers; a wave owns up to 2 column blocks, one 16-byte LDS read per block and tap.
+// 65.7 KB of LDS -> two workgroups per CU: one stages while the other multiplies.
+// ---------------------------------------------------------------------------------------------
+constexpr int kC16Sub = 7;                       // column blocks per segment
+constexpr int kC16Row = kC16Sub * 16 + 2;        // staged pixels per source row
+
+template <int MODE /*FWD_REP or DGRAD_REP*/>
+__global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nseg, int hrun, int nhrun) {
+  constexpr int MT = 2;
+  __shared__ __attribute__((aligned(16))) float s_x[9 * kC16Row * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  f32x4 wr[27];
+  {
+    const float* wp = a.wp + (long)wset * 27 * 256;
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) wr[tp] = ld4(wp + tp * 256 + lane * 4);
+  }
+  const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
+  const int nsub = (Wframe + 15) / 16;
+  const int sub_base = nsub / nseg, sub_rem = nsub % nseg;
+  const int nb = a.B / a.wsets;
+  const long nchunks = (long)nb * a.To * nhrun * nseg;
+
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    long r = ch;
+    const int sg = (int)(r % nseg); r /= nseg;
+    const int hr = (int)(r % nhrun); r /= nhrun;
+    const int t = (int)(r % a.To);
+    const int b = (int)(r / a.To) * a.wsets + wset;
+    const int my_sub = sub_base + (sg < sub_rem ? 1 : 0);              // column blocks of this segment
+    const int p0 = 16 * (sg * sub_base + min(sg, sub_rem));            // first frame column of the segment
+    const int rowlen = my_sub * 16 + 2;
+    // source column of staged pixel i:  fwd: clamp(p0 + i - 1) ; dgrad: p0 + i - 2 (zero outside)
+    const int h0 = hr * hrun, h1 = min(a.Ho, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;
+    const float* in_b = a.in + (long)b * a.i_sB;
+    Slot st[3];
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti);
+
+    for (int h = h0; h < h1; ++h) {
+      __syncthreads();   // previous row's readers are done
+      Slot sh[3];
+      int slot_of[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        sh[oh] = slot_h<MODE>(oh, h, a.Hi);
+        const int hs = sh[oh].src;
+        const int slot = hs % 3;
+        slot_of[oh] = slot;
+        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+        if (cur == hs) continue;
+        if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) {
+          const float* src = in_b + (long)st[ot].src * a.i_sT + (long)hs * a.i_sH;
+          float* dst = s_x + (long)(ot * 3 + slot) * kC16Row * 16;
+          for (int u = tid; u < rowlen * 4; u += 256) {
+            const int px = u >> 2, q4 = u & 3;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == FWD_REP) {
+              const int w = min(max(p0 + px - 1, 0), a.Wi - 1);
+              v = ld4(src + (long)w * a.i_sW + 4 * q4);
+            } else {
+              const int w = p0 + px - 2;
+              if (w >= 0 && w < a.Wi) v = ld4(src + (long)w * a.i_sW + 4 * q4);
+            }
+            st4(dst + px * 16 + 4 * q4, v);
+          }
+        }
+      }
+      __syncthreads();
+
+      f32x4 acc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int sub0 = wave * MT;                                      // this wave's first column block
+      const int blk1 = (sub0 + 1 < my_sub) ? 16 : 0;                   // a lone last block re-reads block 0 (result unused)
+      if (sub0 < my_sub) {
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) {
+#pragma unroll
+          for (int oh = 0; oh < 3; ++oh) {
+            const float* rowp = s_x + ((long)(ot * 3 + slot_of[oh]) * kC16Row + sub0 * 16 + j) * 16 + 4 * kq;
+            const int sel = st[ot].tap * 3 + sh[oh].tap;               // weight row (tile-uniform; differs from ot*3+oh only at edges of the dgrad)
+#pragma unroll
+            for (int gs = 0; gs < 9; ++gs) {
+              if (MODE == FWD_REP ? (gs != ot * 3 + oh) : (gs != sel)) continue;
+#pragma unroll
+              for (int ow = 0; ow < 3; ++ow) {
+                // staged index of the source pixel: fwd p + ow ; dgrad p - ow + 2   (p = column inside the segment)
+                const int sh_px = (MODE == FWD_REP) ? ow : 2 - ow;
+                const f32x4 x0 = ld4(rowp + sh_px * 16);
+                const f32x4 x1 = ld4(rowp + (sh_px + blk1) * 16);
+                const f32x4 wf = wr[gs * 3 + ow];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                  acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], x0[s], acc[0], 0, 0, 0);
+                  acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], x1[s], acc[1], 0, 0, 0);
+                }
+              }
+            }
+          }
+        }
+        // epilogue
+        float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+        const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (sub0 + m >= my_sub) continue;
+          const int p = p0 + (sub0 + m) * 16 + j;
+          if (p >= Wframe) continue;
+          int wdst = p;
+          bool atomic = false;
+          if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
+          f32x4 v = acc[m];
+          if (a.bias) v += ld4(a.bias + (long)wset * 16 + 4 * kq);
+          if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          const long o = (long)wdst * a.o_sW + 4 * kq;
+          if (ref_r) {
+            const f32x4 rr = ld4(ref_r + o);
+            v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+            v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+          }
+          if (atomic) {
+            atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
+            atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
+          } else {
+            if (a.accumulate) v += ld4(out_r + o);
+            st4(out_r + o, v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient of the 16 -> 16 convolutions, LDS-staged.
 // A workgroup walks a run of output rows (fixed batch item and t).  Per row it keeps in LDS the
 // source rows of x it needs — a ring of 3 h-rows for each of the 2-3 t-slots, with a one-pixel halo
@@ -1019,6 +1163,22 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   const bool wlds = (a.GnTot == 1 && a.Gk == 1 && !cin1);
   const int gz = a.GnTot / NT;
   const dim3 block(256);
+  if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
+    if (wlds && a.cout_real == 16) {
+      const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
+      const int nsub = cdiv(Wframe, 16);
+      const int nseg = cdiv(nsub, kC16Sub);
+      const long bt = (long)(a.B / a.wsets) * a.To;
+      int hrun = a.Ho;
+      while (hrun > 8 && bt * cdiv(a.Ho, hrun) * nseg * a.wsets < 6L * kCUs) hrun = (hrun + 1) / 2;
+      const int nhrun = cdiv(a.Ho, hrun);
+      const long nchunks = bt * nhrun * nseg;
+      auto kern = conv16_lds_kernel<MODE>;
+      const dim3 grid(one_round(nchunks, a.wsets, wg_per_cu(kern, 256)), a.wsets);
+      hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nseg, hrun, nhrun);
+      return IDEE_OK;
+    }
+  }
   if constexpr (MODE == FWD_S2 || MODE == DGRAD_S2) {
     const long slab_bytes = (long)a.Gk * NT * 256 * 4;
     if (!cin1 && gz == 1 && NT >= 2 && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
