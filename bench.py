@@ -65,33 +65,31 @@ def swin_flops(geom, backward):
     return 2 * f if backward else f
 
 
-# entry point -> device kernel name prefix, to look the launch's HBM traffic up in the committed PMC summary
-_KERNEL_OF = {"idee_swin_block_bwd": "swin_attn_bwd_kernel", "idee_swin_block_fwd": "swin_fwd_mfma_kernel",
-              "idee_conv_fwd": "conv_kernel", "idee_conv_dgrad": "conv_kernel", "idee_conv_wgrad": "wgrad"}
-
-
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes of this same command, corrected as MI355X_MICROARCH.md prescribes) — or None when the
-    summary has no unambiguous row for this entry point (several kernels share an entry point)."""
+    WRITE_SIZE in separate passes of this same command, corrected as MI355X_MICROARCH.md prescribes; see
+    profiles/collect_pmc.py) — or None when the summary has no unambiguous row for this entry point (e.g. the joint
+    head's two convolutions share one kernel name but have different shapes)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
-        rows = json.load(open(path))["kernels"]
+        rows = {r["kernel"]: r["hbm_bytes_per_launch"] for r in json.load(open(path))["kernels"]}
     except Exception:  # noqa: BLE001
         return None
-    pref = _KERNEL_OF.get(key.split("[")[0])
-    if key.startswith("idee_swin_block_bwd"):       # two kernels per launch: sum MLP + attention parts
-        nw = "32" if "w244" in key else "8"
-        parts = [r for r in rows if r["kernel"].startswith("swin_mlp_bwd_kernel") or
-                 (r["kernel"].startswith("swin_attn_bwd_kernel") and f", {nw}," in r["kernel"])]
-        return round(sum(r["hbm_bytes_per_launch"] for r in parts)) if len(parts) == 2 else None
-    if key.startswith("idee_swin_block_fwd"):
-        nw = "32" if "w244" in key else "8"
-        parts = [r for r in rows if r["kernel"].startswith(pref) and f", {nw}," in r["kernel"]]
-        return round(parts[0]["hbm_bytes_per_launch"]) if len(parts) == 1 else None
-    return None
+    name = key.split("[")[0]
+    nw = "32" if "w244" in key else "8"
+    want = None
+    if name == "idee_swin_block_bwd":       # two kernels per launch
+        want = ["swin_mlp_bwd_kernel<16>", f"swin_attn_bwd_kernel<16, 2, {nw}, 4>"]
+    elif name == "idee_swin_block_fwd":
+        want = [f"swin_fwd_mfma_kernel<16, 2, {nw}, true>"]
+    elif "k333 16->16" in key:
+        want = [{"idee_conv_fwd": "conv16_lds_kernel<0>", "idee_conv_dgrad": "conv16_lds_kernel<1>",
+                 "idee_conv_wgrad": "wgrad16_lds_kernel<0, 8>"}[name]]
+    if not want or any(k not in rows for k in want):
+        return None
+    return round(sum(rows[k] for k in want))
 
 
 def host_cores():
