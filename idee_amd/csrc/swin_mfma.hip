@@ -27,6 +27,7 @@ struct Geom {
   int items;            // window groups (64 tokens) per batch item
   int shifted;
   float scale;
+  float inv_nWhW, inv_nWw, inv_whww, inv_ww;   // reciprocals for the coordinate decode (exact for operands < 2^22)
 };
 
 constexpr float kLnEps = 1e-5f;
@@ -98,10 +99,14 @@ __device__ __forceinline__ Tok locate(const Geom& g, int b, int item, int tau, i
   const int wl = item * G + gi;
   const bool active = (item < g.items) && (wl < g.nWin);
   const int wlc = active ? wl : 0;
-  const int iwd = wlc / (g.nWh * g.nWw), r = wlc % (g.nWh * g.nWw);
-  const int iwh = r / g.nWw, iww = r % g.nWw;
-  const int dt = i / (g.wh * g.ww), r2 = i % (g.wh * g.ww);
-  const int dh = r2 / g.ww, dw = r2 % g.ww;
+  // x / d for small non-negative x: (x + 0.5) * (1/d) truncated is exact while x < 2^22 (grids here are < 2^21 windows)
+  auto fdiv = [](int x, float inv) { return (int)(((float)x + 0.5f) * inv); };
+  const int nWhW = g.nWh * g.nWw;
+  const int iwd = fdiv(wlc, g.inv_nWhW), r = wlc - iwd * nWhW;
+  const int iwh = fdiv(r, g.inv_nWw), iww = r - iwh * g.nWw;
+  const int whww = g.wh * g.ww;
+  const int dt = fdiv(i, g.inv_whww), r2 = i - dt * whww;
+  const int dh = fdiv(r2, g.inv_ww), dw = r2 - dh * g.ww;
   const int pd = iwd * g.wd + dt, ph = iwh * g.wh + dh, pw = iww * g.ww + dw;   // rolled frame
   auto axis = [](int p, int P, int w, int s) { return s == 0 ? 2 : (int)(p >= P - w) + (int)(p >= P - s); };
   t.rid = axis(pd, g.Dp, g.wd, g.sd) * 9 + axis(ph, g.Hp, g.wh, g.sh) * 3 + axis(pw, g.Wp, g.ww, g.sw);
@@ -135,16 +140,20 @@ __device__ __forceinline__ f32x4 vfrag(const float* __restrict__ v, int base, in
                mul * v[base + sig<HS>(4 * kq + 3)]};
 }
 
-// sum over the channels of a token held in TL: in-lane partial -> lanes kq = 0..3 (xor 16, 32)
+// Butterfly over the 4 lanes (kq = 0..3: lane xor 16, xor 32) that hold the channels of one token, with gfx950's
+// v_permlane16_swap / v_permlane32_swap: one VALU instruction per step instead of a ds_bpermute round trip through LDS.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float chan_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float chan_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
+  u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 template <int CT>
@@ -974,6 +983,9 @@ int make_geom(const idee_swin_geom* s, Geom& g, int& NW) {
   if (NW != 8 && NW != 16 && NW != 32 && NW != 64)
     return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: window volume %d not in {8,16,32,64}", NW);
   g.items = cdiv(g.nWin, 64 / NW);
+  g.inv_nWhW = 1.0f / (float)(g.nWh * g.nWw); g.inv_nWw = 1.0f / (float)g.nWw;
+  g.inv_whww = 1.0f / (float)(g.wh * g.ww);   g.inv_ww = 1.0f / (float)g.ww;
+  if ((long)g.nWin >= (1L << 22)) return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: %d windows per batch item exceeds 2^22", g.nWin);
   return IDEE_OK;
 }
 
