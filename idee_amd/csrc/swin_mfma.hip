@@ -156,11 +156,11 @@ __device__ __forceinline__ float chan_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int CT>
-__device__ __forceinline__ void layer_norm_tl(const f32x4 (&x)[CT][MT], f32x4 (&xn)[CT][MT], float (&rstd)[MT], const bool (&keep)[MT]) {
+template <int CT, int M>
+__device__ __forceinline__ void layer_norm_tl(const f32x4 (&x)[CT][M], f32x4 (&xn)[CT][M], float (&rstd)[M], const bool (&keep)[M]) {
   constexpr float invC = 1.f / (16 * CT);
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+  for (int m = 0; m < M; ++m) {
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CT; ++c) s += x[c][m][0] + x[c][m][1] + x[c][m][2] + x[c][m][3];
@@ -179,8 +179,8 @@ __device__ __forceinline__ void layer_norm_tl(const f32x4 (&x)[CT][MT], f32x4 (&
 }
 
 // Y[OT][MT] += W X   with fragments wf[OT][KT] (4 k-steps each) and X[KT][MT] in TL
-template <int OT, int KT>
-__device__ __forceinline__ void mm(f32x4 (&Y)[OT][MT], const f32x4 (&wf)[OT][KT], const f32x4 (&X)[KT][MT]) {
+template <int OT, int KT, int M>
+__device__ __forceinline__ void mm(f32x4 (&Y)[OT][M], const f32x4 (&wf)[OT][KT], const f32x4 (&X)[KT][M]) {
 #pragma unroll
   for (int o = 0; o < OT; ++o)
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ __forceinline__ void mm(f32x4 (&Y)[OT][MT], const f32x4 (&wf)[OT][KT]
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) Y[o][m] = MFMA(wf[o][k][s], X[k][m][s], Y[o][m]);
+        for (int m = 0; m < M; ++m) Y[o][m] = MFMA(wf[o][k][s], X[k][m][s], Y[o][m]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -274,14 +274,14 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
     }
     f32x4 XN[CT][MT];
     float rstd[MT];
-    layer_norm_tl<CT>(X, XN, rstd, keep);   // zero padding is applied AFTER norm1 (Swin_3D.py:229-238)
+    layer_norm_tl(X, XN, rstd, keep);   // zero padding is applied AFTER norm1 (Swin_3D.py:229-238)
 
     f32x4 QKV[3 * CT][MT];
 #pragma unroll
     for (int o = 0; o < 3 * CT; ++o)
 #pragma unroll
       for (int m = 0; m < MT; ++m) QKV[o][m] = bq[o];
-    mm<3 * CT, CT>(QKV, wq, XN);
+    mm(QKV, wq, XN);
 
     wave_sync();   // previous iteration's readers of vt / rid are done
 #pragma unroll
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int m = 0; m < MT; ++m) Hs[c][m] = X[c][m] + bp[c];
-    mm<CT, CT>(Hs, wp, O);
+    mm(Hs, wp, O);
     if (SAVE_H) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -367,13 +367,13 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
     f32x4 HN[CT][MT];
     float rstd2[MT];
     bool all[MT] = {true, true, true, true};
-    layer_norm_tl<CT>(Hs, HN, rstd2, all);
+    layer_norm_tl(Hs, HN, rstd2, all);
     f32x4 A1[HT][MT];
 #pragma unroll
     for (int o = 0; o < HT; ++o)
 #pragma unroll
       for (int m = 0; m < MT; ++m) A1[o][m] = b1[o];
-    mm<HT, CT>(A1, w1, HN);
+    mm(A1, w1, HN);
 #pragma unroll
     for (int o = 0; o < HT; ++o)
 #pragma unroll
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int m = 0; m < MT; ++m) Y[c][m] = Hs[c][m] + b2[c];
-    mm<CT, HT>(Y, w2, A1);
+    mm(Y, w2, A1);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
       if (t[m].valid)
@@ -400,19 +400,20 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
 // ---------------------------------------------------------------------------------------------
 
 // TL tile -> image rows in REAL channel order (permutation HS undone on the way out)
-template <int HS>
-__device__ __forceinline__ void put_img(float* img, const f32x4 (&T)[MT], int lane) {
+template <int HS, int M>
+__device__ __forceinline__ void put_img(float* img, const f32x4 (&T)[M], int lane) {
   const int j = lane & 15, kq = lane >> 4;
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < M; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) img[sig<HS>(4 * kq + r) * VS + 16 * m + j] = T[m][r];
 }
 // acc[m][n] += sum_tok A[m][tok] B[n][tok]   over the wave's 64 tokens
+template <int M = MT>
 __device__ __forceinline__ void gemm_tok(f32x4& acc, const float* A, const float* B, int lane) {
   const int row = (lane & 15) * VS + 4 * (lane >> 4);
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+  for (int m = 0; m < M; ++m) {
     const f32x4 fa = ld4(A + row + 16 * m), fb = ld4(B + row + 16 * m);
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = MFMA(fa[s], fb[s], acc);
@@ -440,12 +441,12 @@ __device__ __forceinline__ void flush_vec(float* dst, f32x4 part, int lane) {
 }
 
 // dx = rstd * (dxn - mean(dxn) - xn * mean(dxn * xn)) + add, per token in TL
-template <int CT>
-__device__ __forceinline__ void layer_norm_bwd_tl(const f32x4 (&dxn)[CT][MT], const f32x4 (&xn)[CT][MT], const float (&rstd)[MT],
-                                                  const f32x4 (&add)[CT][MT], f32x4 (&dx)[CT][MT]) {
+template <int CT, int M>
+__device__ __forceinline__ void layer_norm_bwd_tl(const f32x4 (&dxn)[CT][M], const f32x4 (&xn)[CT][M], const float (&rstd)[M],
+                                                  const f32x4 (&add)[CT][M], f32x4 (&dx)[CT][M]) {
   constexpr float invC = 1.f / (16 * CT);
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+  for (int m = 0; m < M; ++m) {
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -464,13 +465,14 @@ __device__ __forceinline__ void layer_norm_bwd_tl(const f32x4 (&dxn)[CT][MT], co
 // backward, part 1: MLP + norm2 (pure per-token; tokens in memory order)
 //   in: h (block state before the MLP, saved by the forward), dy.  out: dh = dL/dh, MLP weight grads.
 // ---------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
+template <int C, int M>
+__global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
     const float* __restrict__ hs, const float* __restrict__ dy, float* __restrict__ dh, const float* __restrict__ fc1_w,
     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float* __restrict__ g_fc1_w,
     float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L) {
   constexpr int CT = C / 16, HID = 4 * C, HT = HID / 16;
   constexpr int HP = 2;                 // hidden 16-blocks per pass (keeps the live set within 256 registers)
+  constexpr int TOK = 16 * M;           // tokens per wave and iteration
   static_assert(HT % HP == 0, "hidden blocks per pass");
   __shared__ __attribute__((aligned(16))) float s_img[4][(2 * CT + 2) * 16 * VS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -495,17 +497,17 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
   float* imgDY = img + CT * 16 * VS;        // CT images
   float* imgA = img + 2 * CT * 16 * VS;     // dA1 tile
   float* imgB = imgA + 16 * VS;             // gelu tile
-  const long items = (L + 63) / 64;
+  const long items = (L + TOK - 1) / TOK;
 
   for (long it0 = (long)blockIdx.x * 4; it0 < items; it0 += (long)gridDim.x * 4) {
-    const long base = (it0 + wave) * 64;
-    bool valid[MT];
-    f32x4 HN[CT][MT], DY[CT][MT];
-    float rstd2[MT];
+    const long base = (it0 + wave) * TOK;
+    bool valid[M];
+    f32x4 HN[CT][M], DY[CT][M];
+    float rstd2[M];
     {
-      f32x4 Hs[CT][MT];
+      f32x4 Hs[CT][M];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < M; ++m) {
         const long tok = base + 16 * m + j;
         valid[m] = tok < L;
 #pragma unroll
@@ -514,8 +516,10 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
           DY[c][m] = valid[m] ? ld4(dy + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      bool all[MT] = {true, true, true, true};
-      layer_norm_tl<CT>(Hs, HN, rstd2, all);
+      bool all[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) all[m] = true;
+      layer_norm_tl(Hs, HN, rstd2, all);
     }
     wave_sync();   // previous iteration's image readers are done
 #pragma unroll
@@ -523,18 +527,18 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
       put_img<1>(imgHN + c * 16 * VS, HN[c], lane);
       put_img<1>(imgDY + c * 16 * VS, DY[c], lane);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) pb2[c] += DY[c][m];
+      for (int m = 0; m < M; ++m) pb2[c] += DY[c][m];
     }
-    f32x4 dHN[CT][MT];
+    f32x4 dHN[CT][M];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) dHN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < M; ++m) dHN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int hp = 0; hp < HT / HP; ++hp) {
       // fragments of this pass (L1/L2-resident; re-read each pass instead of pinning 48 registers)
-      f32x4 w1[HP][CT], w2t[HP][CT], w1t[CT][HP], A1[HP][MT], dG[HP][MT];
+      f32x4 w1[HP][CT], w2t[HP][CT], w1t[CT][HP], A1[HP][M], dG[HP][M];
       int oz;   // opaque zero: pins this pass's fragment loads inside the pass (no hoisting across passes)
       asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
       const float* fc1_w_ = fc1_w + oz;
@@ -550,14 +554,14 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
           w1t[k][o] = wfrag<true, 1, 1>(fc1_w_, C, 16 * k, 16 * ho, lane);     // [c][hid] = fc1_w[hid][c]
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { A1[o][m] = b1; dG[o][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int m = 0; m < M; ++m) { A1[o][m] = b1; dG[o][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
-      mm<HP, CT>(A1, w1, HN);
-      mm<HP, CT>(dG, w2t, DY);
+      mm(A1, w1, HN);
+      mm(dG, w2t, DY);
 #pragma unroll
       for (int o = 0; o < HP; ++o)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < M; ++m) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float gl, dgl;
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
           }
           pb1[hp * HP + o] += dG[o][m];
         }
-      mm<CT, HP>(dHN, w1t, dG);
+      mm(dHN, w1t, dG);
       // weight gradients of this pass: dW1[hid][c] += dA1 . HN^T ; dW2[c][hid] += DY . G^T  (K = tokens)
 #pragma unroll
       for (int o = 0; o < HP; ++o) {
@@ -578,15 +582,15 @@ __global__ __launch_bounds__(256) void swin_mlp_bwd_kernel(
         wave_sync();
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          gemm_tok(aW1[ho][c], imgA, imgHN + c * 16 * VS, lane);
-          gemm_tok(aW2[c][ho], imgDY + c * 16 * VS, imgB, lane);
+          gemm_tok<M>(aW1[ho][c], imgA, imgHN + c * 16 * VS, lane);
+          gemm_tok<M>(aW2[c][ho], imgDY + c * 16 * VS, imgB, lane);
         }
       }
     }
-    f32x4 dH[CT][MT];
-    layer_norm_bwd_tl<CT>(dHN, HN, rstd2, DY, dH);
+    f32x4 dH[CT][M];
+    layer_norm_bwd_tl(dHN, HN, rstd2, DY, dH);
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < M; ++m)
       if (valid[m])
 #pragma unroll
         for (int c = 0; c < CT; ++c) st4(dh + (base + 16 * m + j) * C + 16 * c + 4 * kq, dH[c][m]);
@@ -707,20 +711,20 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
     }
     f32x4 XN[CT][MT];
     float rstd[MT];
-    layer_norm_tl<CT>(X, XN, rstd, keep);
+    layer_norm_tl(X, XN, rstd, keep);
     f32x4 QKV[3 * CT][MT];
 #pragma unroll
     for (int o = 0; o < 3 * CT; ++o)
 #pragma unroll
       for (int m = 0; m < MT; ++m) QKV[o][m] = bq[o];
-    mm<3 * CT, CT>(QKV, wq, XN);
+    mm(QKV, wq, XN);
     // dO = proj_w^T dH  (TL with the head permutation, like V and O)
     f32x4 DO[CT][MT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int m = 0; m < MT; ++m) { DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pbp[c] += DH[c][m]; }
-    mm<CT, CT>(DO, wpt, DH);
+    mm(DO, wpt, DH);
 
     wave_sync();   // previous iteration's image readers are done
 #pragma unroll
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
             dXN[oc][m] = MFMA(wqt[oc][2 * CT + k][s], DV[k][m][s], dXN[oc][m]);
           }
     f32x4 DX[CT][MT];
-    layer_norm_bwd_tl<CT>(dXN, XN, rstd, DH, DX);
+    layer_norm_bwd_tl(dXN, XN, rstd, DH, DX);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
       if (t[m].valid)
@@ -1038,13 +1042,15 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
   const long L = (long)s->D * s->H * s->W;
   hipStream_t st = (hipStream_t)stream;
   {   // part 1: MLP + norm2 (token order)
-    const dim3 grid = swin_grid(cdiv(cdiv(L, 64), 4), B, 1);
-    if (C == 16)
-      hipLaunchKernelGGL((swin_mlp_bwd_kernel<16>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
+    if (C == 16) {   // 32 tokens per wave: half the live registers -> two waves per SIMD overlap GELU with the MFMA chains
+      const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 2);
+      hipLaunchKernelGGL((swin_mlp_bwd_kernel<16, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
                          p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
-    else if (C == 32)
-      hipLaunchKernelGGL((swin_mlp_bwd_kernel<32>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
+    } else if (C == 32) {
+      const dim3 grid = swin_grid(cdiv(cdiv(L, 64), 4), B, 1);
+      hipLaunchKernelGGL((swin_mlp_bwd_kernel<32, 4>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
                          p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
+    }
     else return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: C=%d is not built", C);
   }
   const int WPB = C == 16 ? 4 : 2;   // waves per workgroup (LDS images: 26 KB per wave at C=16, 48 KB at C=32)
