@@ -40,7 +40,7 @@ constexpr int VS = 68;  // LDS image row stride in floats (64 tokens + pad); row
 // about half the instructions of erff(), which matters because GELU is the largest VALU item of the block.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
@@ -56,7 +56,7 @@ __device__ __forceinline__ float gelu_grad(float a) {
 // gelu(a) and d gelu / da with ONE exp: exp(-a^2/2) serves both the erf tail and the Gaussian density
 __device__ __forceinline__ void gelu_both(float a, float& gl, float& dgl) {
   const float x = a * 0.70710678118654752f, ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
           for (int kt = 0; kt < TPW; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { S[kt][qt][r] = __expf(S[kt][qt][r] - mx); l += S[kt][qt][r]; }
-          const float inv = 1.f / chan_sum(l);
+          const float inv = __builtin_amdgcn_rcpf(chan_sum(l));   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) S[kt][qt] *= inv;
         }
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
           for (int kt = 0; kt < TPW; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { P[kt][qt][r] = __expf(P[kt][qt][r] - mx); l += P[kt][qt][r]; }
-          const float inv = 1.f / chan_sum(l);
+          const float inv = __builtin_amdgcn_rcpf(chan_sum(l));   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
           float D = 0.f;
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) {
