@@ -33,7 +33,7 @@ class SwinGrads(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = ([("mode", _I), ("B", _I), ("wsets", _I), ("T", _I), ("H", _I), ("W", _I), ("Cin", _I), ("Cout", _I)]
                 + [(n, _L) for n in ("x_sB", "x_sT", "x_sH", "x_sW", "x_sG", "y_sB", "y_sT", "y_sH", "y_sW", "y_sG")]
-                + [("relu", _I)])
+                + [("relu", _I), ("x_gpu", _I), ("y_gpu", _I), ("x_sU", _L), ("y_sU", _L)])
 
 
 CONV_K333_REPLICATE, CONV_K233_S2_ZERO = 0, 1

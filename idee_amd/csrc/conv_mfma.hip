@@ -38,13 +38,17 @@ struct ConvArgs {
   int relu;
   int accumulate;         // out += result (plain-store path)
   int ntaps;
-  long i_sB, i_sT, i_sH, i_sW, i_sG;
-  long o_sB, o_sT, o_sH, o_sW, o_sG;
+  long i_sB, i_sT, i_sH, i_sW, i_sG, i_sU;
+  long o_sB, o_sT, o_sH, o_sW, o_sG, o_sU;
+  int i_gpu, o_gpu;                      // 16-channel groups per unit: group g lives at (g / gpu) * sU + (g % gpu) * sG
   int nsub, wtiles, sub_base, sub_rem;   // 16-pixel column blocks per row and their split into wave tiles
   int hgroups, tiles;                    // ceil(Ho/4); To*hgroups*wtiles
 };
 
 struct Slot { int src, tap; bool ok; };
+
+// offset of 16-channel group g: units of `gpu` groups (e.g. the V slices of z_q), sU apart; groups sG apart inside a unit
+__device__ __forceinline__ long goff(int g, int gpu, long sU, long sG) { return (long)(g / gpu) * sU + (long)(g % gpu) * sG; }
 
 template <int MODE>
 __device__ __forceinline__ Slot slot_t(int o, int t, int Ti) {
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256, NT >= 6 ? 2 : 1) void conv_kernel(ConvArgs a) 
                 float v0 = (okm[m] && kq == 0) ? rowp[off[m]] : 0.f;
                 xf[m] = f32x4{v0, 0.f, 0.f, 0.f};
               } else {
-                xf[m] = okm[m] ? ld4(rowp + off[m] + g * a.i_sG) : f32x4{0.f, 0.f, 0.f, 0.f};
+                xf[m] = okm[m] ? ld4(rowp + off[m] + goff(g, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
               }
             }
 #pragma unroll
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, NT >= 6 ? 2 : 1) void conv_kernel(ConvArgs a) 
           else v += ld4(a.bias + (long)wset * a.GnTot * 16 + cg * 16 + 4 * kq);
         }
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const long o = (long)wdst * a.o_sW + (long)cg * a.o_sG + 4 * kq;
+        const long o = (long)wdst * a.o_sW + goff(cg, a.o_gpu, a.o_sU, a.o_sG) + 4 * kq;
         if (ref_r) {
           const f32x4 rr = ld4(ref_r + o);
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
@@ -220,8 +224,9 @@ struct WgradArgs {
   int To;         // dy extent in T (H, W equal)
   int Cin, CoutPad, cout_real;
   int ntaps;
-  long x_sB, x_sT, x_sH, x_sW, x_sG;
-  long y_sB, y_sT, y_sH, y_sW, y_sG;
+  long x_sB, x_sT, x_sH, x_sW, x_sG, x_sU;
+  long y_sB, y_sT, y_sH, y_sW, y_sG, y_sU;
+  int x_gpu, y_gpu;
   int rows;       // To * H  (pixel rows per batch item)
   int row_chunks; // gridDim.x
   int tap_groups; // ntaps / TPW
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int n = 0; n < NTB; ++n) {
         const int co = (gb0 + n) * 16 + r16;
-        bf[n] = (pin && co < a.cout_real) ? dy_r[(long)p * a.y_sW + (a.cout_real == 1 ? -r16 : (long)(gb0 + n) * a.y_sG)] : 0.f;
+        bf[n] = (pin && co < a.cout_real) ? dy_r[(long)p * a.y_sW + (a.cout_real == 1 ? -r16 : goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG))] : 0.f;
         bsum[n] += bf[n];
       }
 #pragma unroll
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const float* xp = x_b + (long)st * a.x_sT + (long)sh * a.x_sH + (long)sw * a.x_sW;
 #pragma unroll
         for (int i = 0; i < NTA; ++i) {
-          const float af = ok ? xp[(long)(ga0 + i) * a.x_sG] : 0.f;
+          const float af = ok ? xp[goff(ga0 + i, a.x_gpu, a.x_sU, a.x_sG)] : 0.f;
 #pragma unroll
           for (int n = 0; n < NTB; ++n)
             acc[tp][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[tp][i][n], 0, 0, 0);
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
         for (int g = 0; g < a.Gk; ++g) {
           if (g + 1 < a.Gk) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) xn[m] = okm[m] ? ld4(rowp + off[m] + (long)(g + 1) * a.i_sG) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MT; ++m) xn[m] = okm[m] ? ld4(rowp + off[m] + goff(g + 1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
         f32x4 v = acc[m][n];
         if (a.bias) v += ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq);
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const long o = (long)p * a.o_sW + (long)n * a.o_sG + 4 * kq;
+        const long o = (long)p * a.o_sW + goff(n, a.o_gpu, a.o_sU, a.o_sG) + 4 * kq;
         if (ref_r) {
           const f32x4 rr = ld4(ref_r + o);
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
           const int px = u / (CI / 4), q = u % (CI / 4);       // q: 16-byte unit inside the pixel's channels
           const int w = w0 + px - 1;
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + (long)(q >> 2) * a.x_sG + 4 * (q & 3));
+          if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + goff(q >> 2, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q & 3));
           st4(dst + px * PSX + 4 * q, v);
         }
       }
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
           const int px = u / (CO / 4), q = u % (CO / 4);
           const int w = w0 + px;
           const bool in = px < seg && w < a.W;
-          st4(s_dy + px * PSY + 4 * q, in ? ld4(src + (long)w * a.y_sW + (long)(q >> 2) * a.y_sG + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f});
+          st4(s_dy + px * PSY + 4 * q, in ? ld4(src + (long)w * a.y_sW + goff(q >> 2, a.y_gpu, a.y_sU, a.y_sG) + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f});
         }
       }
       __syncthreads();
@@ -928,7 +933,8 @@ struct C1Args {
   float* dwp;          // wgrad: (wsets, 18, C, 16)
   float* dbias;        // (wsets, 16) or null
   int B, wsets, H, W, C;
-  long x_sB, x_sT, x_sH, x_sW, x_sG;
+  long x_sB, x_sT, x_sH, x_sW, x_sG, x_sU;
+  int x_gpu;
   int accumulate;
 };
 // weight of (tap, cin) for cout 0 in the packed buffers
@@ -954,7 +960,7 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
       const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H);
       b = (int)(p / ((long)a.W * a.H));
       const float* wp = a.w + (long)(b % a.wsets) * 18 * Gi * 256;
-      const float* xb = a.x + (long)b * a.x_sB + (long)(q / 4) * a.x_sG + 4 * (q % 4);
+      const float* xb = a.x + (long)b * a.x_sB + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -1013,7 +1019,7 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
         acc += (kt == 0 ? wr[oh * 3 + ow] : wr[9 + oh * 3 + ow]) * g;
       }
     }
-    const long off = (long)b * a.x_sB + (long)kt * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + (long)(q / 4) * a.x_sG + 4 * (q % 4);
+    const long off = (long)b * a.x_sB + (long)kt * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
     if (a.relu_ref) {
       const f32x4 rr = ld4(a.relu_ref + off);
 #pragma unroll
@@ -1054,7 +1060,7 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
         g[oh * 3 + ow] = (h >= 0 && h < a.H && w >= 0 && w < a.W) ? dyb[(long)h * a.W + w] : 0.f;
       }
     if (q == 0) bsum += g[4];
-    const float* xb = a.x + (long)b * a.x_sB + (long)hs * a.x_sH + (long)ws * a.x_sW + (long)(q / 4) * a.x_sG + 4 * (q % 4);
+    const float* xb = a.x + (long)b * a.x_sB + (long)hs * a.x_sH + (long)ws * a.x_sW + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const f32x4 xv = ld4(xb + (long)kt * a.x_sT);
@@ -1117,6 +1123,7 @@ void fill_c1(C1Args& a, const idee_conv_desc* d) {
   memset(&a, 0, sizeof(a));
   a.B = d->B; a.wsets = d->wsets; a.H = d->H; a.W = d->W; a.C = d->Cin;
   a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;
+  a.x_sU = d->x_sU; a.x_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30);
 }
 
 int check_desc(const idee_conv_desc* d) {
@@ -1265,6 +1272,7 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const float* x, const floa
   a.Gk = d->Cin / 16; a.GnTot = (d->Cout + 15) / 16; a.cout_real = d->Cout; a.relu = d->relu; a.ntaps = n_taps(d);
   a.i_sB = d->x_sB; a.i_sT = d->x_sT; a.i_sH = d->x_sH; a.i_sW = d->x_sW; a.i_sG = d->x_sG;
   a.o_sB = d->y_sB; a.o_sT = d->y_sT; a.o_sH = d->y_sH; a.o_sW = d->y_sW; a.o_sG = d->y_sG;
+  a.i_sU = d->x_sU; a.i_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30); a.o_sU = d->y_sU; a.o_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30);
   split_tiles(a, a.Wo);
   if (d->mode == IDEE_CONV_K333_REPLICATE) launch_conv<FWD_REP>(a, false, (hipStream_t)stream);
   else launch_conv<FWD_S2>(a, false, (hipStream_t)stream);
@@ -1292,6 +1300,7 @@ extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const f
   a.Gk = (d->Cout + 15) / 16; a.GnTot = d->Cin / 16; a.cout_real = d->Cin; a.relu = 0; a.ntaps = n_taps(d);
   a.i_sB = d->y_sB; a.i_sT = d->y_sT; a.i_sH = d->y_sH; a.i_sW = d->y_sW; a.i_sG = d->y_sG;
   a.o_sB = d->x_sB; a.o_sT = d->x_sT; a.o_sH = d->x_sH; a.o_sW = d->x_sW; a.o_sG = d->x_sG;
+  a.i_sU = d->y_sU; a.i_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30); a.o_sU = d->x_sU; a.o_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30);
   const bool cin1 = d->Cout == 1;
   if (d->mode == IDEE_CONV_K333_REPLICATE) {
     IDEE_CHECK_ARG(!cin1, "conv_dgrad: Cout == 1 is only built for the (2,3,3) mode");
@@ -1323,6 +1332,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
   a.Cin = d->Cin; a.CoutPad = ((d->Cout + 15) / 16) * 16; a.cout_real = d->Cout; a.ntaps = n_taps(d);
   a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;
   a.y_sB = d->y_sB; a.y_sT = d->y_sT; a.y_sH = d->y_sH; a.y_sW = d->y_sW; a.y_sG = d->y_sG;
+  a.x_sU = d->x_sU; a.x_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30); a.y_sU = d->y_sU; a.y_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30);
   a.rows = a.To * d->H;
   const int Ga = d->Cin / 16, Gb = a.CoutPad / 16;
   const long total_rows = (long)(d->B / d->wsets) * a.rows;

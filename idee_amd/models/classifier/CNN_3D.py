@@ -65,7 +65,7 @@ class CNN_3D(_stacked.StackedModule):
             raise NotImplementedError("idee_amd classifier: dropout > 0 is not built (cls_drop_rate default is 0)")
         z, y = ops.ClassifierHeads.apply(zq, self.j_w1, self.j_b1, self.j_w2, self.j_b2, self.j_w3, self.j_b3, self.h_w1,
                                          self.h_b1, self.h_w2, self.h_b2, self.h_w3, self.h_b3)
-        return z, [y[:, v:v + 1] for v in range(self.in_var)]
+        return z, [y[:, v:v + 1] for v in range(self.in_var)]      # (N,1,H,W) each; (N,1,T/8,H,W) when T > 8, as the reference
 
     def forward(self, x):
         """x (N,V,C,T,H,W) as CNN_3D.forward (classifier/CNN_3D.py:112-139)."""

@@ -119,8 +119,11 @@ class SwinBlock(torch.autograd.Function):
 class ConvLayer:
     """One convolution of the path, described once (idee_conv_desc) and run fwd / dgrad / wgrad."""
 
-    def __init__(self, mode, B, wsets, T, H, W, Cin, Cout, xs, ys, relu):
-        self.desc = L.ConvDesc(mode, B, wsets, T, H, W, Cin, Cout, *xs, *ys, int(relu))
+    def __init__(self, mode, B, wsets, T, H, W, Cin, Cout, xs, ys, relu, x_units=None):
+        """xs / ys: (sB, sT, sH, sW, sG) float strides.  x_units = (groups per unit, unit stride): two-level channel
+        groups of the input (the joint head reads the V slices of z_q)."""
+        gpu, sU = x_units if x_units is not None else (0, 0)
+        self.desc = L.ConvDesc(mode, B, wsets, T, H, W, Cin, Cout, *xs, *ys, int(relu), gpu, 0, sU, 0)
         self.mode, self.B, self.wsets, self.Cin, self.Cout = mode, B, wsets, Cin, Cout
         self.ntaps = 27 if mode == L.CONV_K333_REPLICATE else 18
         self.packed_floats = L.load().idee_conv_packed_floats(C.byref(self.desc))
@@ -210,30 +213,31 @@ class ClassifierHeads(torch.autograd.Function):
         N, V, T, H, W, Cc = zq.shape
         dim = hw1.shape[1]
         Dj = jw1.shape[0]
+        if T < 8:
+            raise RuntimeError(f"classifier: T={T} is smaller than the three stride-2 temporal kernels need (the reference "
+                               "raises too: kernel size can't be greater than actual input size)")
         T1 = (T - 2) // 2 + 1
         T2 = (T1 - 2) // 2 + 1
-        T3 = (T2 - 2) // 2 + 1
-        if T3 != 1:
-            raise L.IdeeHipError(f"classifier: T={T} does not reduce to one step (the reference squeezes dim 2); T must be 8")
+        T3 = (T2 - 2) // 2 + 1          # 1 at T = 8 (squeezed); 2 at T = 16: the reference then returns (N,1,2,H,W)
         dev = zq.device
         K = L.CONV_K233_S2_ZERO
         # joint head: channel groups of conv1's input are the V slices of zq
-        j1 = ConvLayer(K, N, 1, T, H, W, V * Cc, Dj, (V * T * H * W * Cc, H * W * Cc, W * Cc, Cc, T * H * W * Cc),
-                       _cl_strides(T1, H, W, Dj), True)
+        j1 = ConvLayer(K, N, 1, T, H, W, V * Cc, Dj, (V * T * H * W * Cc, H * W * Cc, W * Cc, Cc, 16),
+                       _cl_strides(T1, H, W, Dj), True, x_units=(Cc // 16, T * H * W * Cc))
         j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True)
-        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (H * W, H * W, W, 1, 1), False)
+        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False)
         h1 = ConvLayer(K, N * V, V, T, H, W, Cc, dim, _cl_strides(T, H, W, Cc), _cl_strides(T1, H, W, dim), True)
         h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True)
-        h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (H * W, H * W, W, 1, 1), False)
+        h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (T3 * H * W, H * W, W, 1, 1), False)
         convs = (j1, j2, j3, h1, h2, h3)
         weights = (jw1, jw2, jw3, hw1, hw2, hw3)
         packs = [c.pack(w) for c, w in zip(convs, weights)]
         ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=torch.float32)
         ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=torch.float32)
-        z = torch.empty((N, 1, H, W), device=dev, dtype=torch.float32)
+        z = torch.empty((N, 1, H, W) if T3 == 1 else (N, 1, T3, H, W), device=dev, dtype=torch.float32)
         ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=torch.float32)
         ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=torch.float32)
-        y = torch.empty((N, V, H, W), device=dev, dtype=torch.float32)
+        y = torch.empty((N, V, H, W) if T3 == 1 else (N, V, T3, H, W), device=dev, dtype=torch.float32)
         j1.fwd(zq, packs[0][0], jb1, ja1)
         j2.fwd(ja1, packs[1][0], jb2, ja2)
         j3.fwd(ja2, packs[2][0], jb3, z)

@@ -107,7 +107,7 @@ int idee_relpos_bias_scatter(const float* ddense, const int64_t* index, float* d
  * The descriptor speaks about the FORWARD conv: x (input, extent T,H,W) -> y (output extent
  * To,H,W with To = T or (T-2)/2+1).  Tensors are addressed by float strides so one kernel
  * serves per-variable convs (B = N*V, wsets = V) and the joint head whose 16-channel groups
- * are the V slices of z_q (x_sG = T*H*W*16).  Channel group g, channel c: + g*sG + c.
+ * are the V slices of z_q (see x_gpu / x_sU).  Channel group g, channel c: + g*sG + c.
  * Cin must be a multiple of 16; Cout a multiple of 16, or 1 (final class conv).
  * ---------------------------------------------------------------------------------------- */
 enum { IDEE_CONV_K333_REPLICATE = 0, IDEE_CONV_K233_S2_ZERO = 1 };
@@ -120,6 +120,10 @@ typedef struct {
   long x_sB, x_sT, x_sH, x_sW, x_sG;
   long y_sB, y_sT, y_sH, y_sW, y_sG;
   int relu; /* fwd: ReLU after the bias */
+  /* optional two-level channel-group addressing: group g at (g / gpu) * sU + (g % gpu) * sG.
+   * gpu <= 0 means one level (g * sG).  The joint head reads z_q (N,V,T,H,W,C): gpu = C/16, sU = T*H*W*C, sG = 16. */
+  int x_gpu, y_gpu;
+  long x_sU, y_sU;
 } idee_conv_desc;
 
 /* floats in a packed (fragment-ordered) weight buffer / in a packed weight-gradient buffer */

@@ -470,3 +470,62 @@ def test_vq_nearest_golden(tag):
         ((zq * dev(a["r"])).sum() + 1.7 * loss.sum()).backward()
         gclose("dx", x.grad, a["dx"])
         gclose("dembed", q._codebook.embed.grad, grads["_codebook.embed"])
+
+
+def test_small_config_c32_vs_oracle():
+    """Builder-defined "small" width: embed 32, head_dim 16, codebook/cls dim 32 — full model
+    forward + one backward against the oracle."""
+    from oracle import idee_oracle as O
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    torch.manual_seed(21)
+    kw = dict(encoder="Swin_3D", in_channels=2, in_channels_dynamic=2, en_embed_dim=[32, 32], en_depths=[2, 2],
+              codebook_dim=32, cls_dim=32)
+    cfg = default_config(**kw)
+    m = VQ_model(cfg)
+    g = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 / max(1.0, float(p[0].numel() if p.ndim > 1 else 1)) ** 0.5) + (0.0 if p.ndim > 1 else 0.05))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ocfg = O.default_cfg(**kw)
+    x = torch.randn((1, 2, 2, 8, 12, 16), generator=g)
+    sdl = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+    zo, yo, ano, zqo, lzo = O.vq_model_forward(x, sdl, ocfg, training=True)
+    rz = torch.randn(zo.shape, generator=g)
+    ((zo * rz).sum() + sum(t.sum() for t in yo) + lzo.sum()).backward()
+    m = m.to(DEV).train()
+    z, y, an, zq, lz = m(x.to(DEV))
+    s = torch.einsum("nvethw,de->nvthwd", O.swin_encoder(x, sd, ocfg), sd["vq.project_in.weight"]) + sd["vq.project_in.bias"]
+    assert bool((s.abs() > 1e-5).all()), "boundary token in the seeded case"
+    assert torch.equal(an.cpu(), ano)
+    close("z", z, zo, atol=5e-5, rtol=5e-4)
+    close("z_q", zq, zqo)
+    close("loss_z_q", lz, lzo, atol=1e-5, rtol=1e-3)
+    ((z * rz.to(DEV)).sum() + sum(t.sum() for t in y) + lz.sum()).backward()
+    ps = dict(m.encoder.named_parameters())
+    for key, name, idx in m.encoder._key_map():
+        if name.endswith("_index"):
+            continue
+        base = name[:-1] if name.endswith("_ds_w5") else name
+        gg = ps[base].grad
+        gg = gg.view(*gg.shape, 1, 1, 1) if name.endswith("_ds_w5") else gg
+        gclose_relu("d" + key, gg if idx is None else gg[idx], sdl["encoder." + key].grad)
+
+
+def test_classifier_T16_shapes_and_T4_error():
+    """Outside the reference's working envelope: T=16 yields a 2-step map, T=4 raises."""
+    from oracle import idee_oracle as O
+    from idee_amd.models.classifier.CNN_3D import CNN_3D
+    torch.manual_seed(31)
+    c = CNN_3D(in_var=2, embed_dim=16, dim=16, drop_rate=0.0)
+    sd = {k: v.clone() for k, v in c.state_dict().items()}
+    x = torch.randn(1, 2, 16, 16, 6, 10)
+    zo, yo = O.classifier(x, sd, pre="")
+    c = c.to(DEV)
+    z, y = c(x.to(DEV))
+    assert tuple(z.shape) == tuple(zo.shape) == (1, 1, 2, 6, 10)
+    close("z", z, zo)
+    close("y", torch.stack(y), torch.stack(yo))
+    with pytest.raises(RuntimeError):
+        c(torch.randn(1, 2, 16, 4, 6, 10, device=DEV))
