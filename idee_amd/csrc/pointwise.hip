@@ -674,6 +674,61 @@ __global__ __launch_bounds__(256) void vq_nn_bwd_kernel(const float* __restrict_
   for (int i = threadIdx.x; i < K * E; i += 256) atomicAdd(dembed + i, s_g[i]);
 }
 
+// -------------------------------------------------------------------------------------------
+// Device-side bookkeeping of the training drivers (utils/utils_train.py): confusion counts of the thresholded
+// prediction (evaluator :175-267, evaluator_synthetic :269-348) and the majority-vote anomaly collector (:529-554),
+// so that the per-iteration D2H syncs of train_synthetic.py:207-215 become one read per epoch.
+// counts[label*4 + {0 correct, 1 seen, 2 union, 3 predicted}], label in {0, 1}; counts[8] = pixels seen (valid)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void confusion_counts_kernel(const float* __restrict__ logits, const float* __restrict__ gt,
+                                                               const float* __restrict__ valid, long M, float thr,
+                                                               unsigned long long* __restrict__ counts) {
+  unsigned c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long)gridDim.x * 256) {
+    if (valid && !(valid[i] > 0.f)) continue;
+    const float pr = 1.f / (1.f + expf(-logits[i]));     // torch.sigmoid, then `pred > threshold` (train_synthetic.py:209-212)
+    const int pc = pr > thr ? 1 : 0;
+    const float g = gt[i];
+    c[8] += 1;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const bool p = pc == l, t = g == (float)l;
+      c[l * 4 + 0] += p && t; c[l * 4 + 1] += t; c[l * 4 + 2] += p || t; c[l * 4 + 3] += p;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    unsigned v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(counts + k, (unsigned long long)v);
+  }
+}
+
+// acc[v][idx_n - dt + 1 + t][hw] += anomaly[n][v][dt - 1 - t][hw] ; cnt likewise += 1      (np.flip over time)
+__global__ __launch_bounds__(256) void anomaly_vote_kernel(const long long* __restrict__ anomaly, const int* __restrict__ idx_end,
+                                                           float* __restrict__ acc, float* __restrict__ cnt, int n_batch, int V,
+                                                           int dt, long HW, int TT) {
+  const long total = (long)n_batch * V * dt * HW;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long hw = e % HW; long r = e / HW;
+    const int t = (int)(r % dt); r /= dt;
+    const int v = (int)(r % V); const int n = (int)(r / V);
+    const int tt = idx_end[n] - dt + 1 + t;
+    if (tt < 0 || tt >= TT) continue;
+    const float a = (float)anomaly[(((long)n * V + v) * dt + (dt - 1 - t)) * HW + hw];
+    atomicAdd(acc + ((long)v * TT + tt) * HW + hw, a);
+    atomicAdd(cnt + ((long)v * TT + tt) * HW + hw, 1.f);
+  }
+}
+__global__ __launch_bounds__(256) void anomaly_vote_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ cnt,
+                                                                    float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float r = acc[i] / cnt[i];                       // 0/0 -> NaN stays NaN, as in the reference
+    out[i] = r >= 0.5f ? 1.f : (r < 0.5f ? 0.f : r);
+  }
+}
+
 int stream_grid(long items) { return imin(cdiv(items, 256), kCUs * 8); }
 
 }  // namespace
@@ -877,5 +932,30 @@ extern "C" int idee_vq_nn_bwd(const float* x, const float* embed, const int64_t*
   else if (E == 32) hipLaunchKernelGGL((vq_nn_bwd_kernel<32>), dim3(nb), dim3(256), 0, st, x, embed, (const long long*)indices, dq, gloss, dx, dembed, M, K, w_commit);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "vq_nn: dim %d not built", E);
   IDEE_LAUNCH_CHECK("vq_nn_bwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_confusion_counts(const float* logits, const float* gt, const float* valid, long M, float threshold,
+                                     uint64_t* counts, idee_stream_t stream) {
+  IDEE_CHECK_ARG(logits && gt && counts && M > 0, "confusion_counts: bad argument");
+  hipLaunchKernelGGL(confusion_counts_kernel, dim3(imin(cdiv(M, 256), 512)), dim3(256), 0, (hipStream_t)stream, logits, gt, valid,
+                     M, threshold, (unsigned long long*)counts);
+  IDEE_LAUNCH_CHECK("confusion_counts");
+  return IDEE_OK;
+}
+
+extern "C" int idee_anomaly_vote_accumulate(const int64_t* anomaly, const int32_t* idx_end, float* acc, float* cnt, int n_batch,
+                                            int V, int dt, long HW, int TT, idee_stream_t stream) {
+  IDEE_CHECK_ARG(anomaly && idx_end && acc && cnt && n_batch > 0 && V > 0 && dt > 0 && HW > 0 && TT > 0, "anomaly_vote_accumulate: bad argument");
+  hipLaunchKernelGGL(anomaly_vote_kernel, dim3(stream_grid((long)n_batch * V * dt * HW)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)anomaly, idx_end, acc, cnt, n_batch, V, dt, HW, TT);
+  IDEE_LAUNCH_CHECK("anomaly_vote_accumulate");
+  return IDEE_OK;
+}
+
+extern "C" int idee_anomaly_vote_finalize(const float* acc, const float* cnt, float* out, long n, idee_stream_t stream) {
+  IDEE_CHECK_ARG(acc && cnt && out && n > 0, "anomaly_vote_finalize: bad argument");
+  hipLaunchKernelGGL(anomaly_vote_finalize_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, acc, cnt, out, n);
+  IDEE_LAUNCH_CHECK("anomaly_vote_finalize");
   return IDEE_OK;
 }

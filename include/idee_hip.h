@@ -222,6 +222,21 @@ int idee_anomaly_l1_bwd(const float* zq, const float* mask_extreme, const float*
 int idee_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, float grad_scale, idee_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side bookkeeping of the training drivers: replaces the per-iteration
+ * `.cpu().numpy()` + numpy confusion counts of train_synthetic.py:207-215 / utils/utils_train.py:175-348 and the
+ * majority-vote anomaly collector utils_train.py:529-554.
+ *   counts (9 x uint64, accumulate): [label*4 + {correct, seen, union, predicted}] for labels 0,1; [8] = valid pixels
+ *   prediction = sigmoid(logit) > threshold (0.5 synthetic, 0.35 real data); valid (M) | NULL
+ *   vote: anomaly int64 (n, V, dt, HW); idx_end int32 (n) = position of each clip's last step in the timeline;
+ *   acc, cnt (V, TT, HW) accumulate the time-flipped votes; finalize: out = acc/cnt >= 0.5 (NaN where never seen)
+ * ---------------------------------------------------------------------------------------- */
+int idee_confusion_counts(const float* logits, const float* gt, const float* valid, long M, float threshold,
+                          uint64_t* counts, idee_stream_t stream);
+int idee_anomaly_vote_accumulate(const int64_t* anomaly, const int32_t* idx_end, float* acc, float* cnt, int n_batch, int V,
+                                 int dt, long HW, int TT, idee_stream_t stream);
+int idee_anomaly_vote_finalize(const float* acc, const float* cnt, float* out, long n, idee_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

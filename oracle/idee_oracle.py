@@ -411,3 +411,42 @@ def vq_nearest(x, embed, training, commitment_weight=1.0):
         loss = loss + F.mse_loss(q, x) * commitment_weight
         q = x + (q - x).detach()
     return q, idx, loss
+
+
+# ----------------------------------------------------------------------------
+# training-driver bookkeeping (utils/utils_train.py) — SURVEY.md §8(f) rows 1-2
+# ----------------------------------------------------------------------------
+
+
+def confusion_counts(logits, gt, threshold, mask_valid=None):
+    """Counts of evaluator.__call__ (utils_train.py:247-267) / evaluator_synthetic.__call__ (:339-348) after the drivers'
+    thresholding (train_synthetic.py:209-212).  -> float64 (9,): [label*4 + (correct, seen, union, predicted)], [8] = pixels."""
+    pred = torch.sigmoid(logits)
+    pc = torch.where(pred > threshold, torch.ones_like(pred), torch.zeros_like(pred)).flatten()
+    g = gt.flatten().float()
+    if mask_valid is not None:
+        keep = mask_valid.flatten() > 0
+        pc, g = pc[keep], g[keep]
+    out = torch.zeros(9, dtype=torch.float64)
+    for l in (0, 1):
+        p, t = pc == l, g == l
+        out[4 * l + 0] = (p & t).sum(); out[4 * l + 1] = t.sum(); out[4 * l + 2] = (p | t).sum(); out[4 * l + 3] = p.sum()
+    out[8] = g.numel()
+    return out
+
+
+def anomaly_majority_vote(batches, timesteps, delta_t, shape):
+    """anomaly_collector (utils_train.py:529-554): batches = [(anomaly (n,V,dt,H,W), last time steps (n,))]."""
+    import numpy as np
+    acc, cnt = np.zeros(shape), np.zeros(shape)
+    for anomaly, ts in batches:
+        for n in range(len(ts)):
+            idx = int(np.argwhere(ts[n] == timesteps).item())
+            acc[:, idx - delta_t + 1: idx + 1] += np.flip(np.asarray(anomaly[n]), axis=1)
+            cnt[:, idx - delta_t + 1: idx + 1] += 1
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = acc / cnt
+    out = r.copy()
+    out[r >= 0.5] = 1
+    out[r < 0.5] = 0
+    return out, cnt

@@ -359,10 +359,84 @@ if __name__ == "__main__" and "--vq-only" in sys.argv:
     fx_vq("k8_train", 8, True, 820)
 
 
-if __name__ == "__main__" and "--config-only" not in sys.argv and "--vq-only" not in sys.argv:
+
+
+
+
+def fx_evaluators(seed=900):
+    """Confusion-count evaluators of the training drivers (utils/utils_train.py:175-348) on random batches.
+    utils_train imports timm.scheduler (absent): stubbed in memory, the schedulers are not used here."""
+    sched = types.ModuleType("timm.scheduler")
+    for n in ("step_lr", "cosine_lr"):
+        m = types.ModuleType("timm.scheduler." + n)
+        setattr(m, "StepLRScheduler" if n == "step_lr" else "CosineLRScheduler", object)
+        sys.modules["timm.scheduler." + n] = m
+    sys.modules["timm.scheduler"] = sched
+    import logging
+    from utils import utils_train as U
+    logger = logging.getLogger("fx")
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    ev = U.evaluator_synthetic(logger, "Training")
+    logits, gts = [], []
+    for _ in range(3):
+        lg = torch.randn((2, 1, 12, 16), generator=g) * 2
+        gt = (torch.rand((2, 1, 12, 16), generator=g) < 0.3).float()
+        pred = torch.sigmoid(lg)
+        pred_c = pred.clone()
+        pred_c[pred > 0.50] = 1
+        pred_c[pred <= 0.50] = 0                        # train_synthetic.py:209-212
+        ev(pred_c.numpy(), gt.numpy())
+        logits.append(lg); gts.append(gt)
+    ev.get_results(0.0, 0.0)
+    out.update({"syn/logits": torch.stack(logits), "syn/gt": torch.stack(gts),
+                "syn/counts": np.array([ev.correct[0], ev.seen[0], ev.iou_de[0], ev.predicted[0], ev.seen_all], dtype=np.float64),
+                "syn/metrics": np.array([ev.precision[0], ev.accuracy[0], ev.F1[0], ev.iou[0]], dtype=np.float64)})
+    # real-data evaluator: two classes, valid mask, threshold 0.35 (train_ERA5_Land.py:205-211)
+    cfg = ref_cfg()
+    er = U.evaluator(logger, "Training", cfg)
+    logits, gts, mvs = [], [], []
+    for _ in range(3):
+        lg = torch.randn((2, 12, 16), generator=g) * 2
+        gt = (torch.rand((2, 12, 16), generator=g) < 0.3).float()
+        mv = (torch.rand((2, 12, 16), generator=g) < 0.8).float()
+        pred = torch.sigmoid(lg)
+        pred_c = pred.clone()
+        pred_c[pred > 0.35] = 1
+        pred_c[pred <= 0.35] = 0
+        er(pred_c.numpy(), gt.numpy(), mv.numpy())
+        logits.append(lg); gts.append(gt); mvs.append(mv)
+    er.get_results(0.0, 0.0)
+    out.update({"real/logits": torch.stack(logits), "real/gt": torch.stack(gts), "real/mask": torch.stack(mvs),
+                "real/correct": np.array(er.correct_label_all, dtype=np.float64), "real/seen": np.array(er.seen_label_all, dtype=np.float64),
+                "real/iou_de": np.array(er.iou_de_label_all, dtype=np.float64), "real/predicted": np.array(er.predicted_label_all, dtype=np.float64),
+                "real/F1": np.array(er.F1, dtype=np.float64), "real/iou": np.array(er.iou, dtype=np.float64),
+                "real/accuracy_all": np.array(er.accuracy_all, dtype=np.float64)})
+    # majority-vote anomaly collector (utils_train.py:529-554)
+    V, TT, H, W, dt = 3, 20, 4, 5, 8
+    cfg.delta_t = dt
+    timesteps = np.arange(100, 100 + TT)
+    col = U.anomaly_collector(np.zeros((V, TT, H, W)), timesteps, cfg)
+    batches = []
+    for n in range(6):
+        an = (torch.rand((2, V, dt, H, W), generator=g) < 0.4).float().numpy()
+        ts = np.array([timesteps[dt - 1 + 2 * n], timesteps[dt + 2 * n]])
+        col(an, ts)
+        batches.append((an, ts))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        col.majority_vote()
+    out.update({"col/anomaly_batches": np.stack([b[0] for b in batches]), "col/timestep_batches": np.stack([b[1] for b in batches]),
+                "col/timesteps": timesteps, "col/result": col.anomaly, "col/counter": col.anomaly_counter})
+    save("evaluators", **out)
+
+
+if __name__ == "__main__" and "--eval-only" in sys.argv:
+    fx_evaluators()
+
+
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only")):
     main()
     fx_vq("k2_train", 2, True, 800)
     fx_vq("k2_eval", 2, False, 810)
     fx_vq("k8_train", 8, True, 820)
-
-
+    fx_evaluators()

@@ -529,3 +529,43 @@ def test_classifier_T16_shapes_and_T4_error():
     close("y", torch.stack(y), torch.stack(yo))
     with pytest.raises(RuntimeError):
         c(torch.randn(1, 2, 16, 4, 6, 10, device=DEV))
+
+
+def test_harness_evaluators_collector_checkpoint(tmp_path):
+    """Device-side confusion counts / majority vote vs the reference's numpy evaluators (golden), and the checkpoint dict."""
+    import numpy as np
+    from idee_amd import harness
+    a, _, _ = load_golden("evaluators")
+    ev = harness.ConfusionEvaluator(0.5, DEV)
+    for i in range(3):
+        ev.update(dev(a["syn/logits"][i]), dev(a["syn/gt"][i]))
+    r = ev.results()
+    assert [r[1]["correct"], r[1]["seen"], r[1]["iou_de"], r[1]["predicted"], r["seen_all"]] == a["syn/counts"].tolist()
+    np.testing.assert_allclose([r[1]["precision"], r[1]["accuracy"], r[1]["F1"], r[1]["iou"]], a["syn/metrics"].numpy(), rtol=1e-12)
+    er = harness.ConfusionEvaluator(0.35, DEV)
+    for i in range(3):
+        er.update(dev(a["real/logits"][i]), dev(a["real/gt"][i]), dev(a["real/mask"][i]))
+    r = er.results()
+    for l in (0, 1):
+        assert [r[l]["correct"], r[l]["seen"], r[l]["iou_de"], r[l]["predicted"]] == [float(a[k][l]) for k in ("real/correct", "real/seen", "real/iou_de", "real/predicted")]
+    np.testing.assert_allclose([r[0]["F1"], r[1]["F1"]], a["real/F1"].numpy(), rtol=1e-12)
+    np.testing.assert_allclose(r["accuracy_all"], float(a["real/accuracy_all"]), rtol=1e-12)
+    col = harness.AnomalyCollector(3, a["col/timesteps"].tolist(), 4, 5, 8, DEV)
+    for i in range(6):
+        col.update(dev(a["col/anomaly_batches"][i]).long(), a["col/timestep_batches"][i].tolist())
+    out = col.majority_vote().cpu().numpy()
+    assert np.array_equal(col.cnt.cpu().numpy(), a["col/counter"].numpy())
+    assert np.array_equal(np.nan_to_num(out, nan=-1), np.nan_to_num(a["col/result"].numpy(), nan=-1))
+    # checkpoint: reference dict keys and parameter keys
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    from idee_amd import optim
+    cfg = default_config(encoder="Swin_3D", in_channels=1, in_channels_dynamic=2, dir_log=str(tmp_path), name="t")
+    m = VQ_model(cfg).to(DEV)
+    opt = optim.Adam(m.parameters(), lr=1e-3)
+    path = harness.save_model(m, opt, 3, 1.5, 2.5, cfg, "loss")
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "mean_loss_train", "mean_loss_validation", "model_state_dict", "optimizer_state_dict"}
+    assert path.endswith("model_checkpoints/best_loss_model.pth")
+    m2 = VQ_model(cfg)
+    m2.load_state_dict({k.replace("module.", ""): v for k, v in ck["model_state_dict"].items()}, strict=True)

@@ -84,3 +84,20 @@ def test_window_clamp_matches_oracle():
     for ext in [(8, 200, 200), (8, 3, 5), (16, 4, 6), (1, 1, 1)]:
         for w, s in [((2, 4, 4), (1, 2, 2)), ((8, 1, 1), (4, 0, 0))]:
             assert clamp_window(ext, w, s) == O.get_window_size(ext, w, s)
+
+
+def test_cosine_lr_schedule_known_answers():
+    """timm CosineLRScheduler semantics at the reference's settings (config.py:121-126, utils_train.py:156-167):
+    closed-form values (parity unpinned: timm is absent)."""
+    import math
+    from idee_amd.harness import CosineLRScheduler
+
+    class Opt:
+        param_groups = [dict(lr=1e-3)]
+    o = Opt()
+    s = CosineLRScheduler(o, t_initial=100, lr_min=1e-5, warmup_t=2, warmup_lr_init=1e-6)
+    assert o.param_groups[0]["lr"] == 1e-6                      # set at construction
+    s.step_update(1); assert abs(o.param_groups[0]["lr"] - (1e-6 + (1e-3 - 1e-6) / 2)) < 1e-15
+    s.step_update(2); assert abs(o.param_groups[0]["lr"] - (1e-5 + 0.5 * (1e-3 - 1e-5) * (1 + math.cos(math.pi * 2 / 100)))) < 1e-15
+    s.step_update(50); assert abs(o.param_groups[0]["lr"] - (1e-5 + 0.5 * (1e-3 - 1e-5))) < 1e-12
+    s.step_update(100); assert o.param_groups[0]["lr"] == 1e-5   # past the single cycle

@@ -205,3 +205,17 @@ def test_vq_nearest(tag):
         ((zq * a["r"]).sum() + 1.7 * loss.sum()).backward()
         close(x.grad, a["dx"], 1e-6, 1e-3)
         close(emb.grad, grads["_codebook.embed"][0], 1e-6, 1e-3)
+
+
+def test_evaluators_and_collector():
+    import numpy as np
+    a, _, _ = load_golden("evaluators")
+    tot = sum(O.confusion_counts(a["syn/logits"][i], a["syn/gt"][i], 0.5) for i in range(3))
+    assert tot[4:8].tolist() == a["syn/counts"][:4].tolist() and tot[8] == a["syn/counts"][4]
+    tot = sum(O.confusion_counts(a["real/logits"][i], a["real/gt"][i], 0.35, a["real/mask"][i]) for i in range(3))
+    for l in (0, 1):
+        assert tot[4 * l:4 * l + 4].tolist() == [a["real/correct"][l], a["real/seen"][l], a["real/iou_de"][l], a["real/predicted"][l]]
+    batches = [(a["col/anomaly_batches"][i].numpy(), a["col/timestep_batches"][i].numpy()) for i in range(6)]
+    out, cnt = O.anomaly_majority_vote(batches, a["col/timesteps"].numpy(), 8, tuple(a["col/result"].shape))
+    assert np.array_equal(cnt, a["col/counter"].numpy())
+    assert np.array_equal(np.nan_to_num(out, nan=-1), np.nan_to_num(a["col/result"].numpy(), nan=-1))
