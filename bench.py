@@ -65,13 +65,16 @@ def swin_flops(geom, backward):
     return 2 * f if backward else f
 
 
+_HEADLINE = False   # set in main(): the PMC summary was taken at the headline workload only
+
+
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes of this same command, corrected as MI355X_MICROARCH.md prescribes; see
     profiles/collect_pmc.py) — or None when the summary has no unambiguous row for this entry point (e.g. the joint
     head's two convolutions share one kernel name but have different shapes)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    if not _HEADLINE or not os.path.exists(path):
         return None
     try:
         rows = {r["kernel"]: r["hbm_bytes_per_launch"] for r in json.load(open(path))["kernels"]}
@@ -149,6 +152,8 @@ def main():
     _lib.check(_lib.load().idee_check_device(local), "idee_check_device")
     cfg = default_config(encoder=a.encoder, in_channels=1)
     T, H, W = 8, a.hw, a.hw
+    global _HEADLINE
+    _HEADLINE = (a.hw == 200 and a.batch == 4 and a.encoder == "Swin_3D")
     torch.manual_seed(0)
     ts = SyntheticTrainStep(cfg, device=dev)
     x, me, ml = synthetic_batch(cfg, a.batch, T, H, W, rank, dev)

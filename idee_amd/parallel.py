@@ -26,9 +26,14 @@ def init_from_env(backend=None):
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # rehearsal knobs (one-GPU boxes): IDEE_DIST_BACKEND=gloo runs the same collectives through gloo on device tensors,
+    # IDEE_FORCE_DEVICE=0 puts every rank on one device (RCCL itself refuses two ranks per device)
+    backend = os.environ.get("IDEE_DIST_BACKEND", backend)
+    if "IDEE_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["IDEE_FORCE_DEVICE"])
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
