@@ -449,22 +449,28 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // 16 -> 16 3x3x3 replicate convolution, forward and data gradient, activations staged through LDS.
-// A workgroup (4 waves) walks a run of output rows of one row segment (<= 7 column blocks of 16 pixels) for a
-// fixed (batch item, t).  LDS holds, for each of the 3 T-slots, a ring of 3 source rows with a one-pixel halo
-// (replicate clamp resp. zero padding resolved while staging): moving down one row stages 3 new rows.  The 27
-// weight fragments live in registers; a wave owns up to 2 column blocks, one 16-byte LDS read per block and tap.
-// 65.7 KB of LDS -> two workgroups per CU: one stages while the other multiplies.
+// Every WAVE works alone: it owns a strip of 2 column blocks (32 pixels) and walks a run of output rows for a
+// fixed (batch item, t), keeping in its private 19.6 KB of LDS, for each of the 3 T-slots, a ring of 3 source
+// rows with a one-pixel halo (replicate clamp resp. zero padding resolved while staging).  Moving down one row
+// stages 3 new rows.  The 27 weight fragments live in registers.  No workgroup barrier anywhere: the waves of a
+// CU drift apart, so one wave's staging latency hides under another's MFMA chain.
 // ---------------------------------------------------------------------------------------------
-constexpr int kC16Sub = 7;                       // column blocks per segment
-constexpr int kC16Row = kC16Sub * 16 + 2;        // staged pixels per source row
+constexpr int kC16Row = 2 * 16 + 2;             // staged pixels per source row of a strip
+
+__device__ __forceinline__ void wave_fence() {   // LDS hand-off inside one wave: DS ops of a wave execute in order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <int MODE /*FWD_REP or DGRAD_REP*/>
-__global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nseg, int hrun, int nhrun) {
+__global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
   constexpr int MT = 2;
-  __shared__ __attribute__((aligned(16))) float s_x[9 * kC16Row * 16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) float s_xw[4][9 * kC16Row * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
+  float* s_x = s_xw[wave];
   f32x4 wr[27];
   {
     const float* wp = a.wp + (long)wset * 27 * 256;
@@ -473,29 +479,28 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nseg
   }
   const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
   const int nsub = (Wframe + 15) / 16;
-  const int sub_base = nsub / nseg, sub_rem = nsub % nseg;
   const int nb = a.B / a.wsets;
-  const long nchunks = (long)nb * a.To * nhrun * nseg;
+  const long nunits = (long)nb * a.To * nhrun * nstrip;
 
-  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    long r = ch;
-    const int sg = (int)(r % nseg); r /= nseg;
+  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+    long r = un;
+    const int sp = (int)(r % nstrip); r /= nstrip;
     const int hr = (int)(r % nhrun); r /= nhrun;
     const int t = (int)(r % a.To);
     const int b = (int)(r / a.To) * a.wsets + wset;
-    const int my_sub = sub_base + (sg < sub_rem ? 1 : 0);              // column blocks of this segment
-    const int p0 = 16 * (sg * sub_base + min(sg, sub_rem));            // first frame column of the segment
+    const int my_sub = min(MT, nsub - sp * MT);                        // column blocks of this strip (1 or 2)
+    const int p0 = sp * MT * 16;                                       // first frame column of the strip
     const int rowlen = my_sub * 16 + 2;
-    // source column of staged pixel i:  fwd: clamp(p0 + i - 1) ; dgrad: p0 + i - 2 (zero outside)
     const int h0 = hr * hrun, h1 = min(a.Ho, h0 + hrun);
     int res0 = -1, res1 = -1, res2 = -1;
     const float* in_b = a.in + (long)b * a.i_sB;
     Slot st[3];
 #pragma unroll
     for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti);
+    const int blk1 = my_sub > 1 ? 16 : 0;                              // a lone block re-reads block 0 (result unused)
 
     for (int h = h0; h < h1; ++h) {
-      __syncthreads();   // previous row's readers are done
+      wave_fence();   // previous row's reads are ordered before this row's staging writes
       Slot sh[3];
       int slot_of[3];
 #pragma unroll
@@ -507,84 +512,95 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nseg
         const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
         if (cur == hs) continue;
         if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
+        // all 9 loads of the 3 T-slots first (up to 3 x 16 bytes per lane and slot), then the LDS writes: a
+        // load -> wait -> write loop would serialise 9 L2 round trips per row
+        f32x4 stg[3][3];
 #pragma unroll
         for (int ot = 0; ot < 3; ++ot) {
           const float* src = in_b + (long)st[ot].src * a.i_sT + (long)hs * a.i_sH;
-          float* dst = s_x + (long)(ot * 3 + slot) * kC16Row * 16;
-          for (int u = tid; u < rowlen * 4; u += 256) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
             const int px = u >> 2, q4 = u & 3;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == FWD_REP) {
-              const int w = min(max(p0 + px - 1, 0), a.Wi - 1);
-              v = ld4(src + (long)w * a.i_sW + 4 * q4);
-            } else {
-              const int w = p0 + px - 2;
-              if (w >= 0 && w < a.Wi) v = ld4(src + (long)w * a.i_sW + 4 * q4);
+            if (u < rowlen * 4) {
+              if (MODE == FWD_REP) {
+                const int w = min(max(p0 + px - 1, 0), a.Wi - 1);
+                v = ld4(src + (long)w * a.i_sW + 4 * q4);
+              } else {
+                const int w = p0 + px - 2;
+                if (w >= 0 && w < a.Wi) v = ld4(src + (long)w * a.i_sW + 4 * q4);
+              }
             }
-            st4(dst + px * 16 + 4 * q4, v);
+            stg[ot][k] = v;
+          }
+        }
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) {
+          float* dst = s_x + (long)(ot * 3 + slot) * kC16Row * 16;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            if (u < rowlen * 4) st4(dst + (u >> 2) * 16 + 4 * (u & 3), stg[ot][k]);
           }
         }
       }
-      __syncthreads();
+      wave_fence();
 
       f32x4 acc[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int sub0 = wave * MT;                                      // this wave's first column block
-      const int blk1 = (sub0 + 1 < my_sub) ? 16 : 0;                   // a lone last block re-reads block 0 (result unused)
-      if (sub0 < my_sub) {
 #pragma unroll
-        for (int ot = 0; ot < 3; ++ot) {
+      for (int ot = 0; ot < 3; ++ot) {
 #pragma unroll
-          for (int oh = 0; oh < 3; ++oh) {
-            const float* rowp = s_x + ((long)(ot * 3 + slot_of[oh]) * kC16Row + sub0 * 16 + j) * 16 + 4 * kq;
-            const int sel = st[ot].tap * 3 + sh[oh].tap;               // weight row (tile-uniform; differs from ot*3+oh only at edges of the dgrad)
+        for (int oh = 0; oh < 3; ++oh) {
+          const float* rowp = s_x + ((long)(ot * 3 + slot_of[oh]) * kC16Row + j) * 16 + 4 * kq;
+          const int sel = st[ot].tap * 3 + sh[oh].tap;               // weight row (uniform; differs from ot*3+oh only at edges of the dgrad)
 #pragma unroll
-            for (int gs = 0; gs < 9; ++gs) {
-              if (MODE == FWD_REP ? (gs != ot * 3 + oh) : (gs != sel)) continue;
+          for (int gs = 0; gs < 9; ++gs) {
+            if (MODE == FWD_REP ? (gs != ot * 3 + oh) : (gs != sel)) continue;
 #pragma unroll
-              for (int ow = 0; ow < 3; ++ow) {
-                // staged index of the source pixel: fwd p + ow ; dgrad p - ow + 2   (p = column inside the segment)
-                const int sh_px = (MODE == FWD_REP) ? ow : 2 - ow;
-                const f32x4 x0 = ld4(rowp + sh_px * 16);
-                const f32x4 x1 = ld4(rowp + (sh_px + blk1) * 16);
-                const f32x4 wf = wr[gs * 3 + ow];
+            for (int ow = 0; ow < 3; ++ow) {
+              // staged index of the source pixel: fwd p + ow ; dgrad p - ow + 2   (p = column inside the strip)
+              const int sh_px = (MODE == FWD_REP) ? ow : 2 - ow;
+              const f32x4 x0 = ld4(rowp + sh_px * 16);
+              const f32x4 x1 = ld4(rowp + (sh_px + blk1) * 16);
+              const f32x4 wf = wr[gs * 3 + ow];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                  acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], x0[s], acc[0], 0, 0, 0);
-                  acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], x1[s], acc[1], 0, 0, 0);
-                }
+              for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], x0[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], x1[s], acc[1], 0, 0, 0);
               }
             }
           }
         }
-        // epilogue
-        float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
-        const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
+      }
+      // epilogue
+      float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+      const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          if (sub0 + m >= my_sub) continue;
-          const int p = p0 + (sub0 + m) * 16 + j;
-          if (p >= Wframe) continue;
-          int wdst = p;
-          bool atomic = false;
-          if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
-          f32x4 v = acc[m];
-          if (a.bias) v += ld4(a.bias + (long)wset * 16 + 4 * kq);
-          if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-          const long o = (long)wdst * a.o_sW + 4 * kq;
-          if (ref_r) {
-            const f32x4 rr = ld4(ref_r + o);
-            v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
-            v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
-          }
-          if (atomic) {
-            atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
-            atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
-          } else {
-            if (a.accumulate) v += ld4(out_r + o);
-            st4(out_r + o, v);
-          }
+      for (int m = 0; m < MT; ++m) {
+        if (m >= my_sub) continue;
+        const int p = p0 + m * 16 + j;
+        if (p >= Wframe) continue;
+        int wdst = p;
+        bool atomic = false;
+        if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
+        f32x4 v = acc[m];
+        if (a.bias) v += ld4(a.bias + (long)wset * 16 + 4 * kq);
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const long o = (long)wdst * a.o_sW + 4 * kq;
+        if (ref_r) {
+          const f32x4 rr = ld4(ref_r + o);
+          v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+          v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+        }
+        if (atomic) {
+          atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
+          atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
+        } else {
+          if (a.accumulate) v += ld4(out_r + o);
+          st4(out_r + o, v);
         }
       }
     }
@@ -1173,16 +1189,15 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
     if (wlds && a.cout_real == 16) {
       const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
-      const int nsub = cdiv(Wframe, 16);
-      const int nseg = cdiv(nsub, kC16Sub);
+      const int nstrip = cdiv(cdiv(Wframe, 16), 2);
       const long bt = (long)(a.B / a.wsets) * a.To;
-      int hrun = a.Ho;
-      while (hrun > 8 && bt * cdiv(a.Ho, hrun) * nseg * a.wsets < 6L * kCUs) hrun = (hrun + 1) / 2;
+      int hrun = a.Ho;                                      // runs short enough for ~5 work units per resident wave
+      while (hrun > 8 && bt * cdiv(a.Ho, hrun) * nstrip * a.wsets < 5L * kCUs * 8) hrun = (hrun + 1) / 2;
       const int nhrun = cdiv(a.Ho, hrun);
-      const long nchunks = bt * nhrun * nseg;
+      const long nunits = bt * nhrun * nstrip;
       auto kern = conv16_lds_kernel<MODE>;
-      const dim3 grid(one_round(nchunks, a.wsets, wg_per_cu(kern, 256)), a.wsets);
-      hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nseg, hrun, nhrun);
+      const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
+      hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
       return IDEE_OK;
     }
   }
