@@ -653,7 +653,8 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, in
     for (int h = h0; h < h1; ++h) {
       __syncthreads();   // previous row's readers are done
       int slot_of[3];
-      bool ok_h[3];
+      bool ok_h[3], fresh[3];
+      int hsrc[3];
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) {
         int hs = h + oh - 1;
@@ -661,35 +662,45 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, in
         else ok_h[oh] = hs >= 0 && hs < a.H;
         const int slot = ((hs % 3) + 3) % 3;
         slot_of[oh] = slot;
+        hsrc[oh] = hs;
+        fresh[oh] = false;
         if (!ok_h[oh]) continue;
         const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
         if (cur == hs) continue;
         if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
-        // stage source row hs of every t-slot: pixels w0-1 .. w0+seg, 4 x 16-byte units each
+        fresh[oh] = true;
+      }
+      // phase 1: every global load of this row step (new source rows of all T-slots + the dy row) is issued before any
+      // LDS write — a load/wait/write loop would pay one L2 round trip per piece.  (rowlen * 4 <= 512 = one piece per thread)
+      f32x4 stg[3][TSL], stg_dy = {0.f, 0.f, 0.f, 0.f};
+      const int px_ = tid >> 2, q4_ = tid & 3;
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
 #pragma unroll
         for (int ts = 0; ts < TSL; ++ts) {
-          const int tsrc = MODE == FWD_REP ? min(max(t + ts - 1, 0), a.T - 1) : 2 * t + ts;
-          const float* src = x_b + (long)tsrc * a.x_sT + (long)hs * a.x_sH;
-          float* dst = s_x + (long)(ts * 3 + slot) * rowlen * 16;
-          for (int u = tid; u < rowlen * 4; u += 64 * WAVES) {
-            const int px = u >> 2, q4 = u & 3;
-            int w = w0 + px - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == FWD_REP) { w = min(max(w, 0), a.W - 1); v = ld4(src + (long)w * a.x_sW + 4 * q4); }
-            else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * q4);
-            st4(dst + px * 16 + 4 * q4, v);
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (fresh[oh] && tid < rowlen * 4) {
+            const int tsrc = MODE == FWD_REP ? min(max(t + ts - 1, 0), a.T - 1) : 2 * t + ts;
+            const float* src = x_b + (long)tsrc * a.x_sT + (long)hsrc[oh] * a.x_sH;
+            int w = w0 + px_ - 1;
+            if (MODE == FWD_REP) { w = min(max(w, 0), a.W - 1); v = ld4(src + (long)w * a.x_sW + 4 * q4_); }
+            else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * q4_);
           }
+          stg[oh][ts] = v;
         }
       }
-      {   // dy row (zeros past the end of the row so the tail k-steps contribute nothing)
-        const float* src = dy_b + (long)h * a.y_sH;
-        for (int u = tid; u < segp * 4; u += 64 * WAVES) {
-          const int px = u >> 2, q4 = u & 3;
-          const int w = w0 + px;
-          const bool in = px < seg && w < a.W;
-          st4(s_dy + px * 16 + 4 * q4, in ? ld4(src + (long)w * a.y_sW + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f});
-        }
+      if (tid < segp * 4) {
+        const int w = w0 + px_;
+        if (px_ < seg && w < a.W) stg_dy = ld4(dy_b + (long)h * a.y_sH + (long)w * a.y_sW + 4 * q4_);
       }
+      // phase 2: LDS writes
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        if (!fresh[oh] || tid >= rowlen * 4) continue;
+#pragma unroll
+        for (int ts = 0; ts < TSL; ++ts) st4(s_x + ((long)(ts * 3 + slot_of[oh]) * rowlen + px_) * 16 + 4 * q4_, stg[oh][ts]);
+      }
+      if (tid < segp * 4) st4(s_dy + px_ * 16 + 4 * q4_, stg_dy);
       __syncthreads();
 
       int base[TPWV];
