@@ -59,8 +59,12 @@ _SIGS = {
     "idee_ln_relu_res_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P]),
     "idee_ln_relu_res_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P]),
     "idee_lfq_workspace_floats": (_L, [_L, _I]),
-    "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P]),
-    "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _P]),
+    "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P]),
+    "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _P]),
+    "idee_lfq_sign_field_fwd": (_I, [_P, _P, _I, _I, _L, _I, _I, _P]),
+    "idee_lfq_sign_field_bwd": (_I, [_P, _P, _I, _I, _L, _I, _I, _P]),
+    "idee_lfq_fold_weights_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "idee_lfq_fold_weights_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "idee_vq_workspace_floats": (_L, [_L]),
     "idee_vq_nn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     "idee_vq_nn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),

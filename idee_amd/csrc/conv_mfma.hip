@@ -1214,7 +1214,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   }
   if constexpr (MODE == FWD_S2 || MODE == DGRAD_S2) {
     const long slab_bytes = (long)a.Gk * NT * 256 * 4;
-    if (!cin1 && gz == 1 && NT >= 2 && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
+    if (!cin1 && gz == 1 && (NT >= 2 || a.Gk >= 2) && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
       a.hgroups = cdiv(a.Ho, 8);
       a.tiles = a.To * a.hgroups * a.wtiles;
 #define LCW(NT_)                                                                                               \
@@ -1225,7 +1225,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
     const dim3 grid(one_round(a.tiles, a.B, 1), a.B);                                                          \
     hipLaunchKernelGGL(kern, grid, dim3(512), 2 * slab_bytes, stream, a);                                      \
   } while (0)
-      if (NT == 6) LCW(6); else if (NT == 3) LCW(3); else LCW(2);
+      if (NT == 6) LCW(6); else if (NT == 3) LCW(3); else if (NT == 2) LCW(2); else LCW(1);
 #undef LCW
       return IDEE_OK;
     }
@@ -1390,7 +1390,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
       hipLaunchKernelGGL(kern, dim3(one_round(nchunks, d->wsets, wg_per_cu(kern, 512)), d->wsets), dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
     }
   }
-  else if (!rep && Ga == Gb && (Ga == 6 || Ga == 3 || Ga == 2)) {
+  else if (!rep && (Ga == Gb || Ga == 1) && (Gb == 6 || Gb == 3 || Gb == 2) && d->Cout % 16 == 0) {
     // wide LDS-staged kernel: segment width from the LDS budget (ring of 3 x rows + dy row, padded pixel strides)
     const int PSX = d->Cin + ((48 - d->Cin % 32) % 32), PSY = a.CoutPad + ((48 - a.CoutPad % 32) % 32);
     const long budget = 150 * 1024 / 4;                                   // floats
@@ -1405,14 +1405,16 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const long nchunks = (long)(d->B / d->wsets) * a.To * nhrun * nseg;
     const size_t lds = (size_t)(3L * (seg + 2) * PSX + (long)((seg + 3) & ~3) * PSY) * 4;
     const dim3 grid(one_round(nchunks, 2L * d->wsets, 1), d->wsets, 2);
-#define LWW(G_)                                                                                                       \
+#define LWW(GA_, GB_, WAVES_)                                                                                         \
   do {                                                                                                                \
-    auto kern = wgrad_wide_lds_kernel<G_, G_, 8>;                                                                     \
+    auto kern = wgrad_wide_lds_kernel<GA_, GB_, WAVES_>;                                                              \
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
       return idee::fail(IDEE_ERR_LAUNCH, "conv_wgrad: cannot reserve %zu bytes of LDS", lds);                          \
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, seg, nseg, hrun, nhrun);                                    \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_), lds, st, a, seg, nseg, hrun, nhrun);                            \
   } while (0)
-    if (Ga == 6) LWW(6); else if (Ga == 3) LWW(3); else LWW(2);
+    // 16 input channels (the sign field): one tap per wave, 9 waves
+    if (Ga == 1) { if (Gb == 6) LWW(1, 6, 9); else if (Gb == 3) LWW(1, 3, 9); else LWW(1, 2, 9); }
+    else if (Ga == 6) LWW(6, 6, 8); else if (Ga == 3) LWW(3, 3, 8); else LWW(2, 2, 8);
 #undef LWW
   }
   else if (Ga == 1 && Gb == 1) { if (rep) LW(FWD_REP, 27, 1, 1); else LW(FWD_S2, 18, 1, 1); }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void lfq_fwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ b_in, const float* __restrict__ w_out,
                                                       const float* __restrict__ b_out, float* __restrict__ zq,
                                                       long long* __restrict__ indices, float* __restrict__ partials,
-                                                      long M, int training) {
+                                                      float* __restrict__ qs, long M, int training) {
   constexpr int K = 1 << D, R = 2 + K, QE = E / 4;
   __shared__ float smem[R * 4];
   float acc[R];
@@ -201,6 +201,9 @@ __global__ __launch_bounds__(256) void lfq_fwd_kernel(const float* __restrict__ 
     st4(zq + tok * E + 4 * q, o);
     if (q == 0) {
       indices[tok] = idx;
+      if (qs)
+#pragma unroll
+        for (int i = 0; i < D; ++i) qs[tok * D + i] = qv[i];
       if (training) {
         float p[K];
         lfq_probs<D>(s, p);
@@ -253,10 +256,11 @@ template <int E, int D>
 __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dzq,
                                                       const float* __restrict__ w_in, const float* __restrict__ b_in,
                                                       const float* __restrict__ w_out, const float* __restrict__ stats,
-                                                      const float* __restrict__ gscal, float* __restrict__ dz,
-                                                      float* __restrict__ dw_in, float* __restrict__ db_in,
-                                                      float* __restrict__ dw_out, float* __restrict__ db_out, long M,
-                                                      float w_ent, float gamma, float w_commit) {
+                                                      const float* __restrict__ gscal, const float* __restrict__ dqs,
+                                                      float* __restrict__ dz, float* __restrict__ dw_in,
+                                                      float* __restrict__ db_in, float* __restrict__ dw_out,
+                                                      float* __restrict__ db_out, long M, float w_ent, float gamma,
+                                                      float w_commit) {
   constexpr int K = 1 << D, QE = E / 4;
   const float g = gscal[0];
   const float invM = 1.f / (float)M;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
       s[i] = a; qv[i] = a > 0.f ? 1.f : -1.f;
       // straight-through: d x_ste = W_out^T dz_q
       const float d = tok_sum<QE>(go[0] * wo[i][0] + go[1] * wo[i][1] + go[2] * wo[i][2] + go[3] * wo[i][3]);
-      ds[i] = d + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
+      ds[i] = d + (dqs ? dqs[tok * D + i] : 0.f) + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
     }
     float p[K];
     lfq_probs<D>(s, p);
@@ -729,6 +733,112 @@ __global__ __launch_bounds__(256) void anomaly_vote_finalize_kernel(const float*
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// Rank-d classifier input (disclosed in DESIGN.md): LFQ's output is z_q = b_out + sum_i q_i w_out[:, i]
+// with q in {-1,+1}^D per token, so the classifier's first convolutions on the V*C channels of z_q equal convolutions
+// on the "sign field" S (N,T,H,W,CS): channel v*D+i = q_i of variable v, channel V*D = 1 (its zero padding reproduces
+// the border behaviour of the zero-padded z_q exactly), remaining channels 0 — with folded weights
+//   W_eff[co][v*D+i][tap] = sum_c W[co][v*C+c][tap] w_out[c][i] ,  W_eff[co][V*D][tap] = sum_{v,c} W[co][v*C+c][tap] b_out[c].
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __restrict__ qs, float* __restrict__ sx, int N, int V,
+                                                             long THW, int D, int CS) {
+  const long npix = (long)N * THW;
+  const int Q = CS / 4;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < npix * Q; u += (long)gridDim.x * 256) {
+    const long pix = u / Q; const int q = (int)(u % Q);
+    const long n = pix / THW, p = pix % THW;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ch = 4 * q + k;
+      float val = 0.f;
+      if (ch < V * D) val = qs[((n * V + ch / D) * THW + p) * D + ch % D];
+      else if (ch == V * D) val = 1.f;
+      o[k] = val;
+    }
+    st4(sx + pix * CS + 4 * q, o);
+  }
+}
+__global__ __launch_bounds__(256) void sign_field_bwd_kernel(const float* __restrict__ dsx, float* __restrict__ dqs, int N, int V,
+                                                             long THW, int D, int CS) {
+  const long total = (long)N * V * THW * D;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i = (int)(e % D); long r = e / D;
+    const long p = r % THW; r /= THW;
+    const int v = (int)(r % V); const long n = r / V;
+    dqs[e] = dsx[(n * THW + p) * CS + v * D + i];
+  }
+}
+// w (Co, G*C, taps) [G = V for the joint head (G*C input channels), per-variable heads: see `per_var`], p = [w_out | b_out]
+// weff (Co_total, CS, taps).  per_var: w is (V, Co, C, taps) and output row v*Co + co only sees variable v.
+__global__ void fold_fwd_kernel(const float* __restrict__ w, const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                float* __restrict__ weff, int Co, int V, int C, int D, int CS, int taps, int per_var) {
+  const int rows = per_var ? V * Co : Co;
+  const long total = (long)rows * CS * taps;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(e % taps); long r = e / taps;
+    const int ch = (int)(r % CS); const int row = (int)(r / CS);
+    float acc = 0.f;
+    if (ch <= V * D) {
+      const int vr = per_var ? row / Co : -1;            // the only variable this output row reads (heads)
+      for (int v = 0; v < V; ++v) {
+        if (ch < V * D && v != ch / D) continue;
+        if (per_var && v != vr) continue;
+        const float* wrow = per_var ? w + (((long)row) * C) * taps : w + (((long)row) * V * C + (long)v * C) * taps;
+        for (int c = 0; c < C; ++c) {
+          const float wc = wrow[(long)c * taps + tap];
+          acc = fmaf(wc, ch < V * D ? w_out[c * D + ch % D] : b_out[c], acc);
+        }
+      }
+    }
+    weff[e] = acc;
+  }
+}
+// dw[row][(v) c][tap] = sum_i dweff[row][v*D+i][tap] w_out[c][i] + dweff[row][V*D][tap] b_out[c]
+__global__ void fold_bwd_w_kernel(const float* __restrict__ dweff, const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                  float* __restrict__ dw, int Co, int V, int C, int D, int CS, int taps, int per_var) {
+  const int rows = per_var ? V * Co : Co;
+  const int G = per_var ? 1 : V;
+  const long total = (long)rows * G * C * taps;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(e % taps); long r = e / taps;
+    const int c = (int)(r % C); r /= C;
+    const int g = (int)(r % G); const int row = (int)(r / G);
+    const int v = per_var ? row / Co : g;
+    const float* dwe = dweff + ((long)row * CS) * taps + tap;
+    float acc = dwe[(long)(V * D) * taps] * b_out[c];
+#pragma unroll 4
+    for (int i = 0; i < D; ++i) acc = fmaf(dwe[(long)(v * D + i) * taps], w_out[c * D + i], acc);
+    dw[e] = acc;
+  }
+}
+// dw_out[c][i] += sum_{row, v, tap} w[row][(v) c][tap] dweff[row][v*D+i][tap] ; db_out[c] += sum w[..] dweff[row][V*D][tap]
+__global__ void fold_bwd_p_kernel(const float* __restrict__ dweff, const float* __restrict__ w, float* __restrict__ dw_out,
+                                  float* __restrict__ db_out, int Co, int V, int C, int D, int CS, int taps, int per_var) {
+  // one block per (c, i) with i == D meaning b_out
+  const int c = blockIdx.x / (D + 1), i = blockIdx.x % (D + 1);
+  const int rows = per_var ? V * Co : Co;
+  const int G = per_var ? 1 : V;
+  float acc = 0.f;
+  const long total = (long)rows * G * taps;
+  for (long e = threadIdx.x; e < total; e += blockDim.x) {
+    const int tap = (int)(e % taps); long r = e / taps;
+    const int g = (int)(r % G); const int row = (int)(r / G);
+    const int v = per_var ? row / Co : g;
+    const float wv = w[(((long)row * G + g) * C + c) * taps + tap];
+    const int ch = i < D ? v * D + i : V * D;
+    acc = fmaf(wv, dweff[((long)row * CS + ch) * taps + tap], acc);
+  }
+  __shared__ float sm[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = sm[0] + sm[1] + sm[2] + sm[3];
+    if (i < D) atomicAdd(dw_out + c * D + i, t); else atomicAdd(db_out + c, t);
+  }
+}
+
 int stream_grid(long items) { return imin(cdiv(items, 256), kCUs * 8); }
 
 }  // namespace
@@ -773,8 +883,9 @@ extern "C" long idee_lfq_workspace_floats(long M, int codebook_size) {
 static int log2i(int k) { int d = 0; while ((1 << d) < k) ++d; return d; }
 
 extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
-                            float* zq, int64_t* indices, float* stats, float* workspace, long M, int E, int codebook_size,
-                            int training, float w_entropy, float gamma, float w_commit, idee_stream_t stream) {
+                            float* zq, int64_t* indices, float* stats, float* workspace, float* signs, long M, int E,
+                            int codebook_size, int training, float w_entropy, float gamma, float w_commit,
+                            idee_stream_t stream) {
   IDEE_CHECK_ARG(z && w_in && b_in && w_out && b_out && zq && indices && M > 0, "lfq_fwd: bad argument");
   IDEE_CHECK_ARG(!training || (stats && workspace), "lfq_fwd: training needs stats and workspace");
   const int D = log2i(codebook_size);
@@ -783,7 +894,7 @@ extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in
   hipStream_t st = (hipStream_t)stream;
 #define CALL(E_, D_)                                                                                           \
   hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, st, z, w_in, b_in, w_out, b_out, zq,     \
-                     (long long*)indices, workspace, M, training);                                             \
+                     (long long*)indices, workspace, signs, M, training);                                      \
   if (training) hipLaunchKernelGGL((lfq_finalize_kernel<D_>), dim3(1), dim3(64), 0, st, workspace, nb, stats, M, \
                                    w_entropy, gamma, w_commit)
   LFQ_DISPATCH(CALL)
@@ -793,9 +904,9 @@ extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in
 }
 
 extern "C" int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const float* b_in, const float* w_out,
-                            const float* stats, const float* gloss, float* dz, float* dw_in, float* db_in, float* dw_out,
-                            float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma, float w_commit,
-                            idee_stream_t stream) {
+                            const float* stats, const float* gloss, const float* dsigns, float* dz, float* dw_in, float* db_in,
+                            float* dw_out, float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma,
+                            float w_commit, idee_stream_t stream) {
   IDEE_CHECK_ARG(z && dzq && w_in && b_in && w_out && stats && gloss && dz && dw_in && db_in && dw_out && db_out && M > 0,
                  "lfq_bwd: bad argument");
   const int D = log2i(codebook_size);
@@ -803,7 +914,7 @@ extern "C" int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in,
   const int nb = imin(cdiv(M * 4, 256), kCUs * 8);
 #define CALL(E_, D_)                                                                                               \
   hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in, w_out, \
-                     stats, gloss, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
+                     stats, gloss, dsigns, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
   LFQ_DISPATCH(CALL)
 #undef CALL
   IDEE_LAUNCH_CHECK("lfq_bwd");
@@ -957,5 +1068,37 @@ extern "C" int idee_anomaly_vote_finalize(const float* acc, const float* cnt, fl
   IDEE_CHECK_ARG(acc && cnt && out && n > 0, "anomaly_vote_finalize: bad argument");
   hipLaunchKernelGGL(anomaly_vote_finalize_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, acc, cnt, out, n);
   IDEE_LAUNCH_CHECK("anomaly_vote_finalize");
+  return IDEE_OK;
+}
+
+extern "C" int idee_lfq_sign_field_fwd(const float* signs, float* sx, int N, int V, long THW, int D, int CS, idee_stream_t stream) {
+  IDEE_CHECK_ARG(signs && sx && N > 0 && V > 0 && THW > 0 && D > 0 && CS % 16 == 0 && V * D + 1 <= CS, "lfq_sign_field_fwd: bad argument");
+  hipLaunchKernelGGL(sign_field_fwd_kernel, dim3(stream_grid((long)N * THW * (CS / 4))), dim3(256), 0, (hipStream_t)stream, signs, sx, N, V, THW, D, CS);
+  IDEE_LAUNCH_CHECK("lfq_sign_field_fwd");
+  return IDEE_OK;
+}
+extern "C" int idee_lfq_sign_field_bwd(const float* dsx, float* dsigns, int N, int V, long THW, int D, int CS, idee_stream_t stream) {
+  IDEE_CHECK_ARG(dsx && dsigns && N > 0 && V > 0 && THW > 0 && D > 0 && CS % 16 == 0 && V * D + 1 <= CS, "lfq_sign_field_bwd: bad argument");
+  hipLaunchKernelGGL(sign_field_bwd_kernel, dim3(stream_grid((long)N * V * THW * D)), dim3(256), 0, (hipStream_t)stream, dsx, dsigns, N, V, THW, D, CS);
+  IDEE_LAUNCH_CHECK("lfq_sign_field_bwd");
+  return IDEE_OK;
+}
+extern "C" int idee_lfq_fold_weights_fwd(const float* w, const float* w_out, const float* b_out, float* weff, int Co, int V, int C,
+                                         int D, int CS, int taps, int per_var, idee_stream_t stream) {
+  IDEE_CHECK_ARG(w && w_out && b_out && weff && Co > 0 && V > 0 && C > 0 && D > 0 && V * D + 1 <= CS && taps > 0, "lfq_fold_weights_fwd: bad argument");
+  const long total = (long)(per_var ? V * Co : Co) * CS * taps;
+  hipLaunchKernelGGL(fold_fwd_kernel, dim3(imin(cdiv(total, 256), 1024)), dim3(256), 0, (hipStream_t)stream, w, w_out, b_out, weff, Co, V, C, D, CS, taps, per_var);
+  IDEE_LAUNCH_CHECK("lfq_fold_weights_fwd");
+  return IDEE_OK;
+}
+extern "C" int idee_lfq_fold_weights_bwd(const float* dweff, const float* w, const float* w_out, const float* b_out, float* dw,
+                                         float* dw_out, float* db_out, int Co, int V, int C, int D, int CS, int taps, int per_var,
+                                         idee_stream_t stream) {
+  IDEE_CHECK_ARG(dweff && w && w_out && b_out && dw && dw_out && db_out && Co > 0 && V > 0 && C > 0 && D > 0 && V * D + 1 <= CS && taps > 0,
+                 "lfq_fold_weights_bwd: bad argument");
+  const long total = (long)(per_var ? V * Co : Co) * (per_var ? 1 : V) * C * taps;
+  hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(imin(cdiv(total, 256), 1024)), dim3(256), 0, (hipStream_t)stream, dweff, w_out, b_out, dw, Co, V, C, D, CS, taps, per_var);
+  hipLaunchKernelGGL(fold_bwd_p_kernel, dim3(C * (D + 1)), dim3(256), 0, (hipStream_t)stream, dweff, w, dw_out, db_out, Co, V, C, D, CS, taps, per_var);
+  IDEE_LAUNCH_CHECK("lfq_fold_weights_bwd");
   return IDEE_OK;
 }

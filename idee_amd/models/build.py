@@ -8,6 +8,7 @@ returned `z_q` is the permuted VIEW (N,V,C,T,H,W) the reference also returns."""
 from __future__ import annotations
 
 import importlib
+import os
 
 import torch
 import torch.nn as nn
@@ -48,6 +49,8 @@ class VQ_model(nn.Module):
                                                   diversity_gamma=config.diversity_gamma,
                                                   commitment_loss_weight=config.lambda_commitment)
         self.pretrained = config.en_de_pretrained
+        # IDEE_SIGN_FIELD=0 runs the classifier on z_q itself, convolution for convolution as build.py:157
+        self.sign_field_classifier = os.environ.get("IDEE_SIGN_FIELD", "1") != "0"
         self._init_weights()
 
     def _init_weights(self, init_type='normal', gain=.02):
@@ -80,6 +83,12 @@ class VQ_model(nn.Module):
         """x_d (N,V,C,T,H,W) -> z (N,1,H,W), y [V x (N,1,H,W)], anomaly int64 (N,V,T,H,W),
         z_q (N,V,C,T,H,W), loss_z_q (1,)   — build.py:130-159."""
         z = self.encoder.forward_tokens(x_d)                 # (N,V,T,H,W,E)
-        z_q, anomaly, loss_z_q = self.vq.quantize_tokens(z)
-        zc, y = self.cls.forward_tokens(z_q)
+        if self.sign_field_classifier and self.cls.dim // self.cls.in_var % 16 == 0:
+            # z_q has rank codebook_dim per variable: the classifier's first convolutions read the +-1 code bits
+            # with weights folded through project_out (exact refactoring, DESIGN.md "rank-d classifier input")
+            z_q, anomaly, loss_z_q, signs = self.vq.quantize_tokens_signs(z)
+            zc, y = self.cls.forward_signs(signs, self.vq.project_out)
+        else:
+            z_q, anomaly, loss_z_q = self.vq.quantize_tokens(z)
+            zc, y = self.cls.forward_tokens(z_q)
         return zc, y, anomaly, z_q.permute(0, 1, 5, 2, 3, 4), loss_z_q.unsqueeze(0)

@@ -67,6 +67,17 @@ class CNN_3D(_stacked.StackedModule):
                                          self.h_b1, self.h_w2, self.h_b2, self.h_w3, self.h_b3)
         return z, [y[:, v:v + 1] for v in range(self.in_var)]      # (N,1,H,W) each; (N,1,T/8,H,W) when T > 8, as the reference
 
+    def forward_signs(self, signs, project_out):
+        """The same outputs as forward_tokens(z_q) for z_q = project_out(signs): LFQ's output has rank
+        codebook_dim per variable, so conv1 of every head runs on the (N,T,H,W,16)-channel sign field with
+        weights folded through project_out (ops.ClassifierHeadsSigns).  signs (N,V,T,H,W,d)."""
+        if self.training and self.drop_rate and self.drop_rate > 0:
+            raise NotImplementedError("idee_amd classifier: dropout > 0 is not built (cls_drop_rate default is 0)")
+        z, y = ops.ClassifierHeadsSigns.apply(signs, project_out.weight, project_out.bias, self.j_w1, self.j_b1, self.j_w2,
+                                              self.j_b2, self.j_w3, self.j_b3, self.h_w1, self.h_b1, self.h_w2, self.h_b2,
+                                              self.h_w3, self.h_b3)
+        return z, [y[:, v:v + 1] for v in range(self.in_var)]
+
     def forward(self, x):
         """x (N,V,C,T,H,W) as CNN_3D.forward (classifier/CNN_3D.py:112-139)."""
         return self.forward_tokens(x.permute(0, 1, 3, 4, 5, 2).contiguous())

@@ -54,11 +54,16 @@ class LFQ(nn.Module):
 
     def quantize_tokens(self, z):
         """z (..., dim) channels-last tokens -> (z_q (..., dim), indices int64 (...), aux loss ())."""
+        return self.quantize_tokens_signs(z, False)[:3]
+
+    def quantize_tokens_signs(self, z, want_signs=True):
+        """-> (z_q, indices, aux loss, signs (..., codebook_dim) | None): `signs` are the +-1 bits before project_out,
+        carrying the same straight-through gradient as z_q (for the classifier's rank-d input path)."""
         assert z.shape[-1] == self.dim, f"expected dimension of {self.dim} but received {z.shape[-1]}"
         return ops.LFQQuantize.apply(z, self.project_in.weight, self.project_in.bias, self.project_out.weight,
                                      self.project_out.bias, self.codebook_size, self.training,
                                      float(self.entropy_loss_weight), float(self.diversity_gamma),
-                                     float(self.commitment_loss_weight))
+                                     float(self.commitment_loss_weight), want_signs)
 
     def forward(self, x, inv_temperature=100., return_loss_breakdown=False, mask=None):
         """x (b, n, dim) as models/build.py:150-151 passes it (or (b, dim, ...) image/video)."""

@@ -119,11 +119,12 @@ class SwinBlock(torch.autograd.Function):
 class ConvLayer:
     """One convolution of the path, described once (idee_conv_desc) and run fwd / dgrad / wgrad."""
 
-    def __init__(self, mode, B, wsets, T, H, W, Cin, Cout, xs, ys, relu, x_units=None):
-        """xs / ys: (sB, sT, sH, sW, sG) float strides.  x_units = (groups per unit, unit stride): two-level channel
-        groups of the input (the joint head reads the V slices of z_q)."""
+    def __init__(self, mode, B, wsets, T, H, W, Cin, Cout, xs, ys, relu, x_units=None, y_units=None):
+        """xs / ys: (sB, sT, sH, sW, sG) float strides.  x_units / y_units = (groups per unit, unit stride): two-level
+        channel groups (the joint head reads the V slices of z_q; the folded head conv writes the V slices of its output)."""
         gpu, sU = x_units if x_units is not None else (0, 0)
-        self.desc = L.ConvDesc(mode, B, wsets, T, H, W, Cin, Cout, *xs, *ys, int(relu), gpu, 0, sU, 0)
+        ygpu, ysU = y_units if y_units is not None else (0, 0)
+        self.desc = L.ConvDesc(mode, B, wsets, T, H, W, Cin, Cout, *xs, *ys, int(relu), gpu, ygpu, sU, ysU)
         self.mode, self.B, self.wsets, self.Cin, self.Cout = mode, B, wsets, Cin, Cout
         self.ntaps = 27 if mode == L.CONV_K333_REPLICATE else 18
         self.packed_floats = L.load().idee_conv_packed_floats(C.byref(self.desc))
@@ -281,15 +282,123 @@ class ClassifierHeads(torch.autograd.Function):
                 dhb3)
 
 
+class ClassifierHeadsSigns(torch.autograd.Function):
+    """ClassifierHeads fed by LFQ's sign bits instead of z_q (exact refactoring, see
+    idee_hip.h "Rank-d classifier input"): z_q = b_out + signs @ w_out^T has rank d per variable, so both first
+    convolutions run on the (N,T,H,W,CS) sign field with weights folded through [w_out | b_out] — CS = 16 input
+    channels instead of V*C = 96 for the default model.  Layers 2 and 3 are those of ClassifierHeads.
+      signs (N,V,T,H,W,D) +-1;  w_out (C,D), b_out (C): LFQ.project_out;  remaining arguments as ClassifierHeads."""
+
+    @staticmethod
+    def forward(ctx, signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3):
+        ts = [_f32c(t) for t in (signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3)]
+        signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3 = ts
+        N, V, T, H, W, D = signs.shape
+        Cc = w_out.shape[0]
+        dim = hw1.shape[1]
+        Dj = jw1.shape[0]
+        if T < 8:
+            raise RuntimeError(f"classifier: T={T} is smaller than the three stride-2 temporal kernels need (the reference "
+                               "raises too: kernel size can't be greater than actual input size)")
+        if dim % 16 or Dj % 16:
+            raise RuntimeError("classifier (sign-field path): cls_dim must be a multiple of 16")
+        T1 = (T - 2) // 2 + 1
+        T2 = (T1 - 2) // 2 + 1
+        T3 = (T2 - 2) // 2 + 1
+        CS = ((V * D + 1 + 15) // 16) * 16
+        dev = signs.device
+        K = L.CONV_K233_S2_ZERO
+        st = L.stream()
+        sx = torch.empty((N, T, H, W, CS), device=dev, dtype=torch.float32)
+        L.call("idee_lfq_sign_field_fwd", ptr(signs), ptr(sx), N, V, T * H * W, D, CS, st)
+        jwe = torch.empty((Dj, CS, 2, 3, 3), device=dev, dtype=torch.float32)
+        hwe = torch.empty((V * dim, CS, 2, 3, 3), device=dev, dtype=torch.float32)
+        L.call("idee_lfq_fold_weights_fwd", ptr(jw1), ptr(w_out), ptr(b_out), ptr(jwe), Dj, V, Cc, D, CS, 18, 0, st)
+        L.call("idee_lfq_fold_weights_fwd", ptr(hw1), ptr(w_out), ptr(b_out), ptr(hwe), dim, V, Cc, D, CS, 18, 1, st)
+        sxs = _cl_strides(T, H, W, CS)
+        j1 = ConvLayer(K, N, 1, T, H, W, CS, Dj, sxs, _cl_strides(T1, H, W, Dj), True)
+        # the heads' conv1 writes variable v's `dim` channels into slice v of ha1 (N,V,T1,H,W,dim)
+        h1 = ConvLayer(K, N, 1, T, H, W, CS, V * dim, sxs, (V * T1 * H * W * dim, H * W * dim, W * dim, dim, 16), True,
+                       y_units=(dim // 16, T1 * H * W * dim))
+        j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True)
+        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False)
+        h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True)
+        h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (T3 * H * W, H * W, W, 1, 1), False)
+        convs = (j1, j2, j3, h1, h2, h3)
+        weights = (jwe, jw2, jw3, hwe, hw2, hw3)
+        need_dx = ctx.needs_input_grad[0]
+        packs = [c.pack(w, want_dgrad=(need_dx or i not in (0, 3))) for i, (c, w) in enumerate(zip(convs, weights))]
+        ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=torch.float32)
+        ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=torch.float32)
+        z = torch.empty((N, 1, H, W) if T3 == 1 else (N, 1, T3, H, W), device=dev, dtype=torch.float32)
+        ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=torch.float32)
+        ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=torch.float32)
+        y = torch.empty((N, V, H, W) if T3 == 1 else (N, V, T3, H, W), device=dev, dtype=torch.float32)
+        j1.fwd(sx, packs[0][0], jb1, ja1)
+        j2.fwd(ja1, packs[1][0], jb2, ja2)
+        j3.fwd(ja2, packs[2][0], jb3, z)
+        h1.fwd(sx, packs[3][0], hb1.reshape(-1), ha1)
+        h2.fwd(ha1, packs[4][0], hb2, ha2)
+        h3.fwd(ha2, packs[5][0], hb3, y)
+        pd = [p[1] if p[1] is not None else torch.empty(0, device=dev) for p in packs]
+        ctx.save_for_backward(sx, ja1, ja2, ha1, ha2, jw1, hw1, w_out, b_out, *weights, *pd)
+        ctx.convs = convs
+        ctx.geom = (N, V, T, H, W, D, CS, Cc, dim, Dj)
+        return z, y
+
+    @staticmethod
+    def backward(ctx, dz, dy):
+        saved = ctx.saved_tensors
+        sx, ja1, ja2, ha1, ha2, jw1, hw1, w_out, b_out = saved[:9]
+        jwe, jw2, jw3, hwe, hw2, hw3 = saved[9:15]
+        pd = saved[15:21]
+        j1, j2, j3, h1, h2, h3 = ctx.convs
+        N, V, T, H, W, D, CS, Cc, dim, Dj = ctx.geom
+        dz, dy = _f32c(dz), _f32c(dy)
+        st = L.stream()
+        dev = sx.device
+        djw3, djb3 = j3.wgrad(ja2, dz, jw3)
+        dja2 = torch.empty_like(ja2)
+        j3.dgrad(dz, pd[2], ja2, dja2)
+        djw2, djb2 = j2.wgrad(ja1, dja2, jw2)
+        dja1 = torch.empty_like(ja1)
+        j2.dgrad(dja2, pd[1], ja1, dja1)
+        djwe, djb1 = j1.wgrad(sx, dja1, jwe)
+        dhw3, dhb3 = h3.wgrad(ha2, dy, hw3)
+        dha2 = torch.empty_like(ha2)
+        h3.dgrad(dy, pd[5], ha2, dha2)
+        dhw2, dhb2 = h2.wgrad(ha1, dha2, hw2)
+        dha1 = torch.empty_like(ha1)
+        h2.dgrad(dha2, pd[4], ha1, dha1)
+        dhwe, dhb1 = h1.wgrad(sx, dha1, hwe)
+        # unfold the weight gradients through [w_out | b_out]
+        djw1, dhw1 = torch.empty_like(jw1), torch.empty_like(hw1)
+        dw_out, db_out = torch.zeros_like(w_out), torch.zeros_like(b_out)
+        L.call("idee_lfq_fold_weights_bwd", ptr(djwe), ptr(jw1), ptr(w_out), ptr(b_out), ptr(djw1), ptr(dw_out), ptr(db_out),
+               Dj, V, Cc, D, CS, 18, 0, st)
+        L.call("idee_lfq_fold_weights_bwd", ptr(dhwe), ptr(hw1), ptr(w_out), ptr(b_out), ptr(dhw1), ptr(dw_out), ptr(db_out),
+               dim, V, Cc, D, CS, 18, 1, st)
+        dsigns = None
+        if ctx.needs_input_grad[0]:
+            dsx = torch.empty_like(sx)
+            j1.dgrad(dja1, pd[0], None, dsx)
+            h1.dgrad(dha1, pd[3], None, dsx, accumulate=True)
+            dsigns = torch.empty((N, V, T, H, W, D), device=dev, dtype=torch.float32)
+            L.call("idee_lfq_sign_field_bwd", ptr(dsx), ptr(dsigns), N, V, T * H * W, D, CS, st)
+        return (dsigns, dw_out, db_out, djw1, djb1.reshape(-1), djw2, djb2.reshape(-1), djw3, djb3.reshape(-1), dhw1,
+                dhb1.reshape(V, dim), dhw2, dhb2, dhw3, dhb3)
+
+
 # ----------------------------------------------------------------------------------------
 # LFQ
 # ----------------------------------------------------------------------------------------
 class LFQQuantize(torch.autograd.Function):
-    """z (..., E) tokens -> z_q (..., E), indices int64 (...), aux loss ().  Reference:
-    LFQ.forward, models/codebook/LFQ.py:183-307."""
+    """z (..., E) tokens -> z_q (..., E), indices int64 (...), aux loss (), signs (..., D) | None.  Reference:
+    LFQ.forward, models/codebook/LFQ.py:183-307.  `signs` (want_signs) are the +-1 code bits x_ste of LFQ.py:232-240
+    BEFORE project_out, with the same straight-through gradient: consumers may read them instead of z_q."""
 
     @staticmethod
-    def forward(ctx, z, w_in, b_in, w_out, b_out, codebook_size, training, w_entropy, gamma, w_commit):
+    def forward(ctx, z, w_in, b_in, w_out, b_out, codebook_size, training, w_entropy, gamma, w_commit, want_signs=False):
         z, w_in, b_in, w_out, b_out = (_f32c(t) for t in (z, w_in, b_in, w_out, b_out))
         E = z.shape[-1]
         M = z.numel() // E
@@ -298,15 +407,17 @@ class LFQQuantize(torch.autograd.Function):
         idx = torch.empty(z.shape[:-1], device=dev, dtype=torch.int64)
         stats = torch.zeros(4 + codebook_size, device=dev, dtype=torch.float32)
         ws = torch.empty(L.load().idee_lfq_workspace_floats(M, codebook_size), device=dev, dtype=torch.float32)
+        D = max(1, codebook_size.bit_length() - 1)
+        signs = torch.empty(z.shape[:-1] + (D,), device=dev, dtype=torch.float32) if want_signs else None
         L.call("idee_lfq_fwd", ptr(z), ptr(w_in), ptr(b_in), ptr(w_out), ptr(b_out), ptr(zq), ptr(idx), ptr(stats), ptr(ws),
-               M, E, codebook_size, int(training), w_entropy, gamma, w_commit, L.stream())
+               ptr(signs), M, E, codebook_size, int(training), w_entropy, gamma, w_commit, L.stream())
         ctx.save_for_backward(z, w_in, b_in, w_out, stats)
         ctx.cfg = (M, E, codebook_size, w_entropy, gamma, w_commit)
         ctx.mark_non_differentiable(idx)
-        return zq, idx, stats[0]
+        return zq, idx, stats[0], signs
 
     @staticmethod
-    def backward(ctx, dzq, _didx, dloss):
+    def backward(ctx, dzq, _didx, dloss, dsigns=None):
         z, w_in, b_in, w_out, stats = ctx.saved_tensors
         M, E, K, w_entropy, gamma, w_commit = ctx.cfg
         dzq = _f32c(dzq) if dzq is not None else torch.zeros_like(z)
@@ -314,9 +425,10 @@ class LFQQuantize(torch.autograd.Function):
         dz = torch.empty_like(z)
         dw_in, db_in, dw_out = torch.zeros_like(w_in), torch.zeros_like(b_in), torch.zeros_like(w_out)
         db_out = torch.zeros(E, device=z.device, dtype=torch.float32)
-        L.call("idee_lfq_bwd", ptr(z), ptr(dzq), ptr(w_in), ptr(b_in), ptr(w_out), ptr(stats), ptr(gl), ptr(dz), ptr(dw_in),
-               ptr(db_in), ptr(dw_out), ptr(db_out), M, E, K, w_entropy, gamma, w_commit, L.stream())
-        return dz, dw_in, db_in, dw_out, db_out, None, None, None, None, None
+        dsigns = _f32c(dsigns) if dsigns is not None else None
+        L.call("idee_lfq_bwd", ptr(z), ptr(dzq), ptr(w_in), ptr(b_in), ptr(w_out), ptr(stats), ptr(gl), ptr(dsigns), ptr(dz),
+               ptr(dw_in), ptr(db_in), ptr(dw_out), ptr(db_out), M, E, K, w_entropy, gamma, w_commit, L.stream())
+        return dz, dw_in, db_in, dw_out, db_out, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------

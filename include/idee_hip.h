@@ -167,13 +167,32 @@ int idee_ln_relu_res_bwd(const float* c, const float* gamma, const float* beta, 
  * bwd: gloss = device pointer to d(loss)/d(aux loss); dw_in, db_in, dw_out, db_out accumulate.
  * ---------------------------------------------------------------------------------------- */
 long idee_lfq_workspace_floats(long M, int codebook_size);
+/* signs (M, D) | NULL: the +-1 code bits per token; dsigns (M, D) | NULL: an additional gradient on them (straight-through),
+ * coming from consumers that read the sign field instead of z_q (the rank-d classifier input below). */
 int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out, float* zq,
-                 int64_t* indices, float* stats, float* workspace, long M, int E, int codebook_size, int training,
-                 float w_entropy, float gamma, float w_commit, idee_stream_t stream);
+                 int64_t* indices, float* stats, float* workspace, float* signs, long M, int E, int codebook_size,
+                 int training, float w_entropy, float gamma, float w_commit, idee_stream_t stream);
 int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const float* b_in, const float* w_out,
-                 const float* stats, const float* gloss, float* dz, float* dw_in, float* db_in, float* dw_out,
-                 float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma, float w_commit,
+                 const float* stats, const float* gloss, const float* dsigns, float* dz, float* dw_in, float* db_in,
+                 float* dw_out, float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma, float w_commit,
                  idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rank-d classifier input (algebraic refactoring; exact in real arithmetic, disclosed in DESIGN.md):
+ * z_q = b_out + sum_i q_i w_out[:, i], so the first convolutions of the classifier (classifier/CNN_3D.py:83,38 applied to
+ * z_q at build.py:157) equal convolutions on the sign field S (N,T,H,W,CS): channel v*D+i = q_i of variable v,
+ * channel V*D = 1, others 0, CS a multiple of 16 >= V*D+1 — with weights folded through [w_out | b_out].
+ *   sign_field: signs (N,V,THW,D) <-> sx (N,THW,CS)
+ *   fold: w (Co, V*C, taps) joint | (V, Co, C, taps) per_var -> weff (rows, CS, taps), rows = Co | V*Co;
+ *         bwd: dw overwritten, dw_out (C,D) and db_out (C) accumulate.
+ * ---------------------------------------------------------------------------------------- */
+int idee_lfq_sign_field_fwd(const float* signs, float* sx, int N, int V, long THW, int D, int CS, idee_stream_t stream);
+int idee_lfq_sign_field_bwd(const float* dsx, float* dsigns, int N, int V, long THW, int D, int CS, idee_stream_t stream);
+int idee_lfq_fold_weights_fwd(const float* w, const float* w_out, const float* b_out, float* weff, int Co, int V, int C, int D,
+                              int CS, int taps, int per_var, idee_stream_t stream);
+int idee_lfq_fold_weights_bwd(const float* dweff, const float* w, const float* w_out, const float* b_out, float* dw,
+                              float* dw_out, float* db_out, int Co, int V, int C, int D, int CS, int taps, int per_var,
+                              idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Euclidean nearest-neighbour vector quantisation with straight-through gradient and commitment loss — the

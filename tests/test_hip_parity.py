@@ -283,6 +283,72 @@ def test_classifier_vs_oracle(V, H, W):
         gclose_relu("d" + key, g if idx is None else g[idx], sdl[key].grad)
 
 
+@pytest.mark.parametrize("V,D,H,W", [(3, 1, 7, 72), (6, 1, 5, 40), (1, 1, 3, 3), (5, 2, 4, 20), (8, 2, 3, 19)])
+def test_classifier_sign_field_vs_oracle(V, D, H, W):
+    """The rank-d input path (ops.ClassifierHeadsSigns: convs on the sign field with folded weights) against
+    the oracle's classifier applied to z_q = project_out(signs): outputs and every gradient."""
+    from oracle import idee_oracle as O
+    from idee_amd.models.classifier.CNN_3D import CNN_3D
+    N, T, E = 2, 8, 16
+    torch.manual_seed(V * 100 + W)
+    c = CNN_3D(in_var=V, embed_dim=E, dim=16, drop_rate=0.0)
+    po = torch.nn.Linear(D, E)
+    with torch.no_grad():
+        po.bias.normal_(0, 0.3)
+    sd = {k: v.clone() for k, v in c.state_dict().items()}
+    signs = (torch.randint(0, 2, (N, V, T, H, W, D)).float() * 2 - 1)
+    sdl = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    so = signs.clone().requires_grad_()
+    wo, bo = po.weight.detach().clone().requires_grad_(), po.bias.detach().clone().requires_grad_()
+    zq = (so @ wo.t() + bo).permute(0, 1, 5, 2, 3, 4)
+    zo, yo = O.classifier(zq, sdl, pre="")
+    rz, ry = torch.randn_like(zo), torch.randn(V, *yo[0].shape)
+    ((zo * rz).sum() + sum((yo[v] * ry[v]).sum() for v in range(V))).backward()
+    c, po = c.to(DEV), po.to(DEV)
+    sg = signs.to(DEV).requires_grad_()
+    z, y = c.forward_signs(sg, po)
+    close("z", z, zo, atol=2e-5, rtol=2e-4)
+    close("y", torch.stack(y), torch.stack(yo), atol=2e-5, rtol=2e-4)
+    ((z * rz.to(DEV)).sum() + sum((y[v] * ry[v].to(DEV)).sum() for v in range(V))).backward()
+    gclose_relu("dsigns", sg.grad, so.grad)
+    gclose_relu("dw_out", po.weight.grad, wo.grad)
+    gclose_relu("db_out", po.bias.grad, bo.grad)
+    named = dict(c.named_parameters())
+    for key, name, idx in c._key_map():
+        g = named[name].grad
+        gclose_relu("d" + key, g if idx is None else g[idx], sdl[key].grad)
+
+
+def test_sign_field_switch_matches_plain_path(monkeypatch):
+    """VQ_model with and without the rank-d classifier input: same outputs, same gradients (to f32 rounding)."""
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    cfg = default_config(in_channels_dynamic=3, in_channels=1, encoder="Swin_3D")
+    torch.manual_seed(5)
+    x = torch.randn(2, 3, 1, 8, 10, 20, device=DEV)
+    outs = []
+    sd = None
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IDEE_SIGN_FIELD", flag)
+        torch.manual_seed(11)
+        m = VQ_model(cfg).to(DEV).train()
+        if sd is None:
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+        m.load_state_dict(sd)
+        assert m.sign_field_classifier == (flag == "1")
+        zc, y, an, zq, lq = m(x)
+        (zc.sum() + sum(t.square().sum() for t in y) + zq.abs().sum() + lq.sum()).backward()
+        outs.append((zc, torch.stack(y), an, zq, lq, {n: p.grad.clone() for n, p in m.named_parameters()}))
+    a, b = outs
+    close("z", a[0], b[0], atol=2e-5, rtol=2e-4)
+    close("y", a[1], b[1], atol=2e-5, rtol=2e-4)
+    assert torch.equal(a[2], b[2])
+    close("zq", a[3], b[3], atol=0, rtol=0)
+    close("loss", a[4], b[4], atol=0, rtol=0)
+    for n in a[5]:
+        gclose_relu("d" + n, a[5][n], b[5][n])
+
+
 def test_losses_golden():
     from idee_amd.models import losses as Lm
     a, _, _ = load_golden("losses")
