@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
                 + [("relu", _I), ("x_gpu", _I), ("y_gpu", _I), ("x_sU", _L), ("y_sU", _L)])
 
 
-CONV_K333_REPLICATE, CONV_K233_S2_ZERO = 0, 1
+CONV_K333_REPLICATE, CONV_K233_S2_ZERO, CONV_K133_ZERO = 0, 1, 2
 
 # name -> (restype, argtypes); every symbol include/idee_hip.h declares
 _SIGS = {
@@ -61,10 +61,10 @@ _SIGS = {
     "idee_lfq_workspace_floats": (_L, [_L, _I]),
     "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P]),
     "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _P]),
-    "idee_lfq_sign_field_fwd": (_I, [_P, _P, _I, _I, _L, _I, _I, _P]),
-    "idee_lfq_sign_field_bwd": (_I, [_P, _P, _I, _I, _L, _I, _I, _P]),
-    "idee_lfq_fold_weights_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "idee_lfq_fold_weights_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "idee_lfq_sign_field_fwd": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _P]),
+    "idee_lfq_sign_field_bwd": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _P]),
+    "idee_lfq_fold_weights_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "idee_lfq_fold_weights_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "idee_vq_workspace_floats": (_L, [_L]),
     "idee_vq_nn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     "idee_vq_nn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),

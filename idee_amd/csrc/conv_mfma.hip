@@ -38,6 +38,7 @@ struct ConvArgs {
   int relu;
   int accumulate;         // out += result (plain-store path)
   int ntaps;
+  int kt;                 // temporal taps of the (kt,3,3) zero-padded modes: 2 (stride 2 in T) or 1 (stride 1)
   long i_sB, i_sT, i_sH, i_sW, i_sG, i_sU;
   long o_sB, o_sT, o_sH, o_sW, o_sG, o_sU;
   int i_gpu, o_gpu;                      // 16-channel groups per unit: group g lives at (g / gpu) * sU + (g % gpu) * sG
@@ -51,15 +52,15 @@ struct Slot { int src, tap; bool ok; };
 __device__ __forceinline__ long goff(int g, int gpu, long sU, long sG) { return (long)(g / gpu) * sU + (long)(g % gpu) * sG; }
 
 template <int MODE>
-__device__ __forceinline__ Slot slot_t(int o, int t, int Ti) {
+__device__ __forceinline__ Slot slot_t(int o, int t, int Ti, int kt) {
   Slot s;
   if (MODE == FWD_REP) { s.src = min(max(t + o - 1, 0), Ti - 1); s.tap = o; s.ok = true; }
   else if (MODE == DGRAD_REP) {
     const int q = t - (o - 1);
     const bool in = q >= 0 && q < Ti;
     s.src = min(max(q, 0), Ti - 1); s.tap = in ? o : 2 - o; s.ok = true;
-  } else if (MODE == FWD_S2) { s.src = 2 * t + o; s.tap = o; s.ok = (o < 2) && (s.src < Ti); }
-  else { s.src = t >> 1; s.tap = t & 1; s.ok = (o == 0) && (s.src < Ti); }
+  } else if (MODE == FWD_S2) { s.src = kt * t + o; s.tap = o; s.ok = (o < kt) && (s.src < Ti); }
+  else { s.src = kt == 2 ? t >> 1 : t; s.tap = kt == 2 ? t & 1 : 0; s.ok = (o == 0) && (s.src < Ti); }
   return s;
 }
 template <int MODE>
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256, NT >= 6 ? 2 : 1) void conv_kernel(ConvArgs a) 
     const float* in_b = a.in + (long)b * a.i_sB;
 #pragma unroll
     for (int ot = 0; ot < 3; ++ot) {
-      const Slot st = slot_t<MODE>(ot, t, a.Ti);
+      const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
       if (!st.ok) continue;
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) {
@@ -224,6 +225,7 @@ struct WgradArgs {
   int To;         // dy extent in T (H, W equal)
   int Cin, CoutPad, cout_real;
   int ntaps;
+  int kt;         // temporal taps (= temporal stride) of the zero-padded modes: 2 or 1
   long x_sB, x_sT, x_sH, x_sW, x_sG, x_sU;
   long y_sB, y_sT, y_sH, y_sW, y_sG, y_sU;
   int x_gpu, y_gpu;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
           st = min(max(t + ot - 1, 0), a.T - 1); sh = min(max(h + oh - 1, 0), a.H - 1);
           sw = min(max(p + ow - 1, 0), a.W - 1);
         } else {
-          st = 2 * t + ot; sh = h + oh - 1; sw = p + ow - 1;
+          st = a.kt * t + ot; sh = h + oh - 1; sw = p + ow - 1;
           ok = ok && sh >= 0 && sh < a.H && sw >= 0 && sw < a.W;
         }
         const float* xp = x_b + (long)st * a.x_sT + (long)sh * a.x_sH + (long)sw * a.x_sW;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // multiplied, the next slab travels global -> registers -> LDS.  Weight traffic from L2 drops 8x against the
 // per-wave fragment loads of conv_kernel; activations still come straight from L1/L2.
 // ---------------------------------------------------------------------------------------------
-template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT>
+template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT, bool RES /*all taps' weights resident in LDS: no barriers per tap*/>
 __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
   constexpr int MT = 4, WAVES = 8;
   extern __shared__ __attribute__((aligned(16))) float s_wd[];   // [2][Gk * NT * 256]
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
   const int slab = a.Gk * NT * 256;                       // floats per tap
   const float* wp = a.wp + (long)wset * a.ntaps * slab;
   const int slab4 = slab / 4;
-  const int NOT = (MODE == FWD_S2) ? 2 : 1;               // T-slots
+  const int NOT = (MODE == FWD_S2) ? a.kt : 1;            // T-slots
 
   for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
     const int wt = tile % a.wtiles, r = tile / a.wtiles;
@@ -360,47 +362,67 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
     const int ntap_it = NOT * 9;
     auto tap_of = [&](int it) {                            // iteration -> weight tap index
       const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
-      const int tt = (MODE == FWD_S2) ? ot : (t & 1);
+      const int tt = (MODE == FWD_S2) ? ot : (a.kt == 2 ? (t & 1) : 0);
       return (tt * 3 + oh) * 3 + ow;
     };
-    __syncthreads();                                       // previous tile's readers done
-    for (int u = tid; u < slab4; u += 512) st4(s_wd + 4 * u, ld4(wp + (long)tap_of(0) * slab + 4 * u));
-    __syncthreads();
+    if constexpr (RES) {
+      if (tile == (int)blockIdx.x) {                       // once per workgroup
+        for (int u = tid; u < a.ntaps * slab4; u += 512) st4(s_wd + 4 * u, ld4(wp + 4 * u));
+        __syncthreads();
+      }
+    } else {
+      __syncthreads();                                     // previous tile's readers done
+      for (int u = tid; u < slab4; u += 512) st4(s_wd + 4 * u, ld4(wp + (long)tap_of(0) * slab + 4 * u));
+      __syncthreads();
+    }
+
+    // activations are prefetched one (tap, channel-block) step ahead, ACROSS tap boundaries: a tap whose source row
+    // is outside the frame (or a wave past the last row) loads nothing and multiplies zeros
+    struct TapSrc { const float* rowp; long off[MT]; bool okm[MT]; };
+    auto tap_src = [&](int it) {
+      TapSrc s;
+      const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
+      const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
+      const Slot sh = slot_h<MODE>(oh, h, a.Hi);
+      const bool okr = row_ok && st.ok && sh.ok;
+      s.rowp = in_b + (long)(okr ? st.src : 0) * a.i_sT + (long)(okr ? sh.src : 0) * a.i_sH + 4 * kq;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int p = w0 + m * 16 + j;
+        bool ok;
+        const int q = src_w<MODE>(ow, p, a.Wi, ok);
+        s.okm[m] = okr && ok && (p < a.Wo) && (m < my_mt);
+        s.off[m] = (long)q * a.i_sW;
+      }
+      return s;
+    };
+    TapSrc cur = tap_src(0);
+    f32x4 xc[MT], xn[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xc[m] = cur.okm[m] ? ld4(cur.rowp + cur.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int it = 0; it < ntap_it; ++it) {
-      const float* wcur = s_wd + (it & 1) * slab;
+      const float* wcur = RES ? s_wd + tap_of(it) * slab : s_wd + (it & 1) * slab;
       float* wnext = s_wd + ((it + 1) & 1) * slab;
       // prefetch the next slab into registers (up to 5 x 16 bytes per thread for a 6x6 slab)
       f32x4 pre[5];
       const bool more = it + 1 < ntap_it;
-      if (more) {
+      if (more && !RES) {
         const float* src = wp + (long)tap_of(it + 1) * slab;
 #pragma unroll
         for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) pre[q] = ld4(src + 4 * u); }
       }
-      const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
-      const Slot st = slot_t<MODE>(ot, t, a.Ti);
-      const Slot sh = slot_h<MODE>(oh, h, a.Hi);
-      if (row_ok && st.ok && sh.ok) {
-        const float* rowp = in_b + (long)st.src * a.i_sT + (long)sh.src * a.i_sH + 4 * kq;
-        long off[MT];
-        bool okm[MT];
+      TapSrc nxt = cur;
+      if (more) nxt = tap_src(it + 1);
+      for (int g = 0; g < a.Gk; ++g) {
+        if (g + 1 < a.Gk) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int p = w0 + m * 16 + j;
-          bool ok;
-          const int q = src_w<MODE>(ow, p, a.Wi, ok);
-          okm[m] = ok && (p < a.Wo) && (m < my_mt);
-          off[m] = (long)q * a.i_sW;
+          for (int m = 0; m < MT; ++m) xn[m] = cur.okm[m] ? ld4(cur.rowp + cur.off[m] + goff(g + 1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (more) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) xn[m] = nxt.okm[m] ? ld4(nxt.rowp + nxt.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 xc[MT], xn[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) xc[m] = okm[m] ? ld4(rowp + off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int g = 0; g < a.Gk; ++g) {
-          if (g + 1 < a.Gk) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) xn[m] = okm[m] ? ld4(rowp + off[m] + goff(g + 1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+        if (row_ok) {
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             const f32x4 wf = ld4(wcur + (g * NT + n) * 256 + lane * 4);
@@ -410,15 +432,18 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
               for (int m = 0; m < MT; ++m)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
           }
-#pragma unroll
-          for (int m = 0; m < MT; ++m) xc[m] = xn[m];
         }
-      }
-      if (more) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) st4(wnext + 4 * u, pre[q]); }
+        for (int m = 0; m < MT; ++m) xc[m] = xn[m];
       }
-      __syncthreads();
+      cur = nxt;
+      if constexpr (!RES) {
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) st4(wnext + 4 * u, pre[q]); }
+        }
+        __syncthreads();
+      }
     }
 
     if (!row_ok) continue;
@@ -496,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
     const float* in_b = a.in + (long)b * a.i_sB;
     Slot st[3];
 #pragma unroll
-    for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti);
+    for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti, a.kt);
     const int blk1 = my_sub > 1 ? 16 : 0;                              // a lone block re-reads block 0 (result unused)
 
     for (int h = h0; h < h1; ++h) {
@@ -813,7 +838,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
     const int w0 = sg * seg;
     const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
     int res0 = -1, res1 = -1, res2 = -1;
-    const float* x_bt = a.x + (long)b * a.x_sB + (long)(2 * t + kt) * a.x_sT;
+    const float* x_bt = a.x + (long)b * a.x_sB + (long)(a.kt * t + kt) * a.x_sT;
     const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
 
     for (int h = h0; h < h1; ++h) {
@@ -1155,7 +1180,8 @@ void fill_c1(C1Args& a, const idee_conv_desc* d) {
 
 int check_desc(const idee_conv_desc* d) {
   IDEE_CHECK_ARG(d, "conv: null descriptor");
-  IDEE_CHECK_ARG(d->mode == IDEE_CONV_K333_REPLICATE || d->mode == IDEE_CONV_K233_S2_ZERO, "conv: bad mode %d", d->mode);
+  IDEE_CHECK_ARG(d->mode == IDEE_CONV_K333_REPLICATE || d->mode == IDEE_CONV_K233_S2_ZERO || d->mode == IDEE_CONV_K133_ZERO,
+                 "conv: bad mode %d", d->mode);
   IDEE_CHECK_ARG(d->B > 0 && d->wsets > 0 && d->B % d->wsets == 0, "conv: B %d must be a multiple of wsets %d", d->B, d->wsets);
   IDEE_CHECK_ARG(d->T > 0 && d->H > 0 && d->W > 0, "conv: empty extent");
   IDEE_CHECK_ARG(d->Cin > 0 && d->Cin % 16 == 0, "conv: Cin %d must be a multiple of 16", d->Cin);
@@ -1163,8 +1189,9 @@ int check_desc(const idee_conv_desc* d) {
   if (d->mode == IDEE_CONV_K233_S2_ZERO) IDEE_CHECK_ARG(d->T >= 2, "conv (2,3,3): T %d < kernel 2", d->T);
   return IDEE_OK;
 }
-inline int out_T(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REPLICATE ? d->T : (d->T - 2) / 2 + 1; }
-inline int n_taps(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REPLICATE ? 27 : 18; }
+inline int out_T(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K233_S2_ZERO ? (d->T - 2) / 2 + 1 : d->T; }
+inline int n_taps(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REPLICATE ? 27 : d->mode == IDEE_CONV_K233_S2_ZERO ? 18 : 9; }
+inline int mode_kt(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K133_ZERO ? 1 : 2; }
 inline int pick_nt(int G) { return G % 6 == 0 ? 6 : G % 3 == 0 ? 3 : G % 2 == 0 ? 2 : 1; }
 
 // resident workgroups per CU of a kernel (occupancy API; advisory, only steers the grid size)
@@ -1217,16 +1244,20 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
     if (!cin1 && gz == 1 && (NT >= 2 || a.Gk >= 2) && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
       a.hgroups = cdiv(a.Ho, 8);
       a.tiles = a.To * a.hgroups * a.wtiles;
-#define LCW(NT_)                                                                                               \
+      const bool res = a.ntaps * slab_bytes <= 150 * 1024;      // every tap's weights stay in LDS
+      const long lds_bytes = res ? a.ntaps * slab_bytes : 2 * slab_bytes;
+#define LCW2(NT_, RES_)                                                                                        \
   do {                                                                                                         \
-    auto kern = conv_wide_kernel<MODE, NT_>;                                                                   \
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * slab_bytes)) != hipSuccess) \
-      return idee::fail(IDEE_ERR_LAUNCH, "conv: cannot reserve %ld bytes of LDS", 2 * slab_bytes);               \
+    auto kern = conv_wide_kernel<MODE, NT_, RES_>;                                                             \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) \
+      return idee::fail(IDEE_ERR_LAUNCH, "conv: cannot reserve %ld bytes of LDS", lds_bytes);                    \
     const dim3 grid(one_round(a.tiles, a.B, 1), a.B);                                                          \
-    hipLaunchKernelGGL(kern, grid, dim3(512), 2 * slab_bytes, stream, a);                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, a);                                           \
   } while (0)
+#define LCW(NT_) do { if (res) LCW2(NT_, true); else LCW2(NT_, false); } while (0)
       if (NT == 6) LCW(6); else if (NT == 3) LCW(3); else if (NT == 2) LCW(2); else LCW(1);
 #undef LCW
+#undef LCW2
       return IDEE_OK;
     }
   }
@@ -1295,7 +1326,7 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const float* x, const floa
   a.B = d->B; a.wsets = d->wsets;
   a.Ti = d->T; a.Hi = d->H; a.Wi = d->W;
   a.To = out_T(d); a.Ho = d->H; a.Wo = d->W;
-  a.Gk = d->Cin / 16; a.GnTot = (d->Cout + 15) / 16; a.cout_real = d->Cout; a.relu = d->relu; a.ntaps = n_taps(d);
+  a.Gk = d->Cin / 16; a.GnTot = (d->Cout + 15) / 16; a.cout_real = d->Cout; a.relu = d->relu; a.ntaps = n_taps(d); a.kt = mode_kt(d);
   a.i_sB = d->x_sB; a.i_sT = d->x_sT; a.i_sH = d->x_sH; a.i_sW = d->x_sW; a.i_sG = d->x_sG;
   a.o_sB = d->y_sB; a.o_sT = d->y_sT; a.o_sH = d->y_sH; a.o_sW = d->y_sW; a.o_sG = d->y_sG;
   a.i_sU = d->x_sU; a.i_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30); a.o_sU = d->y_sU; a.o_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30);
@@ -1323,7 +1354,7 @@ extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const f
   a.B = d->B; a.wsets = d->wsets;
   a.Ti = out_T(d); a.Hi = d->H; a.Wi = d->W;
   a.To = d->T; a.Ho = d->H; a.Wo = d->W;
-  a.Gk = (d->Cout + 15) / 16; a.GnTot = d->Cin / 16; a.cout_real = d->Cin; a.relu = 0; a.ntaps = n_taps(d);
+  a.Gk = (d->Cout + 15) / 16; a.GnTot = d->Cin / 16; a.cout_real = d->Cin; a.relu = 0; a.ntaps = n_taps(d); a.kt = mode_kt(d);
   a.i_sB = d->y_sB; a.i_sT = d->y_sT; a.i_sH = d->y_sH; a.i_sW = d->y_sW; a.i_sG = d->y_sG;
   a.o_sB = d->x_sB; a.o_sT = d->x_sT; a.o_sH = d->x_sH; a.o_sW = d->x_sW; a.o_sG = d->x_sG;
   a.i_sU = d->y_sU; a.i_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30); a.o_sU = d->x_sU; a.o_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30);
@@ -1355,7 +1386,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
   memset(&a, 0, sizeof(a));
   a.x = x; a.dy = dy; a.dwp = dw_packed; a.dbias = dbias;
   a.B = d->B; a.wsets = d->wsets; a.T = d->T; a.H = d->H; a.W = d->W; a.To = out_T(d);
-  a.Cin = d->Cin; a.CoutPad = ((d->Cout + 15) / 16) * 16; a.cout_real = d->Cout; a.ntaps = n_taps(d);
+  a.Cin = d->Cin; a.CoutPad = ((d->Cout + 15) / 16) * 16; a.cout_real = d->Cout; a.ntaps = n_taps(d); a.kt = mode_kt(d);
   a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;
   a.y_sB = d->y_sB; a.y_sT = d->y_sT; a.y_sH = d->y_sH; a.y_sW = d->y_sW; a.y_sG = d->y_sG;
   a.x_sU = d->x_sU; a.x_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30); a.y_sU = d->y_sU; a.y_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30);
@@ -1373,7 +1404,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     a.row_chunks = gx;                                                                                       \
     hipLaunchKernelGGL((wgrad_kernel<MODE_, TPW_, NTA_, NTB_>), dim3(gx, gy, d->wsets), dim3(256), 0, st, a); \
   } while (0)
-  if (Ga == 1 && Gb == 1 && d->Cout == 16) {
+  if (Ga == 1 && Gb == 1 && d->Cout == 16 && d->mode != IDEE_CONV_K133_ZERO) {
     // LDS-staged kernel: row segments of <= kSegMax pixels, runs of hrun rows per (b, t)
     const int nseg = cdiv(d->W, kSegMax);
     const int seg = ((cdiv(d->W, nseg) + 3) / 4) * 4 > kSegMax ? kSegMax : ((cdiv(d->W, nseg) + 3) / 4) * 4;
@@ -1398,13 +1429,13 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     if (segmax > 256) segmax = 256;
     const int nseg = cdiv(d->W, segmax);
     const int seg = ((cdiv(d->W, nseg) + 3) / 4) * 4;
-    const long btk = (long)(d->B / d->wsets) * a.To * 2;
+    const long btk = (long)(d->B / d->wsets) * a.To * a.kt;
     int hrun = d->H;
     while (hrun > 8 && btk * cdiv(d->H, hrun) * nseg * d->wsets < 3L * kCUs) hrun = (hrun + 1) / 2;
     const int nhrun = cdiv(d->H, hrun);
     const long nchunks = (long)(d->B / d->wsets) * a.To * nhrun * nseg;
     const size_t lds = (size_t)(3L * (seg + 2) * PSX + (long)((seg + 3) & ~3) * PSY) * 4;
-    const dim3 grid(one_round(nchunks, 2L * d->wsets, 1), d->wsets, 2);
+    const dim3 grid(one_round(nchunks, (long)a.kt * d->wsets, 1), d->wsets, a.kt);
 #define LWW(GA_, GB_, WAVES_)                                                                                         \
   do {                                                                                                                \
     auto kern = wgrad_wide_lds_kernel<GA_, GB_, WAVES_>;                                                              \
@@ -1417,7 +1448,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     else if (Ga == 6) LWW(6, 6, 8); else if (Ga == 3) LWW(3, 3, 8); else LWW(2, 2, 8);
 #undef LWW
   }
-  else if (Ga == 1 && Gb == 1) { if (rep) LW(FWD_REP, 27, 1, 1); else LW(FWD_S2, 18, 1, 1); }
+  else if (Ga == 1 && Gb == 1) { if (rep) LW(FWD_REP, 27, 1, 1); else if (a.kt == 2) LW(FWD_S2, 18, 1, 1); else LW(FWD_S2, 9, 1, 1); }
   else {
     const int na = pick_nt(Ga), nb = pick_nt(Gb);
     // one tap per wave; channel blocks up to 6x6

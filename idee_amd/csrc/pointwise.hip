@@ -735,99 +735,104 @@ __global__ __launch_bounds__(256) void anomaly_vote_finalize_kernel(const float*
 
 // -------------------------------------------------------------------------------------------
 // Rank-d classifier input (disclosed in DESIGN.md): LFQ's output is z_q = b_out + sum_i q_i w_out[:, i]
-// with q in {-1,+1}^D per token, so the classifier's first convolutions on the V*C channels of z_q equal convolutions
-// on the "sign field" S (N,T,H,W,CS): channel v*D+i = q_i of variable v, channel V*D = 1 (its zero padding reproduces
-// the border behaviour of the zero-padded z_q exactly), remaining channels 0 — with folded weights
-//   W_eff[co][v*D+i][tap] = sum_c W[co][v*C+c][tap] w_out[c][i] ,  W_eff[co][V*D][tap] = sum_{v,c} W[co][v*C+c][tap] b_out[c].
+// with q in {-1,+1}^D per token, so the classifier's first (2,3,3)-stride-(2,1,1) convolutions on the V*C channels of
+// z_q equal (1,3,3) convolutions on the PAIRED SIGN FIELD S (N,T/2,H,W,CP): with R = V*D + 1,
+//   channel kt*R + v*D + i = q_i of variable v in frame 2*t1 + kt,   channel kt*R + V*D = 1
+// (the constant's zero padding reproduces the border behaviour of the zero-padded z_q exactly), other channels 0, and
+//   W_eff[co][kt*R + v*D+i][kh,kw] = sum_c W[co][v*C+c][kt,kh,kw] w_out[c][i]
+//   W_eff[co][kt*R + V*D][kh,kw]   = sum_{v,c} W[co][v*C+c][kt,kh,kw] b_out[c].
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __restrict__ qs, float* __restrict__ sx, int N, int V,
-                                                             long THW, int D, int CS) {
-  const long npix = (long)N * THW;
-  const int Q = CS / 4;
+__global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __restrict__ qs, float* __restrict__ sp, int N, int V,
+                                                             int T, long HW, int D, int CP) {
+  const int T1 = T / 2, R = V * D + 1, Q = CP / 4;
+  const long npix = (long)N * T1 * HW;
   for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < npix * Q; u += (long)gridDim.x * 256) {
     const long pix = u / Q; const int q = (int)(u % Q);
-    const long n = pix / THW, p = pix % THW;
+    const long p = pix % HW; long r = pix / HW;
+    const int t1 = (int)(r % T1); const long n = r / T1;
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int ch = 4 * q + k;
+      const int chp = 4 * q + k;
+      const int kt = chp / R, ch = chp % R;
       float val = 0.f;
-      if (ch < V * D) val = qs[((n * V + ch / D) * THW + p) * D + ch % D];
-      else if (ch == V * D) val = 1.f;
+      if (kt < 2) val = ch < V * D ? qs[(((n * V + ch / D) * T + 2 * t1 + kt) * HW + p) * D + ch % D] : 1.f;
       o[k] = val;
     }
-    st4(sx + pix * CS + 4 * q, o);
+    st4(sp + pix * CP + 4 * q, o);
   }
 }
-__global__ __launch_bounds__(256) void sign_field_bwd_kernel(const float* __restrict__ dsx, float* __restrict__ dqs, int N, int V,
-                                                             long THW, int D, int CS) {
-  const long total = (long)N * V * THW * D;
+__global__ __launch_bounds__(256) void sign_field_bwd_kernel(const float* __restrict__ dsp, float* __restrict__ dqs, int N, int V,
+                                                             int T, long HW, int D, int CP) {
+  const int T1 = T / 2, R = V * D + 1;
+  const long total = (long)N * V * T * HW * D;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int i = (int)(e % D); long r = e / D;
-    const long p = r % THW; r /= THW;
+    const long p = r % HW; r /= HW;
+    const int t = (int)(r % T); r /= T;
     const int v = (int)(r % V); const long n = r / V;
-    dqs[e] = dsx[(n * THW + p) * CS + v * D + i];
+    dqs[e] = t < 2 * T1 ? dsp[((n * T1 + t / 2) * HW + p) * CP + (t & 1) * R + v * D + i] : 0.f;   // an odd last frame is never read
   }
 }
-// w (Co, G*C, taps) [G = V for the joint head (G*C input channels), per-variable heads: see `per_var`], p = [w_out | b_out]
-// weff (Co_total, CS, taps).  per_var: w is (V, Co, C, taps) and output row v*Co + co only sees variable v.
+// w (Co, V*C, 2, 9) joint | (V, Co, C, 2, 9) per_var -> weff (rows, CP, 9), rows = Co | V*Co (row v*Co+co sees only variable v)
 __global__ void fold_fwd_kernel(const float* __restrict__ w, const float* __restrict__ w_out, const float* __restrict__ b_out,
-                                float* __restrict__ weff, int Co, int V, int C, int D, int CS, int taps, int per_var) {
-  const int rows = per_var ? V * Co : Co;
-  const long total = (long)rows * CS * taps;
+                                float* __restrict__ weff, int Co, int V, int C, int D, int CP, int per_var) {
+  const int rows = per_var ? V * Co : Co, R = V * D + 1;
+  const long total = (long)rows * CP * 9;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int tap = (int)(e % taps); long r = e / taps;
-    const int ch = (int)(r % CS); const int row = (int)(r / CS);
+    const int tap9 = (int)(e % 9); long r = e / 9;
+    const int chp = (int)(r % CP); const int row = (int)(r / CP);
+    const int kt = chp / R, ch = chp % R;
     float acc = 0.f;
-    if (ch <= V * D) {
-      const int vr = per_var ? row / Co : -1;            // the only variable this output row reads (heads)
+    if (kt < 2) {
+      const int tap = kt * 9 + tap9;
+      const int vr = per_var ? row / Co : -1;
       for (int v = 0; v < V; ++v) {
         if (ch < V * D && v != ch / D) continue;
         if (per_var && v != vr) continue;
-        const float* wrow = per_var ? w + (((long)row) * C) * taps : w + (((long)row) * V * C + (long)v * C) * taps;
-        for (int c = 0; c < C; ++c) {
-          const float wc = wrow[(long)c * taps + tap];
-          acc = fmaf(wc, ch < V * D ? w_out[c * D + ch % D] : b_out[c], acc);
-        }
+        const float* wrow = per_var ? w + ((long)row * C) * 18 : w + ((long)row * V * C + (long)v * C) * 18;
+        for (int c = 0; c < C; ++c)
+          acc = fmaf(wrow[(long)c * 18 + tap], ch < V * D ? w_out[c * D + ch % D] : b_out[c], acc);
       }
     }
     weff[e] = acc;
   }
 }
-// dw[row][(v) c][tap] = sum_i dweff[row][v*D+i][tap] w_out[c][i] + dweff[row][V*D][tap] b_out[c]
+// dw[row][(v) c][kt, tap9] = sum_i dweff[row][kt*R + v*D+i][tap9] w_out[c][i] + dweff[row][kt*R + V*D][tap9] b_out[c]
 __global__ void fold_bwd_w_kernel(const float* __restrict__ dweff, const float* __restrict__ w_out, const float* __restrict__ b_out,
-                                  float* __restrict__ dw, int Co, int V, int C, int D, int CS, int taps, int per_var) {
-  const int rows = per_var ? V * Co : Co;
+                                  float* __restrict__ dw, int Co, int V, int C, int D, int CP, int per_var) {
+  const int rows = per_var ? V * Co : Co, R = V * D + 1;
   const int G = per_var ? 1 : V;
-  const long total = (long)rows * G * C * taps;
+  const long total = (long)rows * G * C * 18;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int tap = (int)(e % taps); long r = e / taps;
+    const int tap = (int)(e % 18); long r = e / 18;
     const int c = (int)(r % C); r /= C;
     const int g = (int)(r % G); const int row = (int)(r / G);
     const int v = per_var ? row / Co : g;
-    const float* dwe = dweff + ((long)row * CS) * taps + tap;
-    float acc = dwe[(long)(V * D) * taps] * b_out[c];
+    const int kt = tap / 9, tap9 = tap % 9;
+    const float* dwe = dweff + ((long)row * CP + kt * R) * 9 + tap9;
+    float acc = dwe[(long)(V * D) * 9] * b_out[c];
 #pragma unroll 4
-    for (int i = 0; i < D; ++i) acc = fmaf(dwe[(long)(v * D + i) * taps], w_out[c * D + i], acc);
+    for (int i = 0; i < D; ++i) acc = fmaf(dwe[(long)(v * D + i) * 9], w_out[c * D + i], acc);
     dw[e] = acc;
   }
 }
-// dw_out[c][i] += sum_{row, v, tap} w[row][(v) c][tap] dweff[row][v*D+i][tap] ; db_out[c] += sum w[..] dweff[row][V*D][tap]
+// dw_out[c][i] += sum_{row, v, tap} w[row][(v) c][tap] dweff[row][kt*R + v*D+i][tap9] ; db_out[c] likewise with the constant channel
 __global__ void fold_bwd_p_kernel(const float* __restrict__ dweff, const float* __restrict__ w, float* __restrict__ dw_out,
-                                  float* __restrict__ db_out, int Co, int V, int C, int D, int CS, int taps, int per_var) {
+                                  float* __restrict__ db_out, int Co, int V, int C, int D, int CP, int per_var) {
   // one block per (c, i) with i == D meaning b_out
   const int c = blockIdx.x / (D + 1), i = blockIdx.x % (D + 1);
-  const int rows = per_var ? V * Co : Co;
+  const int rows = per_var ? V * Co : Co, R = V * D + 1;
   const int G = per_var ? 1 : V;
   float acc = 0.f;
-  const long total = (long)rows * G * taps;
+  const long total = (long)rows * G * 18;
   for (long e = threadIdx.x; e < total; e += blockDim.x) {
-    const int tap = (int)(e % taps); long r = e / taps;
+    const int tap = (int)(e % 18); long r = e / 18;
     const int g = (int)(r % G); const int row = (int)(r / G);
     const int v = per_var ? row / Co : g;
-    const float wv = w[(((long)row * G + g) * C + c) * taps + tap];
+    const float wv = w[(((long)row * G + g) * C + c) * 18 + tap];
     const int ch = i < D ? v * D + i : V * D;
-    acc = fmaf(wv, dweff[((long)row * CS + ch) * taps + tap], acc);
+    acc = fmaf(wv, dweff[((long)row * CP + (tap / 9) * R + ch) * 9 + tap % 9], acc);
   }
   __shared__ float sm[4];
   acc = wave_sum(acc);
@@ -1071,34 +1076,34 @@ extern "C" int idee_anomaly_vote_finalize(const float* acc, const float* cnt, fl
   return IDEE_OK;
 }
 
-extern "C" int idee_lfq_sign_field_fwd(const float* signs, float* sx, int N, int V, long THW, int D, int CS, idee_stream_t stream) {
-  IDEE_CHECK_ARG(signs && sx && N > 0 && V > 0 && THW > 0 && D > 0 && CS % 16 == 0 && V * D + 1 <= CS, "lfq_sign_field_fwd: bad argument");
-  hipLaunchKernelGGL(sign_field_fwd_kernel, dim3(stream_grid((long)N * THW * (CS / 4))), dim3(256), 0, (hipStream_t)stream, signs, sx, N, V, THW, D, CS);
+extern "C" int idee_lfq_sign_field_fwd(const float* signs, float* sp, int N, int V, int T, long HW, int D, int CP, idee_stream_t stream) {
+  IDEE_CHECK_ARG(signs && sp && N > 0 && V > 0 && T >= 2 && HW > 0 && D > 0 && CP % 16 == 0 && 2 * (V * D + 1) <= CP, "lfq_sign_field_fwd: bad argument");
+  hipLaunchKernelGGL(sign_field_fwd_kernel, dim3(stream_grid((long)N * (T / 2) * HW * (CP / 4))), dim3(256), 0, (hipStream_t)stream, signs, sp, N, V, T, HW, D, CP);
   IDEE_LAUNCH_CHECK("lfq_sign_field_fwd");
   return IDEE_OK;
 }
-extern "C" int idee_lfq_sign_field_bwd(const float* dsx, float* dsigns, int N, int V, long THW, int D, int CS, idee_stream_t stream) {
-  IDEE_CHECK_ARG(dsx && dsigns && N > 0 && V > 0 && THW > 0 && D > 0 && CS % 16 == 0 && V * D + 1 <= CS, "lfq_sign_field_bwd: bad argument");
-  hipLaunchKernelGGL(sign_field_bwd_kernel, dim3(stream_grid((long)N * V * THW * D)), dim3(256), 0, (hipStream_t)stream, dsx, dsigns, N, V, THW, D, CS);
+extern "C" int idee_lfq_sign_field_bwd(const float* dsp, float* dsigns, int N, int V, int T, long HW, int D, int CP, idee_stream_t stream) {
+  IDEE_CHECK_ARG(dsp && dsigns && N > 0 && V > 0 && T >= 2 && HW > 0 && D > 0 && CP % 16 == 0 && 2 * (V * D + 1) <= CP, "lfq_sign_field_bwd: bad argument");
+  hipLaunchKernelGGL(sign_field_bwd_kernel, dim3(stream_grid((long)N * V * T * HW * D)), dim3(256), 0, (hipStream_t)stream, dsp, dsigns, N, V, T, HW, D, CP);
   IDEE_LAUNCH_CHECK("lfq_sign_field_bwd");
   return IDEE_OK;
 }
 extern "C" int idee_lfq_fold_weights_fwd(const float* w, const float* w_out, const float* b_out, float* weff, int Co, int V, int C,
-                                         int D, int CS, int taps, int per_var, idee_stream_t stream) {
-  IDEE_CHECK_ARG(w && w_out && b_out && weff && Co > 0 && V > 0 && C > 0 && D > 0 && V * D + 1 <= CS && taps > 0, "lfq_fold_weights_fwd: bad argument");
-  const long total = (long)(per_var ? V * Co : Co) * CS * taps;
-  hipLaunchKernelGGL(fold_fwd_kernel, dim3(imin(cdiv(total, 256), 1024)), dim3(256), 0, (hipStream_t)stream, w, w_out, b_out, weff, Co, V, C, D, CS, taps, per_var);
+                                         int D, int CP, int per_var, idee_stream_t stream) {
+  IDEE_CHECK_ARG(w && w_out && b_out && weff && Co > 0 && V > 0 && C > 0 && D > 0 && 2 * (V * D + 1) <= CP, "lfq_fold_weights_fwd: bad argument");
+  const long total = (long)(per_var ? V * Co : Co) * CP * 9;
+  hipLaunchKernelGGL(fold_fwd_kernel, dim3(imin(cdiv(total, 256), 1024)), dim3(256), 0, (hipStream_t)stream, w, w_out, b_out, weff, Co, V, C, D, CP, per_var);
   IDEE_LAUNCH_CHECK("lfq_fold_weights_fwd");
   return IDEE_OK;
 }
 extern "C" int idee_lfq_fold_weights_bwd(const float* dweff, const float* w, const float* w_out, const float* b_out, float* dw,
-                                         float* dw_out, float* db_out, int Co, int V, int C, int D, int CS, int taps, int per_var,
+                                         float* dw_out, float* db_out, int Co, int V, int C, int D, int CP, int per_var,
                                          idee_stream_t stream) {
-  IDEE_CHECK_ARG(dweff && w && w_out && b_out && dw && dw_out && db_out && Co > 0 && V > 0 && C > 0 && D > 0 && V * D + 1 <= CS && taps > 0,
+  IDEE_CHECK_ARG(dweff && w && w_out && b_out && dw && dw_out && db_out && Co > 0 && V > 0 && C > 0 && D > 0 && 2 * (V * D + 1) <= CP,
                  "lfq_fold_weights_bwd: bad argument");
-  const long total = (long)(per_var ? V * Co : Co) * (per_var ? 1 : V) * C * taps;
-  hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(imin(cdiv(total, 256), 1024)), dim3(256), 0, (hipStream_t)stream, dweff, w_out, b_out, dw, Co, V, C, D, CS, taps, per_var);
-  hipLaunchKernelGGL(fold_bwd_p_kernel, dim3(C * (D + 1)), dim3(256), 0, (hipStream_t)stream, dweff, w, dw_out, db_out, Co, V, C, D, CS, taps, per_var);
+  const long total = (long)(per_var ? V * Co : Co) * (per_var ? 1 : V) * C * 18;
+  hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(imin(cdiv(total, 256), 1024)), dim3(256), 0, (hipStream_t)stream, dweff, w_out, b_out, dw, Co, V, C, D, CP, per_var);
+  hipLaunchKernelGGL(fold_bwd_p_kernel, dim3(C * (D + 1)), dim3(256), 0, (hipStream_t)stream, dweff, w, dw_out, db_out, Co, V, C, D, CP, per_var);
   IDEE_LAUNCH_CHECK("lfq_fold_weights_bwd");
   return IDEE_OK;
 }

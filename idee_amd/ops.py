@@ -126,7 +126,7 @@ class ConvLayer:
         ygpu, ysU = y_units if y_units is not None else (0, 0)
         self.desc = L.ConvDesc(mode, B, wsets, T, H, W, Cin, Cout, *xs, *ys, int(relu), gpu, ygpu, sU, ysU)
         self.mode, self.B, self.wsets, self.Cin, self.Cout = mode, B, wsets, Cin, Cout
-        self.ntaps = 27 if mode == L.CONV_K333_REPLICATE else 18
+        self.ntaps = {L.CONV_K333_REPLICATE: 27, L.CONV_K233_S2_ZERO: 18, L.CONV_K133_ZERO: 9}[mode]
         self.packed_floats = L.load().idee_conv_packed_floats(C.byref(self.desc))
         self.wgrad_floats = L.load().idee_conv_wgrad_floats(C.byref(self.desc))
 
@@ -285,8 +285,9 @@ class ClassifierHeads(torch.autograd.Function):
 class ClassifierHeadsSigns(torch.autograd.Function):
     """ClassifierHeads fed by LFQ's sign bits instead of z_q (exact refactoring, see
     idee_hip.h "Rank-d classifier input"): z_q = b_out + signs @ w_out^T has rank d per variable, so both first
-    convolutions run on the (N,T,H,W,CS) sign field with weights folded through [w_out | b_out] — CS = 16 input
-    channels instead of V*C = 96 for the default model.  Layers 2 and 3 are those of ClassifierHeads.
+    convolutions run as (1,3,3) convolutions on the paired (N,T/2,H,W,CP) sign field with weights folded through
+    [w_out | b_out] — K = 9 taps x 16 channels instead of 18 x 96 for the default model.  Layers 2 and 3 are those of
+    ClassifierHeads.
       signs (N,V,T,H,W,D) +-1;  w_out (C,D), b_out (C): LFQ.project_out;  remaining arguments as ClassifierHeads."""
 
     @staticmethod
@@ -305,20 +306,20 @@ class ClassifierHeadsSigns(torch.autograd.Function):
         T1 = (T - 2) // 2 + 1
         T2 = (T1 - 2) // 2 + 1
         T3 = (T2 - 2) // 2 + 1
-        CS = ((V * D + 1 + 15) // 16) * 16
+        CS = ((2 * (V * D + 1) + 15) // 16) * 16        # both frames of a temporal pair side by side in the channels
         dev = signs.device
-        K = L.CONV_K233_S2_ZERO
+        K, KP = L.CONV_K233_S2_ZERO, L.CONV_K133_ZERO
         st = L.stream()
-        sx = torch.empty((N, T, H, W, CS), device=dev, dtype=torch.float32)
-        L.call("idee_lfq_sign_field_fwd", ptr(signs), ptr(sx), N, V, T * H * W, D, CS, st)
-        jwe = torch.empty((Dj, CS, 2, 3, 3), device=dev, dtype=torch.float32)
-        hwe = torch.empty((V * dim, CS, 2, 3, 3), device=dev, dtype=torch.float32)
-        L.call("idee_lfq_fold_weights_fwd", ptr(jw1), ptr(w_out), ptr(b_out), ptr(jwe), Dj, V, Cc, D, CS, 18, 0, st)
-        L.call("idee_lfq_fold_weights_fwd", ptr(hw1), ptr(w_out), ptr(b_out), ptr(hwe), dim, V, Cc, D, CS, 18, 1, st)
-        sxs = _cl_strides(T, H, W, CS)
-        j1 = ConvLayer(K, N, 1, T, H, W, CS, Dj, sxs, _cl_strides(T1, H, W, Dj), True)
+        sx = torch.empty((N, T1, H, W, CS), device=dev, dtype=torch.float32)
+        L.call("idee_lfq_sign_field_fwd", ptr(signs), ptr(sx), N, V, T, H * W, D, CS, st)
+        jwe = torch.empty((Dj, CS, 1, 3, 3), device=dev, dtype=torch.float32)
+        hwe = torch.empty((V * dim, CS, 1, 3, 3), device=dev, dtype=torch.float32)
+        L.call("idee_lfq_fold_weights_fwd", ptr(jw1), ptr(w_out), ptr(b_out), ptr(jwe), Dj, V, Cc, D, CS, 0, st)
+        L.call("idee_lfq_fold_weights_fwd", ptr(hw1), ptr(w_out), ptr(b_out), ptr(hwe), dim, V, Cc, D, CS, 1, st)
+        sxs = _cl_strides(T1, H, W, CS)
+        j1 = ConvLayer(KP, N, 1, T1, H, W, CS, Dj, sxs, _cl_strides(T1, H, W, Dj), True)
         # the heads' conv1 writes variable v's `dim` channels into slice v of ha1 (N,V,T1,H,W,dim)
-        h1 = ConvLayer(K, N, 1, T, H, W, CS, V * dim, sxs, (V * T1 * H * W * dim, H * W * dim, W * dim, dim, 16), True,
+        h1 = ConvLayer(KP, N, 1, T1, H, W, CS, V * dim, sxs, (V * T1 * H * W * dim, H * W * dim, W * dim, dim, 16), True,
                        y_units=(dim // 16, T1 * H * W * dim))
         j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True)
         j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False)
@@ -375,16 +376,16 @@ class ClassifierHeadsSigns(torch.autograd.Function):
         djw1, dhw1 = torch.empty_like(jw1), torch.empty_like(hw1)
         dw_out, db_out = torch.zeros_like(w_out), torch.zeros_like(b_out)
         L.call("idee_lfq_fold_weights_bwd", ptr(djwe), ptr(jw1), ptr(w_out), ptr(b_out), ptr(djw1), ptr(dw_out), ptr(db_out),
-               Dj, V, Cc, D, CS, 18, 0, st)
+               Dj, V, Cc, D, CS, 0, st)
         L.call("idee_lfq_fold_weights_bwd", ptr(dhwe), ptr(hw1), ptr(w_out), ptr(b_out), ptr(dhw1), ptr(dw_out), ptr(db_out),
-               dim, V, Cc, D, CS, 18, 1, st)
+               dim, V, Cc, D, CS, 1, st)
         dsigns = None
         if ctx.needs_input_grad[0]:
             dsx = torch.empty_like(sx)
             j1.dgrad(dja1, pd[0], None, dsx)
             h1.dgrad(dha1, pd[3], None, dsx, accumulate=True)
             dsigns = torch.empty((N, V, T, H, W, D), device=dev, dtype=torch.float32)
-            L.call("idee_lfq_sign_field_bwd", ptr(dsx), ptr(dsigns), N, V, T * H * W, D, CS, st)
+            L.call("idee_lfq_sign_field_bwd", ptr(dsx), ptr(dsigns), N, V, T, H * W, D, CS, st)
         return (dsigns, dw_out, db_out, djw1, djb1.reshape(-1), djw2, djb2.reshape(-1), djw3, djb3.reshape(-1), dhw1,
                 dhb1.reshape(V, dim), dhw2, dhb2, dhw3, dhb3)
 

@@ -104,13 +104,15 @@ int idee_relpos_bias_scatter(const float* ddense, const int64_t* index, float* d
  *       proj_var (Swin_3D.py:586-592, encoder/CNN_3D.py:185-191), conv_block convs (:99-106)
  *   IDEE_CONV_K233_S2_ZERO:   Conv3d((2,3,3), (2,1,1), (0,1,1)) zero padding
  *       classifier heads (classifier/CNN_3D.py:38-40, :83-85)
+ *   IDEE_CONV_K133_ZERO:      Conv3d((1,3,3), 1, (0,1,1)) zero padding — the same classifier conv with its two
+ *       temporal taps folded into the channels (frame pairs side by side); used on LFQ's paired sign field below
  * The descriptor speaks about the FORWARD conv: x (input, extent T,H,W) -> y (output extent
- * To,H,W with To = T or (T-2)/2+1).  Tensors are addressed by float strides so one kernel
+ * To,H,W with To = T, or (T-2)/2+1 for the stride-2 mode).  Tensors are addressed by float strides so one kernel
  * serves per-variable convs (B = N*V, wsets = V) and the joint head whose 16-channel groups
  * are the V slices of z_q (see x_gpu / x_sU).  Channel group g, channel c: + g*sG + c.
  * Cin must be a multiple of 16; Cout a multiple of 16, or 1 (final class conv).
  * ---------------------------------------------------------------------------------------- */
-enum { IDEE_CONV_K333_REPLICATE = 0, IDEE_CONV_K233_S2_ZERO = 1 };
+enum { IDEE_CONV_K333_REPLICATE = 0, IDEE_CONV_K233_S2_ZERO = 1, IDEE_CONV_K133_ZERO = 2 };
 
 typedef struct {
   int mode;
@@ -179,19 +181,20 @@ int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const floa
 
 /* ------------------------------------------------------------------------------------------
  * Rank-d classifier input (algebraic refactoring; exact in real arithmetic, disclosed in DESIGN.md):
- * z_q = b_out + sum_i q_i w_out[:, i], so the first convolutions of the classifier (classifier/CNN_3D.py:83,38 applied to
- * z_q at build.py:157) equal convolutions on the sign field S (N,T,H,W,CS): channel v*D+i = q_i of variable v,
- * channel V*D = 1, others 0, CS a multiple of 16 >= V*D+1 — with weights folded through [w_out | b_out].
- *   sign_field: signs (N,V,THW,D) <-> sx (N,THW,CS)
- *   fold: w (Co, V*C, taps) joint | (V, Co, C, taps) per_var -> weff (rows, CS, taps), rows = Co | V*Co;
+ * z_q = b_out + sum_i q_i w_out[:, i], so the first (2,3,3)-stride-2 convolutions of the classifier
+ * (classifier/CNN_3D.py:83,38 applied to z_q at build.py:157) equal IDEE_CONV_K133_ZERO convolutions on the paired sign
+ * field S (N,T/2,H,W,CP): with R = V*D+1, channel kt*R + v*D+i = q_i of variable v in frame 2*t1+kt, channel kt*R + V*D = 1,
+ * others 0; CP a multiple of 16 >= 2R — with weights folded through [w_out | b_out].
+ *   sign_field: signs (N,V,T,HW,D) <-> S (N,T/2,HW,CP)
+ *   fold: w (Co, V*C, 2,3,3) joint | (V, Co, C, 2,3,3) per_var -> weff (rows, CP, 1,3,3), rows = Co | V*Co;
  *         bwd: dw overwritten, dw_out (C,D) and db_out (C) accumulate.
  * ---------------------------------------------------------------------------------------- */
-int idee_lfq_sign_field_fwd(const float* signs, float* sx, int N, int V, long THW, int D, int CS, idee_stream_t stream);
-int idee_lfq_sign_field_bwd(const float* dsx, float* dsigns, int N, int V, long THW, int D, int CS, idee_stream_t stream);
+int idee_lfq_sign_field_fwd(const float* signs, float* sp, int N, int V, int T, long HW, int D, int CP, idee_stream_t stream);
+int idee_lfq_sign_field_bwd(const float* dsp, float* dsigns, int N, int V, int T, long HW, int D, int CP, idee_stream_t stream);
 int idee_lfq_fold_weights_fwd(const float* w, const float* w_out, const float* b_out, float* weff, int Co, int V, int C, int D,
-                              int CS, int taps, int per_var, idee_stream_t stream);
+                              int CP, int per_var, idee_stream_t stream);
 int idee_lfq_fold_weights_bwd(const float* dweff, const float* w, const float* w_out, const float* b_out, float* dw,
-                              float* dw_out, float* db_out, int Co, int V, int C, int D, int CS, int taps, int per_var,
+                              float* dw_out, float* db_out, int Co, int V, int C, int D, int CP, int per_var,
                               idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
