@@ -344,21 +344,30 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
   const int slab4 = slab / 4;
   const int NOT = (MODE == FWD_S2) ? a.kt : 1;            // T-slots
 
+  // a (b, t) plane is cut into 16-pixel column blocks, numbered row-major; a wave owns MT consecutive blocks (they
+  // may wrap to the next row), a workgroup WAVES * MT of them: no partially filled wave tiles at any width
+  const int nblk = a.Ho * a.nsub;
   for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
-    const int wt = tile % a.wtiles, r = tile / a.wtiles;
-    const int hg = r % a.hgroups, t = r / a.hgroups;
-    const int h = hg * WAVES + wave;
-    const bool row_ok = h < a.Ho;
-    const int my_mt = a.sub_base + (wt < a.sub_rem ? 1 : 0);
-    const int w0 = 16 * (wt * a.sub_base + min(wt, a.sub_rem));
+    const int tb = tile % a.hgroups, t = tile / a.hgroups;      // hgroups = workgroup tiles per plane
+    const int blk0 = (tb * WAVES + wave) * MT;
+    const bool row_ok = blk0 < nblk;
+    int hm[MT], wm[MT];
+    bool vm[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int blk = blk0 + m;
+      vm[m] = blk < nblk;
+      hm[m] = blk / a.nsub;
+      wm[m] = (blk - hm[m] * a.nsub) * 16 + j;
+      vm[m] = vm[m] && wm[m] < a.Wo;
+    }
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* in_b = a.in + (long)b * a.i_sB;
+    const float* in_b = a.in + (long)b * a.i_sB + 4 * kq;
 
-    // first slab
     const int ntap_it = NOT * 9;
     auto tap_of = [&](int it) {                            // iteration -> weight tap index
       const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
@@ -376,30 +385,27 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
       __syncthreads();
     }
 
-    // activations are prefetched one (tap, channel-block) step ahead, ACROSS tap boundaries: a tap whose source row
-    // is outside the frame (or a wave past the last row) loads nothing and multiplies zeros
-    struct TapSrc { const float* rowp; long off[MT]; bool okm[MT]; };
+    // activations are prefetched one (tap, channel-block) step ahead, ACROSS tap boundaries: a source pixel outside
+    // the frame loads nothing and multiplies zeros
+    struct TapSrc { long off[MT]; bool okm[MT]; };
     auto tap_src = [&](int it) {
       TapSrc s;
       const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
       const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
-      const Slot sh = slot_h<MODE>(oh, h, a.Hi);
-      const bool okr = row_ok && st.ok && sh.ok;
-      s.rowp = in_b + (long)(okr ? st.src : 0) * a.i_sT + (long)(okr ? sh.src : 0) * a.i_sH + 4 * kq;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int p = w0 + m * 16 + j;
+        const Slot sh = slot_h<MODE>(oh, hm[m], a.Hi);
         bool ok;
-        const int q = src_w<MODE>(ow, p, a.Wi, ok);
-        s.okm[m] = okr && ok && (p < a.Wo) && (m < my_mt);
-        s.off[m] = (long)q * a.i_sW;
+        const int q = src_w<MODE>(ow, wm[m], a.Wi, ok);
+        s.okm[m] = vm[m] && st.ok && sh.ok && ok;
+        s.off[m] = s.okm[m] ? (long)st.src * a.i_sT + (long)sh.src * a.i_sH + (long)q * a.i_sW : 0;
       }
       return s;
     };
     TapSrc cur = tap_src(0);
     f32x4 xc[MT], xn[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) xc[m] = cur.okm[m] ? ld4(cur.rowp + cur.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) xc[m] = cur.okm[m] ? ld4(in_b + cur.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int it = 0; it < ntap_it; ++it) {
       const float* wcur = RES ? s_wd + tap_of(it) * slab : s_wd + (it & 1) * slab;
@@ -417,10 +423,10 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
       for (int g = 0; g < a.Gk; ++g) {
         if (g + 1 < a.Gk) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) xn[m] = cur.okm[m] ? ld4(cur.rowp + cur.off[m] + goff(g + 1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int m = 0; m < MT; ++m) xn[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(g + 1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
         } else if (more) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) xn[m] = nxt.okm[m] ? ld4(nxt.rowp + nxt.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int m = 0; m < MT; ++m) xn[m] = nxt.okm[m] ? ld4(in_b + nxt.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (row_ok) {
 #pragma unroll
@@ -447,19 +453,18 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
     }
 
     if (!row_ok) continue;
-    float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
-    const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      if (m >= my_mt) continue;
-      const int p = w0 + m * 16 + j;
-      if (p >= a.Wo) continue;
+      if (!vm[m]) continue;
+      const long ro = (long)b * a.o_sB + (long)t * a.o_sT + (long)hm[m] * a.o_sH + (long)wm[m] * a.o_sW + 4 * kq;
+      float* out_r = a.out + ro;
+      const float* ref_r = a.relu_ref ? a.relu_ref + ro : nullptr;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         f32x4 v = acc[m][n];
         if (a.bias) v += ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq);
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const long o = (long)p * a.o_sW + goff(n, a.o_gpu, a.o_sU, a.o_sG) + 4 * kq;
+        const long o = goff(n, a.o_gpu, a.o_sU, a.o_sG);
         if (ref_r) {
           const f32x4 rr = ld4(ref_r + o);
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
@@ -1242,8 +1247,8 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   if constexpr (MODE == FWD_S2 || MODE == DGRAD_S2) {
     const long slab_bytes = (long)a.Gk * NT * 256 * 4;
     if (!cin1 && gz == 1 && (NT >= 2 || a.Gk >= 2) && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
-      a.hgroups = cdiv(a.Ho, 8);
-      a.tiles = a.To * a.hgroups * a.wtiles;
+      a.hgroups = cdiv((long)a.Ho * a.nsub, 32);            // workgroup tiles (8 waves x 4 column blocks) per plane
+      a.tiles = a.To * a.hgroups;
       const bool res = a.ntaps * slab_bytes <= 150 * 1024;      // every tap's weights stay in LDS
       const long lds_bytes = res ? a.ntaps * slab_bytes : 2 * slab_bytes;
 #define LCW2(NT_, RES_)                                                                                        \
