@@ -402,54 +402,92 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
       }
       return s;
     };
-    TapSrc cur = tap_src(0);
-    f32x4 xc[MT], xn[MT];
+    if constexpr (NT == 1 && RES) {
+      // one output block per wave (the data gradient into a 16-channel tensor): only 16 MFMAs per channel block, so the
+      // activations are prefetched a whole TAP ahead: block g of the next tap is requested as soon as block g of the
+      // current one has been multiplied (Gk <= 6, weights resident: no barriers)
+      constexpr int GKM = 6;
+      TapSrc cur = tap_src(0);
+      f32x4 xq[GKM][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) xc[m] = cur.okm[m] ? ld4(in_b + cur.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int it = 0; it < ntap_it; ++it) {
-      const float* wcur = RES ? s_wd + tap_of(it) * slab : s_wd + (it & 1) * slab;
-      float* wnext = s_wd + ((it + 1) & 1) * slab;
-      // prefetch the next slab into registers (up to 5 x 16 bytes per thread for a 6x6 slab)
-      f32x4 pre[5];
-      const bool more = it + 1 < ntap_it;
-      if (more && !RES) {
-        const float* src = wp + (long)tap_of(it + 1) * slab;
+      for (int g = 0; g < GKM; ++g)
+        if (g < a.Gk)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) pre[q] = ld4(src + 4 * u); }
-      }
-      TapSrc nxt = cur;
-      if (more) nxt = tap_src(it + 1);
-      for (int g = 0; g < a.Gk; ++g) {
-        if (g + 1 < a.Gk) {
+          for (int m = 0; m < MT; ++m)
+            xq[g][m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(g, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < ntap_it; ++it) {
+        const float* wcur = s_wd + tap_of(it) * slab;
+        const bool more = it + 1 < ntap_it;
+        TapSrc nxt = cur;
+        if (more) nxt = tap_src(it + 1);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) xn[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(g + 1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        } else if (more) {
-#pragma unroll
-          for (int m = 0; m < MT; ++m) xn[m] = nxt.okm[m] ? ld4(in_b + nxt.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (row_ok) {
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const f32x4 wf = ld4(wcur + (g * NT + n) * 256 + lane * 4);
+        for (int g = 0; g < GKM; ++g) {
+          if (g < a.Gk) {
+            const f32x4 wf = ld4(wcur + g * 256 + lane * 4);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
               for (int m = 0; m < MT; ++m)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xq[g][m][s], acc[m][0], 0, 0, 0);
+            if (more)
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                xq[g][m] = nxt.okm[m] ? ld4(in_b + nxt.off[m] + goff(g, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) xc[m] = xn[m];
+        cur = nxt;
       }
-      cur = nxt;
-      if constexpr (!RES) {
-        if (more) {
-#pragma unroll
-          for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) st4(wnext + 4 * u, pre[q]); }
+    } else {
+      TapSrc cur = tap_src(0);
+      f32x4 xc[MT], xn[MT];
+  #pragma unroll
+      for (int m = 0; m < MT; ++m) xc[m] = cur.okm[m] ? ld4(in_b + cur.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+      for (int it = 0; it < ntap_it; ++it) {
+        const float* wcur = RES ? s_wd + tap_of(it) * slab : s_wd + (it & 1) * slab;
+        float* wnext = s_wd + ((it + 1) & 1) * slab;
+        // prefetch the next slab into registers (up to 5 x 16 bytes per thread for a 6x6 slab)
+        f32x4 pre[5];
+        const bool more = it + 1 < ntap_it;
+        if (more && !RES) {
+          const float* src = wp + (long)tap_of(it + 1) * slab;
+  #pragma unroll
+          for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) pre[q] = ld4(src + 4 * u); }
         }
-        __syncthreads();
+        TapSrc nxt = cur;
+        if (more) nxt = tap_src(it + 1);
+        for (int g = 0; g < a.Gk; ++g) {
+          if (g + 1 < a.Gk) {
+  #pragma unroll
+            for (int m = 0; m < MT; ++m) xn[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(g + 1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          } else if (more) {
+  #pragma unroll
+            for (int m = 0; m < MT; ++m) xn[m] = nxt.okm[m] ? ld4(in_b + nxt.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          if (row_ok) {
+  #pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const f32x4 wf = ld4(wcur + (g * NT + n) * 256 + lane * 4);
+  #pragma unroll
+              for (int s = 0; s < 4; ++s)
+  #pragma unroll
+                for (int m = 0; m < MT; ++m)
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
+            }
+          }
+  #pragma unroll
+          for (int m = 0; m < MT; ++m) xc[m] = xn[m];
+        }
+        cur = nxt;
+        if constexpr (!RES) {
+          if (more) {
+  #pragma unroll
+            for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) st4(wnext + 4 * u, pre[q]); }
+          }
+          __syncthreads();
+        }
       }
+
     }
 
     if (!row_ok) continue;
@@ -1246,7 +1284,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   }
   if constexpr (MODE == FWD_S2 || MODE == DGRAD_S2) {
     const long slab_bytes = (long)a.Gk * NT * 256 * 4;
-    if (!cin1 && gz == 1 && (NT >= 2 || a.Gk >= 2) && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
+    if (!cin1 && gz == 1 && (NT >= 2 || (a.Gk >= 2 && a.Gk <= 6)) && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
       a.hgroups = cdiv((long)a.Ho * a.nsub, 32);            // workgroup tiles (8 waves x 4 column blocks) per plane
       a.tiles = a.To * a.hgroups;
       const bool res = a.ntaps * slab_bytes <= 150 * 1024;      // every tap's weights stay in LDS
