@@ -36,35 +36,50 @@ constexpr int VS = 68;  // LDS image row stride in floats (64 tokens + pad); row
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. at f32 rounding level): one rcp, one exp, five fma —
-// about half the instructions of erff(), which matters because GELU is the largest VALU item of the block.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.f - p * t * __expf(-ax * ax);
-  return copysignf(e, x);
-}
-__device__ __forceinline__ float gelu(float a) { return 0.5f * a * (1.f + erf_fast(a * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad(float a) {
-  return 0.5f * (1.f + erf_fast(a * 0.70710678118654752f)) + a * 0.39894228040143268f * __expf(-0.5f * a * a);
-}
+constexpr float kLog2e = 1.4426950408889634f;
 
-// gelu(a) and d gelu / da with ONE exp: exp(-a^2/2) serves both the erf tail and the Gaussian density
-__device__ __forceinline__ void gelu_both(float a, float& gl, float& dgl) {
-  const float x = a * 0.70710678118654752f, ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float E = __expf(-0.5f * a * a);
-  const float phi = 0.5f * (1.f + copysignf(1.f - p * t * E, x));   // Phi(a)
-  gl = a * phi;
-  dgl = fmaf(a * 0.39894228040143268f, E, phi);
+// gfx950 does not co-issue VALU work with the f32 MFMA (measured: tools/micro/coexec.hip), so every VALU instruction of
+// these kernels costs MFMA time.  The element-wise math below is therefore written on f32x4 values so that the compiler
+// emits PACKED f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of work per issue slot).
+__device__ __forceinline__ f32x4 splat(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float hsum(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// GELU(erf) with erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. at f32 rounding level):
+//   Phi(a) = 1 - q (a >= 0), q (a < 0),  q = 0.5 p(t) t exp(-a^2/2),  t = 1 / (1 + 0.3275911 |a| / sqrt2)
+//   gelu(a) = max(a, 0) - |a| q = 0.5 a + (0.5 |a| - |a| q)
+// One v_rcp and one v_exp per element; everything else packed.
+struct GeluParts { f32x4 ax, hq, E; };   // |a|, 0.5 - q, exp(-a^2/2)
+__device__ __forceinline__ GeluParts gelu_parts(f32x4 a) {
+  GeluParts g;
+  g.ax = __builtin_elementwise_abs(a);
+  const f32x4 den = fma4(g.ax, splat(0.3275911f * 0.70710678118654752f), splat(1.f));
+  f32x4 t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_rcpf(den[r]);
+  // -0.5 p(t): the sign and the half are folded into the coefficients (a negation would cost a v_xor per element)
+  f32x4 p = fma4(splat(-0.5f * 1.061405429f), t, splat(0.5f * 1.453152027f));
+  p = fma4(p, t, splat(-0.5f * 1.421413741f));
+  p = fma4(p, t, splat(0.5f * 0.284496736f));
+  p = fma4(p, t, splat(-0.5f * 0.254829592f));
+  const f32x4 ea = fma4(a * a, splat(-0.5f * kLog2e), splat(0.f));   // fma form keeps the constant multiply packed
+#pragma unroll
+  for (int r = 0; r < 4; ++r) g.E[r] = __builtin_amdgcn_exp2f(ea[r]);   // exp(-a^2/2)
+  g.hq = fma4(p * t, g.E, splat(0.5f));
+  return g;
+}
+__device__ __forceinline__ f32x4 gelu4(f32x4 a) {
+  const GeluParts g = gelu_parts(a);
+  return fma4(a, splat(0.5f), g.ax * g.hq);
+}
+// gelu(a) and d gelu / da = Phi(a) + a phi(a), sharing the exponential
+__device__ __forceinline__ void gelu_both4(f32x4 a, f32x4& gl, f32x4& dgl) {
+  const GeluParts g = gelu_parts(a);
+  gl = fma4(a, splat(0.5f), g.ax * g.hq);
+  f32x4 phi;                                       // Phi - 0.5 = +-(0.5 - q)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) phi[r] = copysignf(g.hq[r], a[r]);
+  dgl = fma4(a * splat(0.39894228040143268f), g.E, phi + splat(0.5f));
 }
 
 // All LDS in these kernels is private to a wave (indexed by the wave id), and the LDS unit executes one wave's
@@ -161,20 +176,17 @@ __device__ __forceinline__ void layer_norm_tl(const f32x4 (&x)[CT][M], f32x4 (&x
   constexpr float invC = 1.f / (16 * CT);
 #pragma unroll
   for (int m = 0; m < M; ++m) {
-    float s = 0.f;
+    f32x4 s4 = x[0][m];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) s += x[c][m][0] + x[c][m][1] + x[c][m][2] + x[c][m][3];
-    const float mean = chan_sum(s) * invC;
-    float v = 0.f;
+    for (int c = 1; c < CT; ++c) s4 += x[c][m];
+    const float mean = chan_sum(hsum(s4)) * invC;
+    f32x4 d[CT], v4 = splat(0.f);
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+    for (int c = 0; c < CT; ++c) { d[c] = x[c][m] - splat(mean); v4 = fma4(d[c], d[c], v4); }
+    rstd[m] = rsqrtf(chan_sum(hsum(v4)) * invC + kLnEps);
+    const float rk = keep[m] ? rstd[m] : 0.f;      // padded tokens normalise to exactly 0
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float d = x[c][m][r] - mean; v = fmaf(d, d, v); }
-    rstd[m] = rsqrtf(chan_sum(v) * invC + kLnEps);
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xn[c][m][r] = keep[m] ? (x[c][m][r] - mean) * rstd[m] : 0.f;
+    for (int c = 0; c < CT; ++c) xn[c][m] = d[c] * splat(rk);
   }
 }
 
@@ -325,12 +337,16 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(S[kt][qt][0], S[kt][qt][1]), fmaxf(S[kt][qt][2], S[kt][qt][3])));
           mx = chan_max(mx);
-          float l = 0.f;
+          const float mxl = -mx * kLog2e;
+          f32x4 l4 = splat(0.f);
 #pragma unroll
-          for (int kt = 0; kt < TPW; ++kt)
+          for (int kt = 0; kt < TPW; ++kt) {
+            const f32x4 ea = fma4(S[kt][qt], splat(kLog2e), splat(mxl));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { S[kt][qt][r] = __expf(S[kt][qt][r] - mx); l += S[kt][qt][r]; }
-          const float inv = __builtin_amdgcn_rcpf(chan_sum(l));   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
+            for (int r = 0; r < 4; ++r) S[kt][qt][r] = __builtin_amdgcn_exp2f(ea[r]);
+            l4 += S[kt][qt];
+          }
+          const float inv = __builtin_amdgcn_rcpf(chan_sum(hsum(l4)));   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) S[kt][qt] *= inv;
         }
@@ -377,9 +393,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
 #pragma unroll
     for (int o = 0; o < HT; ++o)
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) A1[o][m][r] = gelu(A1[o][m][r]);
+      for (int m = 0; m < MT; ++m) A1[o][m] = gelu4(A1[o][m]);
     f32x4 Y[CT][MT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -447,17 +461,13 @@ __device__ __forceinline__ void layer_norm_bwd_tl(const f32x4 (&dxn)[CT][M], con
   constexpr float invC = 1.f / (16 * CT);
 #pragma unroll
   for (int m = 0; m < M; ++m) {
-    float a = 0.f, b = 0.f;
+    f32x4 a4 = dxn[0][m], b4 = dxn[0][m] * xn[0][m];
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+    for (int c = 1; c < CT; ++c) { a4 += dxn[c][m]; b4 = fma4(dxn[c][m], xn[c][m], b4); }
+    const float a = chan_sum(hsum(a4)) * invC;
+    const float b = chan_sum(hsum(b4)) * invC;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a += dxn[c][m][r]; b = fmaf(dxn[c][m][r], xn[c][m][r], b); }
-    a = chan_sum(a) * invC;
-    b = chan_sum(b) * invC;
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dx[c][m][r] = rstd[m] * (dxn[c][m][r] - a - xn[c][m][r] * b) + add[c][m][r];
+    for (int c = 0; c < CT; ++c) dx[c][m] = fma4(splat(rstd[m]), (dxn[c][m] - splat(a)) - xn[c][m] * splat(b), add[c][m]);
   }
 }
 
@@ -562,13 +572,10 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
       for (int o = 0; o < HP; ++o)
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float gl, dgl;
-            gelu_both(A1[o][m][r], gl, dgl);
-            dG[o][m][r] *= dgl;               // dG now holds dA1
-            A1[o][m][r] = gl;                 // A1 now holds gelu(A1)
-          }
+          f32x4 gl, dgl;
+          gelu_both4(A1[o][m], gl, dgl);
+          dG[o][m] *= dgl;                    // dG now holds dA1
+          A1[o][m] = gl;                      // A1 now holds gelu(A1)
           pb1[hp * HP + o] += dG[o][m];
         }
       mm(dHN, w1t, dG);
@@ -773,25 +780,27 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(P[kt][qt][0], P[kt][qt][1]), fmaxf(P[kt][qt][2], P[kt][qt][3])));
           mx = chan_max(mx);
-          float l = 0.f;
+          const float mxl = -mx * kLog2e;
+          f32x4 l4 = splat(0.f);
 #pragma unroll
-          for (int kt = 0; kt < TPW; ++kt)
+          for (int kt = 0; kt < TPW; ++kt) {
+            const f32x4 ea = fma4(P[kt][qt], splat(kLog2e), splat(mxl));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { P[kt][qt][r] = __expf(P[kt][qt][r] - mx); l += P[kt][qt][r]; }
-          const float inv = __builtin_amdgcn_rcpf(chan_sum(l));   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
-          float D = 0.f;
+            for (int r = 0; r < 4; ++r) P[kt][qt][r] = __builtin_amdgcn_exp2f(ea[r]);
+            l4 += P[kt][qt];
+          }
+          const float inv = __builtin_amdgcn_rcpf(chan_sum(hsum(l4)));   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
+          f32x4 D4 = splat(0.f);
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) {
             P[kt][qt] *= inv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) D = fmaf(P[kt][qt][r], dP[kt][qt][r], D);
+            D4 = fma4(P[kt][qt], dP[kt][qt], D4);
           }
-          D = chan_sum(D);
-          if (kq == 0) { const int q = 16 * (grp * TPW + qt) + j; st_m[q] = mx; st_il[q] = inv; st_D[q] = D; }
+          const float D = chan_sum(hsum(D4));
+          if (kq == 0) { const int q = 16 * (grp * TPW + qt) + j; st_m[q] = mxl; st_il[q] = inv; st_D[q] = D; }   // max stored pre-scaled
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dP[kt][qt][r] = P[kt][qt][r] * (dP[kt][qt][r] - D);   // dP now holds dS
+            dP[kt][qt] = P[kt][qt] * (dP[kt][qt] - splat(D));   // dP now holds dS
             dB[h][kt][qt] += dP[kt][qt];
           }
         }
@@ -831,13 +840,13 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
               acc[0] += rq.x != rk ? -100.f : 0.f; acc[1] += rq.y != rk ? -100.f : 0.f;
               acc[2] += rq.z != rk ? -100.f : 0.f; acc[3] += rq.w != rk ? -100.f : 0.f;
             }
-            const f32x4 m4 = ld4(st_m + q0), il4 = ld4(st_il + q0), D4 = ld4(st_D + q0);
+            const f32x4 m4 = ld4(st_m + q0), il4 = ld4(st_il + q0), D4 = ld4(st_D + q0);   // m4 = -max * log2e
+            const f32x4 ea = fma4(acc, splat(kLog2e), m4);
+            f32x4 e;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = __expf(acc[r] - m4[r]) * il4[r];
-              PT[qt][kt][r] = p;
-              dST[qt][kt][r] = p * (accd[r] - D4[r]);
-            }
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(ea[r]);
+            PT[qt][kt] = e * il4;
+            dST[qt][kt] = PT[qt][kt] * (accd - D4);
           }
 #pragma unroll
         for (int kt = 0; kt < TPW; ++kt) {
