@@ -203,6 +203,21 @@ __device__ __forceinline__ void mm(f32x4 (&Y)[OT][M], const f32x4 (&wf)[OT][KT],
         for (int m = 0; m < M; ++m) Y[o][m] = MFMA(wf[o][k][s], X[k][m][s], Y[o][m]);
 }
 
+// the same with the weight fragments read from LDS (lane-fragment order: fragment (o, k) at ((o * KT + k) * 64 + lane) * 4)
+template <int OT, int KT, int M>
+__device__ __forceinline__ void mm_lds(f32x4 (&Y)[OT][M], const float* wl, const f32x4 (&X)[KT][M], int lane) {
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const f32x4 w = ld4(wl + (o * KT + k) * 256 + lane * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < M; ++m) Y[o][m] = MFMA(w[s], X[k][m][s], Y[o][m]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -643,39 +658,64 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
   g_qkv_w += (long)v * 3 * C * C;  g_qkv_b += v * 3 * C;  g_proj_w += (long)v * C * C;  g_proj_b += v * C;
   g_rel_bias += (long)v * NH * NW * NW;
 
-  f32x4 wq[3 * CT][CT], bq[3 * CT], wpt[CT][CT], wqt[CT][3 * CT];
+  // Weight fragments and the relative-position bias tiles (both orientations) live in LDS in lane-fragment order
+  // (tile i, lane l -> 16 bytes at (i * 64 + l) * 4): the same for every wave of the workgroup, read with one
+  // ds_read_b128 where used.  Keeping them in registers (136 per lane at C = 16) forced the accumulators of this
+  // kernel through AGPR copies and scratch.
+  constexpr int NRB = NH * TPW * TPW;
+  constexpr int W_Q = 0, W_QT = 3 * CT * CT, W_PT = 6 * CT * CT, W_BQ = 7 * CT * CT, NWF = 7 * CT * CT + 3 * CT;
+  __shared__ __attribute__((aligned(16))) float s_rb[2 * NRB * 256];
+  __shared__ __attribute__((aligned(16))) float s_wf[NWF * 256];
+  {
+    int i = 0;
 #pragma unroll
-  for (int o = 0; o < 3 * CT; ++o) {
-    const float mul = o < CT ? g.scale : 1.f;
-    bq[o] = vfrag<HPC>(qkv_b, 16 * o, lane, mul);
+    for (int o = 0; o < 3 * CT; ++o) {
+      const float mul = o < CT ? g.scale : 1.f;
+      if ((i++) % WPB == wave) st4(s_wf + (W_BQ + o) * 256 + lane * 4, vfrag<HPC>(qkv_b, 16 * o, lane, mul));
 #pragma unroll
-    for (int k = 0; k < CT; ++k) {
-      wq[o][k] = wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul);
-      wqt[k][o] = wfrag<true, 1, HPC>(qkv_w, C, 16 * k, 16 * o, lane, mul);   // [c][o] = qkv_w[o][c] (q rows carry the scale)
+      for (int k = 0; k < CT; ++k) {
+        if ((i++) % WPB == wave) st4(s_wf + (W_Q + o * CT + k) * 256 + lane * 4, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul));
+        // [c][o] = qkv_w[o][c] (q rows carry the scale)
+        if ((i++) % WPB == wave) st4(s_wf + (W_QT + k * 3 * CT + o) * 256 + lane * 4, wfrag<true, 1, HPC>(qkv_w, C, 16 * k, 16 * o, lane, mul));
+      }
     }
+#pragma unroll
+    for (int o = 0; o < CT; ++o)
+#pragma unroll
+      for (int k = 0; k < CT; ++k)   // [c'][c] = proj_w[c][c']
+        if ((i++) % WPB == wave) st4(s_wf + (W_PT + o * CT + k) * 256 + lane * 4, wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane));
+    // bias in both orientations: rb rows = keys, col = query ; rbT rows = queries, col = key
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt) {
+          if ((i++) % WPB != wave) continue;
+          f32x4 f, fT;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
+            f[r] = (key / NW) == (qry / NW) ? rel_bias[(h * NW + qry % NW) * NW + key % NW] : -1e30f;
+            const int qry2 = 16 * qt + 4 * kq + r, key2 = 16 * kt + j;
+            fT[r] = (key2 / NW) == (qry2 / NW) ? rel_bias[(h * NW + qry2 % NW) * NW + key2 % NW] : -1e30f;
+          }
+          const int ti = (h * TPW + kt) * TPW + qt;
+          st4(s_rb + ti * 256 + lane * 4, f);
+          st4(s_rb + (NRB + ti) * 256 + lane * 4, fT);
+        }
+    __syncthreads();
   }
-#pragma unroll
-  for (int o = 0; o < CT; ++o)
-#pragma unroll
-    for (int k = 0; k < CT; ++k) wpt[o][k] = wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane);   // [c'][c] = proj_w[c][c']
-
-  // bias in both orientations: rb rows = keys, col = query ; rbT rows = queries, col = key
-  f32x4 rb[NH][TPW][TPW], rbT[NH][TPW][TPW], dB[NH][TPW][TPW];
+  auto WF = [&](int i) { return ld4(s_wf + i * 256 + lane * 4); };
+  auto RB = [&](int h, int kt, int qt) { return ld4(s_rb + ((h * TPW + kt) * TPW + qt) * 256 + lane * 4); };
+  auto RBT = [&](int h, int kt, int qt) { return ld4(s_rb + (NRB + (h * TPW + kt) * TPW + qt) * 256 + lane * 4); };
+  f32x4 dB[NH][TPW][TPW];
 #pragma unroll
   for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int kt = 0; kt < TPW; ++kt)
 #pragma unroll
-      for (int qt = 0; qt < TPW; ++qt) {
-        dB[h][kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
-          rb[h][kt][qt][r] = (key / NW) == (qry / NW) ? rel_bias[(h * NW + qry % NW) * NW + key % NW] : -1e30f;
-          const int qry2 = 16 * qt + 4 * kq + r, key2 = 16 * kt + j;
-          rbT[h][kt][qt][r] = (key2 / NW) == (qry2 / NW) ? rel_bias[(h * NW + qry2 % NW) * NW + key2 % NW] : -1e30f;
-        }
-      }
+      for (int qt = 0; qt < TPW; ++qt) dB[h][kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 aWq[3 * CT][CT], aWp[CT][CT], pbq[3 * CT], pbp[CT];
 #pragma unroll
   for (int o = 0; o < 3 * CT; ++o) {
@@ -721,17 +761,19 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
     layer_norm_tl(X, XN, rstd, keep);
     f32x4 QKV[3 * CT][MT];
 #pragma unroll
-    for (int o = 0; o < 3 * CT; ++o)
+    for (int o = 0; o < 3 * CT; ++o) {
+      const f32x4 bqo = WF(W_BQ + o);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) QKV[o][m] = bq[o];
-    mm(QKV, wq, XN);
+      for (int m = 0; m < MT; ++m) QKV[o][m] = bqo;
+    }
+    mm_lds(QKV, s_wf + W_Q * 256, XN, lane);
     // dO = proj_w^T dH  (TL with the head permutation, like V and O)
     f32x4 DO[CT][MT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int m = 0; m < MT; ++m) { DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pbp[c] += DH[c][m]; }
-    mm(DO, wpt, DH);
+    mm_lds(DO, s_wf + W_PT * 256, DH, lane);
 
     wave_sync();   // previous iteration's image readers are done
 #pragma unroll
@@ -759,7 +801,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
         for (int kt = 0; kt < TPW; ++kt)
 #pragma unroll
           for (int qt = 0; qt < TPW; ++qt) {
-            f32x4 acc = rb[h][kt][qt], accd = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = RB(h, kt, qt), accd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < SP; ++s) {
               acc = MFMA(QKV[CT + c][grp * TPW + kt][s0 + s], QKV[c][grp * TPW + qt][s0 + s], acc);
@@ -827,7 +869,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
         for (int qt = 0; qt < TPW; ++qt)
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) {
-            f32x4 acc = rbT[h][kt][qt], accd = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = RBT(h, kt, qt), accd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < SP; ++s) {
               acc = MFMA(QKV[c][grp * TPW + qt][s0 + s], QKV[CT + c][grp * TPW + kt][s0 + s], acc);
@@ -883,15 +925,17 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
     for (int oc = 0; oc < CT; ++oc)
 #pragma unroll
-      for (int k = 0; k < CT; ++k)
+      for (int k = 0; k < CT; ++k) {
+        const f32x4 wa = WF(W_QT + oc * 3 * CT + k), wb = WF(W_QT + oc * 3 * CT + CT + k), wc = WF(W_QT + oc * 3 * CT + 2 * CT + k);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            dXN[oc][m] = MFMA(wqt[oc][k][s], DQ[k][m][s], dXN[oc][m]);
-            dXN[oc][m] = MFMA(wqt[oc][CT + k][s], DK[k][m][s], dXN[oc][m]);
-            dXN[oc][m] = MFMA(wqt[oc][2 * CT + k][s], DV[k][m][s], dXN[oc][m]);
+            dXN[oc][m] = MFMA(wa[s], DQ[k][m][s], dXN[oc][m]);
+            dXN[oc][m] = MFMA(wb[s], DK[k][m][s], dXN[oc][m]);
+            dXN[oc][m] = MFMA(wc[s], DV[k][m][s], dXN[oc][m]);
           }
+      }
     f32x4 DX[CT][MT];
     layer_norm_bwd_tl(dXN, XN, rstd, DH, DX);
 #pragma unroll
