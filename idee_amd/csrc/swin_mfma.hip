@@ -106,9 +106,9 @@ struct Tok {
 };
 
 // token tau (0..63) of work item `item` of batch item b
-template <int NW>
+template <int NW, int TOK = 64>
 __device__ __forceinline__ Tok locate(const Geom& g, int b, int item, int tau, int C) {
-  constexpr int G = 64 / NW;
+  constexpr int G = TOK / NW;
   Tok t;
   const int gi = tau / NW, i = tau % NW;
   const int wl = item * G + gi;
@@ -429,18 +429,18 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
 // ---------------------------------------------------------------------------------------------
 
 // TL tile -> image rows in REAL channel order (permutation HS undone on the way out)
-template <int HS, int M>
+template <int HS, int M, int VSN = VS>
 __device__ __forceinline__ void put_img(float* img, const f32x4 (&T)[M], int lane) {
   const int j = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int m = 0; m < M; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) img[sig<HS>(4 * kq + r) * VS + 16 * m + j] = T[m][r];
+    for (int r = 0; r < 4; ++r) img[sig<HS>(4 * kq + r) * VSN + 16 * m + j] = T[m][r];
 }
 // acc[m][n] += sum_tok A[m][tok] B[n][tok]   over the wave's 64 tokens
-template <int M = MT>
+template <int M = MT, int VSN = VS>
 __device__ __forceinline__ void gemm_tok(f32x4& acc, const float* A, const float* B, int lane) {
-  const int row = (lane & 15) * VS + 4 * (lane >> 4);
+  const int row = (lane & 15) * VSN + 4 * (lane >> 4);
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const f32x4 fa = ld4(A + row + 16 * m), fb = ld4(B + row + 16 * m);
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
 // backward, part 2: attention + norm1.  in: x (block input), dh (from part 1).  out: dx and the
 // gradients of qkv / proj / relative-position bias.  Everything is recomputed from x.
 // ---------------------------------------------------------------------------------------------
-template <int C, int NH, int NW, int WPB>
+template <int C, int NH, int NW, int WPB, int MTK /*16-token column blocks per wave and work item*/>
 __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dh, float* __restrict__ dx, const float* __restrict__ qkv_w,
     const float* __restrict__ qkv_b, const float* __restrict__ proj_w, const float* __restrict__ rel_bias,
@@ -643,12 +643,14 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
   constexpr int CT = C / 16, HD = C / NH;
   static_assert(C % 16 == 0 && HD <= 16 && 16 % HD == 0, "head_dim must divide 16");
   constexpr int HPC = 16 / HD, SP = 4 / HPC;
-  constexpr int TPW = NW >= 16 ? NW / 16 : 1, NG = MT / TPW;
-  constexpr int IMG = 16 * VS;
+  constexpr int TPW = NW >= 16 ? NW / 16 : 1, NG = MTK / TPW;
+  static_assert(MTK % TPW == 0 && NG >= 1, "a work item holds whole windows");
+  constexpr int VSK = 16 * MTK + 4;   // image row stride (floats)
+  constexpr int IMG = 16 * VSK;
   // per wave, images [channel][token]: [0,CT) K  [CT,2CT) Q  [2CT,3CT) V  [3CT,4CT) dO  [4CT,5CT) scratch B  [5CT] scratch A
   __shared__ __attribute__((aligned(16))) float s_img[WPB][(5 * CT + 1) * IMG];
-  __shared__ __attribute__((aligned(16))) int s_rid[WPB][64];
-  __shared__ __attribute__((aligned(16))) float s_stat[WPB][3][64];   // per query: max, 1/l, D  (current group/head)
+  __shared__ __attribute__((aligned(16))) int s_rid[WPB][16 * MTK];
+  __shared__ __attribute__((aligned(16))) float s_stat[WPB][3][16 * MTK];   // per query: max, 1/l, D  (current group/head)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -743,12 +745,12 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
   float* st_D = s_stat[wave][2];
 
   for (int it0 = blockIdx.x * WPB; it0 < g.items; it0 += gridDim.x * WPB) {
-    Tok t[MT];
-    bool keep[MT];
-    f32x4 X[CT][MT], DH[CT][MT];
+    Tok t[MTK];
+    bool keep[MTK];
+    f32x4 X[CT][MTK], DH[CT][MTK];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      t[m] = locate<NW>(g, b, it0 + wave, 16 * m + j, C);
+    for (int m = 0; m < MTK; ++m) {
+      t[m] = locate<NW, 16 * MTK>(g, b, it0 + wave, 16 * m + j, C);
       keep[m] = t[m].valid;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
@@ -756,45 +758,45 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
         DH[c][m] = t[m].valid ? ld4(dh + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    f32x4 XN[CT][MT];
-    float rstd[MT];
+    f32x4 XN[CT][MTK];
+    float rstd[MTK];
     layer_norm_tl(X, XN, rstd, keep);
-    f32x4 QKV[3 * CT][MT];
+    f32x4 QKV[3 * CT][MTK];
 #pragma unroll
     for (int o = 0; o < 3 * CT; ++o) {
       const f32x4 bqo = WF(W_BQ + o);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) QKV[o][m] = bqo;
+      for (int m = 0; m < MTK; ++m) QKV[o][m] = bqo;
     }
     mm_lds(QKV, s_wf + W_Q * 256, XN, lane);
     // dO = proj_w^T dH  (TL with the head permutation, like V and O)
-    f32x4 DO[CT][MT];
+    f32x4 DO[CT][MTK];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) { DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pbp[c] += DH[c][m]; }
+      for (int m = 0; m < MTK; ++m) { DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pbp[c] += DH[c][m]; }
     mm_lds(DO, s_wf + W_PT * 256, DH, lane);
 
     wave_sync();   // previous iteration's image readers are done
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-      put_img<HPC>(imgQ + c * IMG, QKV[c], lane);
-      put_img<HPC>(imgK + c * IMG, QKV[CT + c], lane);
-      put_img<HPC>(imgV + c * IMG, QKV[2 * CT + c], lane);
-      put_img<HPC>(imgDO + c * IMG, DO[c], lane);
+      put_img<HPC, MTK, VSK>(imgQ + c * IMG, QKV[c], lane);
+      put_img<HPC, MTK, VSK>(imgK + c * IMG, QKV[CT + c], lane);
+      put_img<HPC, MTK, VSK>(imgV + c * IMG, QKV[2 * CT + c], lane);
+      put_img<HPC, MTK, VSK>(imgDO + c * IMG, DO[c], lane);
     }
     if (kq == 0)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) rid_l[16 * m + j] = t[m].rid;
+      for (int m = 0; m < MTK; ++m) rid_l[16 * m + j] = t[m].rid;
     wave_sync();
 
-    f32x4 O[CT][MT], DQ[CT][MT], DK[CT][MT], DV[CT][MT];
+    f32x4 O[CT][MTK], DQ[CT][MTK], DK[CT][MTK], DV[CT][MTK];
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int c = h / HPC, s0 = (h % HPC) * SP;
-        const int hrow = (16 * c + sig<HPC>(lane & 15)) * VS + 4 * kq;   // image row of this lane's A-operand channel
+        const int hrow = (16 * c + sig<HPC>(lane & 15)) * VSK + 4 * kq;   // image row of this lane's A-operand channel
         // ---- row pass: S, P, dP with keys on rows, query on the column ----
         f32x4 P[TPW][TPW], dP[TPW][TPW];
 #pragma unroll
@@ -909,16 +911,16 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
     }
     // ---- proj / qkv weight gradients and dxn ----
     // dproj_w[c][c'] += dH[c] O[c'] ; dqkv_w[o][c] += dQKV[o] XN[c] ; K = tokens
-    f32x4 dXN[CT][MT];
+    f32x4 dXN[CT][MTK];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) dXN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MTK; ++m) dXN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the q gradient refers to the pre-scaled q: fold the scale into wqt (done) and into dWq / dbq here
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < MTK; ++m) {
         pbq[c] += DQ[c][m] * g.scale; pbq[CT + c] += DK[c][m]; pbq[2 * CT + c] += DV[c][m];
       }
     // dxn = Wqkv^T dQKV
@@ -930,16 +932,16 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
+          for (int m = 0; m < MTK; ++m) {
             dXN[oc][m] = MFMA(wa[s], DQ[k][m][s], dXN[oc][m]);
             dXN[oc][m] = MFMA(wb[s], DK[k][m][s], dXN[oc][m]);
             dXN[oc][m] = MFMA(wc[s], DV[k][m][s], dXN[oc][m]);
           }
       }
-    f32x4 DX[CT][MT];
+    f32x4 DX[CT][MTK];
     layer_norm_bwd_tl(dXN, XN, rstd, DH, DX);
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MTK; ++m)
       if (t[m].valid)
 #pragma unroll
         for (int c = 0; c < CT; ++c) st4(dx + t[m].off + 16 * c + 4 * kq, DX[c][m]);
@@ -948,30 +950,30 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
     for (int ca = 0; ca < CT; ++ca) {        // dproj_w rows (c) from dH, cols (c') from O
       wave_sync();
-      put_img<1>(imgA, DH[ca], lane);
+      put_img<1, MTK, VSK>(imgA, DH[ca], lane);
       if (ca == 0)
 #pragma unroll
-        for (int cb = 0; cb < CT; ++cb) put_img<HPC>(imgB + cb * IMG, O[cb], lane);
+        for (int cb = 0; cb < CT; ++cb) put_img<HPC, MTK, VSK>(imgB + cb * IMG, O[cb], lane);
       wave_sync();
 #pragma unroll
-      for (int cb = 0; cb < CT; ++cb) gemm_tok(aWp[ca][cb], imgA, imgB + cb * IMG, lane);
+      for (int cb = 0; cb < CT; ++cb) gemm_tok<MTK, VSK>(aWp[ca][cb], imgA, imgB + cb * IMG, lane);
     }
     wave_sync();
 #pragma unroll
-    for (int cb = 0; cb < CT; ++cb) put_img<1>(imgB + cb * IMG, XN[cb], lane);
+    for (int cb = 0; cb < CT; ++cb) put_img<1, MTK, VSK>(imgB + cb * IMG, XN[cb], lane);
 #pragma unroll
     for (int o = 0; o < 3 * CT; ++o) {
       wave_sync();
       if (o < CT) {
-        f32x4 tmp[MT];
+        f32x4 tmp[MTK];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) tmp[m] = DQ[o][m] * g.scale;
-        put_img<HPC>(imgA, tmp, lane);
-      } else if (o < 2 * CT) put_img<HPC>(imgA, DK[o - CT], lane);
-      else put_img<HPC>(imgA, DV[o - 2 * CT], lane);
+        for (int m = 0; m < MTK; ++m) tmp[m] = DQ[o][m] * g.scale;
+        put_img<HPC, MTK, VSK>(imgA, tmp, lane);
+      } else if (o < 2 * CT) put_img<HPC, MTK, VSK>(imgA, DK[o - CT], lane);
+      else put_img<HPC, MTK, VSK>(imgA, DV[o - 2 * CT], lane);
       wave_sync();
 #pragma unroll
-      for (int cb = 0; cb < CT; ++cb) gemm_tok(aWq[o][cb], imgA, imgB + cb * IMG, lane);
+      for (int cb = 0; cb < CT; ++cb) gemm_tok<MTK, VSK>(aWq[o][cb], imgA, imgB + cb * IMG, lane);
     }
   }
 
@@ -1106,12 +1108,18 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
     }
     else return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: C=%d is not built", C);
   }
-  const int WPB = C == 16 ? 4 : 2;   // waves per workgroup (LDS images: 26 KB per wave at C=16, 48 KB at C=32)
-  const dim3 grid = swin_grid(cdiv(g.items, WPB), B, 1);
+  // C = 16: 32 tokens per wave and work item, 8 waves per workgroup (LDS images 13.8 KB per wave): at most 256 registers
+  // per lane, so two waves share a SIMD and one's LDS / global latency hides under the other's MFMA chain.
+  // C = 32: 64 tokens per wave, 2 waves (48 KB of images each).
+  const int WPB = C == 16 ? 8 : 2, MTK = C == 16 ? 2 : 4;
+  Geom ga = g;
+  ga.items = cdiv(g.nWin, (16 * MTK) / NW);
+  const dim3 grid = swin_grid(cdiv(ga.items, WPB), B, 1);
 #define CALL(C_, NH_, NW_)                                                                                           \
-  hipLaunchKernelGGL((swin_attn_bwd_kernel<C_, NH_, NW_, (C_ == 16 ? 4 : 2)>), grid, dim3(64 * (C_ == 16 ? 4 : 2)), 0, st, x, \
+  hipLaunchKernelGGL((swin_attn_bwd_kernel<C_, NH_, NW_, (C_ == 16 ? 8 : 2), (C_ == 16 ? 2 : 4)>), grid,             \
+                     dim3(64 * (C_ == 16 ? 8 : 2)), 0, st, x,                                                        \
                      dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,    \
-                     d->proj_b, d->rel_bias, g)
+                     d->proj_b, d->rel_bias, ga)
   SWIN_DISPATCH(CALL)
 #undef CALL
   IDEE_LAUNCH_CHECK("swin_block_bwd");
