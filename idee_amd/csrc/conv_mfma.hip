@@ -718,67 +718,66 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, in
     const float* x_b = a.x + (long)b * a.x_sB;
     const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
 
-    for (int h = h0; h < h1; ++h) {
-      __syncthreads();   // previous row's readers are done
-      int slot_of[3];
-      bool ok_h[3], fresh[3];
-      int hsrc[3];
-#pragma unroll
-      for (int oh = 0; oh < 3; ++oh) {
-        int hs = h + oh - 1;
-        if (MODE == FWD_REP) { hs = min(max(hs, 0), a.H - 1); ok_h[oh] = true; }
-        else ok_h[oh] = hs >= 0 && hs < a.H;
-        const int slot = ((hs % 3) + 3) % 3;
-        slot_of[oh] = slot;
-        hsrc[oh] = hs;
-        fresh[oh] = false;
-        if (!ok_h[oh]) continue;
-        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
-        if (cur == hs) continue;
-        if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
-        fresh[oh] = true;
-      }
-      // phase 1: every global load of this row step (new source rows of all T-slots + the dy row) is issued before any
-      // LDS write — a load/wait/write loop would pay one L2 round trip per piece.  (rowlen * 4 <= 512 = one piece per thread)
+    // Row pipeline: while the MFMAs of row h run out of LDS, the global loads of row h+1 (its new source rows of all
+    // T-slots and its dy row) are already in flight into registers; they are written to LDS after the barrier that
+    // ends row h.  Every load of a row step is issued before any LDS write (a load/wait/write loop would pay one L2
+    // round trip per piece; rowlen * 4 <= 512 = one piece per thread).
+    const int px_ = tid >> 2, q4_ = tid & 3;
+    int slot_of[3] = {0, 0, 0};
+    bool ok_h[3] = {false, false, false};
+    // iteration h = h0 - 1 only stages the first row
+    for (int h = h0 - 1; h < h1; ++h) {
+      const bool more = h + 1 < h1;
+      int n_slot[3] = {0, 0, 0}, n_hsrc[3] = {0, 0, 0};
+      bool n_ok[3] = {false, false, false}, n_fresh[3] = {false, false, false};
       f32x4 stg[3][TSL], stg_dy = {0.f, 0.f, 0.f, 0.f};
-      const int px_ = tid >> 2, q4_ = tid & 3;
+      if (more) {
+        const int hn = h + 1;
 #pragma unroll
-      for (int oh = 0; oh < 3; ++oh) {
+        for (int oh = 0; oh < 3; ++oh) {
+          int hs = hn + oh - 1;
+          if (MODE == FWD_REP) { hs = min(max(hs, 0), a.H - 1); n_ok[oh] = true; }
+          else n_ok[oh] = hs >= 0 && hs < a.H;
+          const int slot = ((hs % 3) + 3) % 3;
+          n_slot[oh] = slot;
+          n_hsrc[oh] = hs;
+          if (!n_ok[oh]) continue;
+          const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+          if (cur == hs) continue;
+          if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
+          n_fresh[oh] = true;
+        }
 #pragma unroll
-        for (int ts = 0; ts < TSL; ++ts) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (fresh[oh] && tid < rowlen * 4) {
-            const int tsrc = MODE == FWD_REP ? min(max(t + ts - 1, 0), a.T - 1) : 2 * t + ts;
-            const float* src = x_b + (long)tsrc * a.x_sT + (long)hsrc[oh] * a.x_sH;
-            int w = w0 + px_ - 1;
-            if (MODE == FWD_REP) { w = min(max(w, 0), a.W - 1); v = ld4(src + (long)w * a.x_sW + 4 * q4_); }
-            else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * q4_);
+        for (int oh = 0; oh < 3; ++oh) {
+#pragma unroll
+          for (int ts = 0; ts < TSL; ++ts) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n_fresh[oh] && tid < rowlen * 4) {
+              const int tsrc = MODE == FWD_REP ? min(max(t + ts - 1, 0), a.T - 1) : 2 * t + ts;
+              const float* src = x_b + (long)tsrc * a.x_sT + (long)n_hsrc[oh] * a.x_sH;
+              int w = w0 + px_ - 1;
+              if (MODE == FWD_REP) { w = min(max(w, 0), a.W - 1); v = ld4(src + (long)w * a.x_sW + 4 * q4_); }
+              else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * q4_);
+            }
+            stg[oh][ts] = v;
           }
-          stg[oh][ts] = v;
+        }
+        if (tid < segp * 4) {
+          const int w = w0 + px_;
+          if (px_ < seg && w < a.W) stg_dy = ld4(dy_b + (long)hn * a.y_sH + (long)w * a.y_sW + 4 * q4_);
         }
       }
-      if (tid < segp * 4) {
-        const int w = w0 + px_;
-        if (px_ < seg && w < a.W) stg_dy = ld4(dy_b + (long)h * a.y_sH + (long)w * a.y_sW + 4 * q4_);
-      }
-      // phase 2: LDS writes
-#pragma unroll
-      for (int oh = 0; oh < 3; ++oh) {
-        if (!fresh[oh] || tid >= rowlen * 4) continue;
-#pragma unroll
-        for (int ts = 0; ts < TSL; ++ts) st4(s_x + ((long)(ts * 3 + slot_of[oh]) * rowlen + px_) * 16 + 4 * q4_, stg[oh][ts]);
-      }
-      if (tid < segp * 4) st4(s_dy + px_ * 16 + 4 * q4_, stg_dy);
-      __syncthreads();
-
+      if (h >= h0) {
       int base[TPWV];
       bool okt[TPWV];
 #pragma unroll
       for (int k = 0; k < TPWV; ++k) {
         const int tap = wave + k * WAVES;
         const int ot = tap / 9, oh = (tap / 3) % 3, ow = tap % 3;
-        okt[k] = tap < NTAPS && ok_h[oh % 3];
-        base[k] = ((ot * 3 + slot_of[oh % 3]) * rowlen + ow + kq) * 16 + r16;
+        const bool okh = oh == 0 ? ok_h[0] : oh == 1 ? ok_h[1] : ok_h[2];              // selects: a runtime index would
+        const int slot = oh == 0 ? slot_of[0] : oh == 1 ? slot_of[1] : slot_of[2];     // put the arrays in scratch
+        okt[k] = tap < NTAPS && okh;
+        base[k] = ((ot * 3 + slot) * rowlen + ow + kq) * 16 + r16;
       }
       const int steps = segp >> 2;
       // branch-free inner loops when this wave's taps are all live (always in the replicate mode, interior rows otherwise)
@@ -818,6 +817,20 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, in
           }
         }
       }
+      }
+      if (more) {
+        __syncthreads();   // this row's readers are done: the ring slot of row h-1 and the dy row may be overwritten
+#pragma unroll
+        for (int oh = 0; oh < 3; ++oh) {
+          if (!n_fresh[oh] || tid >= rowlen * 4) continue;
+#pragma unroll
+          for (int ts = 0; ts < TSL; ++ts) st4(s_x + ((long)(ts * 3 + n_slot[oh]) * rowlen + px_) * 16 + 4 * q4_, stg[oh][ts]);
+        }
+        if (tid < segp * 4) st4(s_dy + px_ * 16 + 4 * q4_, stg_dy);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) { slot_of[oh] = n_slot[oh]; ok_h[oh] = n_ok[oh]; }
     }
   }
   float* dw = a.dwp + (long)wset * NTAPS * 16 * 16;
