@@ -517,6 +517,8 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // 16 -> 16 3x3x3 replicate convolution, forward and data gradient, activations staged through LDS.
+// (LDS row layout [channel quad][pixel][4 channels]: the 16 lanes of a quad read consecutive 16-byte chunks — the
+// pixel-major layout [pixel][16] put every other lane on the same banks.)
 // Every WAVE works alone: it owns a strip of 2 column blocks (32 pixels) and walks a run of output rows for a
 // fixed (batch item, t), keeping in its private 19.6 KB of LDS, for each of the 3 T-slots, a ring of 3 source
 // rows with a one-pixel halo (replicate clamp resp. zero padding resolved while staging).  Moving down one row
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int u = lane + 64 * k;
-            if (u < rowlen * 4) st4(dst + (u >> 2) * 16 + 4 * (u & 3), stg[ot][k]);
+            if (u < rowlen * 4) st4(dst + (u & 3) * (kC16Row * 4) + (u >> 2) * 4, stg[ot][k]);   // [channel quad][pixel][4]
           }
         }
       }
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
       for (int ot = 0; ot < 3; ++ot) {
 #pragma unroll
         for (int oh = 0; oh < 3; ++oh) {
-          const float* rowp = s_x + ((long)(ot * 3 + slot_of[oh]) * kC16Row + j) * 16 + 4 * kq;
+          const float* rowp = s_x + (long)(ot * 3 + slot_of[oh]) * kC16Row * 16 + kq * (kC16Row * 4) + j * 4;
           const int sel = st[ot].tap * 3 + sh[oh].tap;               // weight row (uniform; differs from ot*3+oh only at edges of the dgrad)
 #pragma unroll
           for (int gs = 0; gs < 9; ++gs) {
@@ -631,8 +633,8 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
             for (int ow = 0; ow < 3; ++ow) {
               // staged index of the source pixel: fwd p + ow ; dgrad p - ow + 2   (p = column inside the strip)
               const int sh_px = (MODE == FWD_REP) ? ow : 2 - ow;
-              const f32x4 x0 = ld4(rowp + sh_px * 16);
-              const f32x4 x1 = ld4(rowp + (sh_px + blk1) * 16);
+              const f32x4 x0 = ld4(rowp + sh_px * 4);
+              const f32x4 x1 = ld4(rowp + (sh_px + blk1) * 4);
               const f32x4 wf = wr[gs * 3 + ow];
 #pragma unroll
               for (int s = 0; s < 4; ++s) {
