@@ -844,6 +844,153 @@ __global__ void fold_bwd_p_kernel(const float* __restrict__ dweff, const float* 
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// PatchMerging (Swin_3D.py:290-335; never instantiated by the reference's own configs, built for API parity):
+// gather 4 neighbours -> LayerNorm(4C, affine) -> Linear(4C -> 2C, no bias).  Sampling as the reference writes it:
+// x_q at (d, h, w) = (2 d2 + (q & 1), 2 h2 + (q & 1), 2 w2 + (q >> 1)) for D > 1, and with d = 0 for D == 1;
+// odd extents are zero-padded.  16 lanes per output token, C/4 input channels per lane.
+// -------------------------------------------------------------------------------------------
+template <int C>
+struct PMTok {
+  float v[C / 4];     // gathered input values of this lane (zero when padded)
+  long src;           // offset of the lane's first value in x, or -1
+  float mean, rstd;
+};
+template <int C>
+__device__ __forceinline__ PMTok<C> pm_gather(const float* __restrict__ x, long tok, long ntok, int D, int H, int W, int D2,
+                                               int H2, int W2, int l16) {
+  PMTok<C> t;
+  const int q = l16 >> 2, part = l16 & 3;
+  t.src = -1;
+#pragma unroll
+  for (int k = 0; k < C / 4; ++k) t.v[k] = 0.f;
+  if (tok < ntok) {
+    long r = tok;
+    const int w2 = (int)(r % W2); r /= W2;
+    const int h2 = (int)(r % H2); r /= H2;
+    const int d2 = (int)(r % D2); const long b = r / D2;
+    const int d = D == 1 ? 0 : 2 * d2 + (q & 1), h = 2 * h2 + (q & 1), w = 2 * w2 + (q >> 1);
+    if (d < D && h < H && w < W) {
+      t.src = ((((long)b * D + d) * H + h) * W + w) * C + part * (C / 4);
+#pragma unroll
+      for (int k = 0; k < C / 16; ++k) {
+        const f32x4 f = ld4(x + t.src + 4 * k);
+        t.v[4 * k] = f[0]; t.v[4 * k + 1] = f[1]; t.v[4 * k + 2] = f[2]; t.v[4 * k + 3] = f[3];
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < C / 4; ++k) s += t.v[k];
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+  t.mean = s * (1.f / (4 * C));
+  float vs = 0.f;
+#pragma unroll
+  for (int k = 0; k < C / 4; ++k) { const float dlt = t.v[k] - t.mean; vs = fmaf(dlt, dlt, vs); }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) vs += __shfl_xor(vs, o, 64);
+  t.rstd = rsqrtf(vs * (1.f / (4 * C)) + 1e-5f);
+  return t;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void patch_merging_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ w,
+                                                                float* __restrict__ y, long ntok, int D, int H, int W, int D2,
+                                                                int H2, int W2) {
+  constexpr int K = 4 * C, O = 2 * C;
+  __shared__ float s_w[O][K + 1];
+  __shared__ float s_xn[16][K];
+  const int tid = threadIdx.x, tl = tid >> 4, l16 = tid & 15;
+  for (int e = tid; e < O * K; e += 256) s_w[e / K][e % K] = w[e];
+  const int i0 = (l16 >> 2) * C + (l16 & 3) * (C / 4);     // this lane's first index in the 4C vector
+  for (long base = (long)blockIdx.x * 16; base < ntok; base += (long)gridDim.x * 16) {
+    const long tok = base + tl;
+    const PMTok<C> t = pm_gather<C>(x, tok, ntok, D, H, W, D2, H2, W2, l16);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) s_xn[tl][i0 + k] = (t.v[k] - t.mean) * t.rstd * gamma[i0 + k] + beta[i0 + k];
+    __syncthreads();
+    if (tok < ntok) {
+#pragma unroll
+      for (int oo = 0; oo < O / 16; ++oo) {
+        const int o = l16 * (O / 16) + oo;
+        float acc = 0.f;
+        for (int i = 0; i < K; ++i) acc = fmaf(s_xn[tl][i], s_w[o][i], acc);
+        y[tok * O + o] = acc;
+      }
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void patch_merging_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ w, float* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float* __restrict__ dw, long ntok, int D, int H, int W, int D2,
+                                                                int H2, int W2) {
+  constexpr int K = 4 * C, O = 2 * C, WPT = O * K / 256;   // dW entries per thread
+  __shared__ float s_w[O][K + 1];
+  __shared__ float s_xa[16][K];     // affine-normalised inputs (the Linear's input)
+  __shared__ float s_dy[16][O];
+  const int tid = threadIdx.x, tl = tid >> 4, l16 = tid & 15;
+  for (int e = tid; e < O * K; e += 256) s_w[e / K][e % K] = w[e];
+  const int i0 = (l16 >> 2) * C + (l16 & 3) * (C / 4);
+  float aw[WPT], ag[C / 4], ab[C / 4];
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) aw[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < C / 4; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+  for (long base = (long)blockIdx.x * 16; base < ntok; base += (long)gridDim.x * 16) {
+    const long tok = base + tl;
+    const PMTok<C> t = pm_gather<C>(x, tok, ntok, D, H, W, D2, H2, W2, l16);
+    __syncthreads();
+    float xh[C / 4];
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) {
+      xh[k] = (t.v[k] - t.mean) * t.rstd;
+      s_xa[tl][i0 + k] = tok < ntok ? xh[k] * gamma[i0 + k] + beta[i0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int oo = 0; oo < O / 16; ++oo) s_dy[tl][l16 * (O / 16) + oo] = tok < ntok ? dy[tok * O + l16 * (O / 16) + oo] : 0.f;
+    __syncthreads();
+    // d(affine output)[i] = sum_o dy[o] w[o][i]
+    float da[C / 4], sa = 0.f, sb = 0.f, dxh[C / 4];
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) {
+      float acc = 0.f;
+      for (int o = 0; o < O; ++o) acc = fmaf(s_dy[tl][o], s_w[o][i0 + k], acc);
+      da[k] = acc;
+      ag[k] = fmaf(acc, xh[k], ag[k]);
+      ab[k] += acc;
+      dxh[k] = acc * gamma[i0 + k];
+      sa += dxh[k];
+      sb = fmaf(dxh[k], xh[k], sb);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+    sa *= 1.f / K; sb *= 1.f / K;
+    if (t.src >= 0)
+#pragma unroll
+      for (int k = 0; k < C / 4; ++k) dx[t.src + k] = t.rstd * (dxh[k] - sa - xh[k] * sb);
+    // dW[o][i] += sum over the 16 tokens of dy[o] xa[i]
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+      const int e = tid + 256 * k, o = e / K, i = e % K;
+      float acc = aw[k];
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) acc = fmaf(s_dy[tt][o], s_xa[tt][i], acc);
+      aw[k] = acc;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) atomicAdd(dw + tid + 256 * k, aw[k]);
+#pragma unroll
+  for (int k = 0; k < C / 4; ++k) { atomicAdd(dgamma + i0 + k, ag[k]); atomicAdd(dbeta + i0 + k, ab[k]); }
+}
+
 int stream_grid(long items) { return imin(cdiv(items, 256), kCUs * 8); }
 
 }  // namespace
@@ -1105,5 +1252,32 @@ extern "C" int idee_lfq_fold_weights_bwd(const float* dweff, const float* w, con
   hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(imin(cdiv(total, 256), 1024)), dim3(256), 0, (hipStream_t)stream, dweff, w_out, b_out, dw, Co, V, C, D, CP, per_var);
   hipLaunchKernelGGL(fold_bwd_p_kernel, dim3(C * (D + 1)), dim3(256), 0, (hipStream_t)stream, dweff, w, dw_out, db_out, Co, V, C, D, CP, per_var);
   IDEE_LAUNCH_CHECK("lfq_fold_weights_bwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_patch_merging_fwd(const float* x, const float* gamma, const float* beta, const float* w, float* y, int B, int D,
+                                      int H, int W, int C, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && gamma && beta && w && y && B > 0 && D > 0 && H > 0 && W > 0, "patch_merging_fwd: bad argument");
+  const int D2 = D == 1 ? 1 : (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const long ntok = (long)B * D2 * H2 * W2;
+  const dim3 grid(imin(cdiv(ntok, 16), kCUs * 8));
+  if (C == 16) hipLaunchKernelGGL(patch_merging_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, w, y, ntok, D, H, W, D2, H2, W2);
+  else if (C == 32) hipLaunchKernelGGL(patch_merging_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, w, y, ntok, D, H, W, D2, H2, W2);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "patch_merging: C=%d is not built (16, 32)", C);
+  IDEE_LAUNCH_CHECK("patch_merging_fwd");
+  return IDEE_OK;
+}
+extern "C" int idee_patch_merging_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* w,
+                                      float* dx, float* dgamma, float* dbeta, float* dw, int B, int D, int H, int W, int C,
+                                      idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && dy && gamma && beta && w && dx && dgamma && dbeta && dw && B > 0 && D > 0 && H > 0 && W > 0,
+                 "patch_merging_bwd: bad argument");
+  const int D2 = D == 1 ? 1 : (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const long ntok = (long)B * D2 * H2 * W2;
+  const dim3 grid(imin(cdiv(ntok, 16), kCUs * 2));
+  if (C == 16) hipLaunchKernelGGL(patch_merging_bwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, beta, w, dx, dgamma, dbeta, dw, ntok, D, H, W, D2, H2, W2);
+  else if (C == 32) hipLaunchKernelGGL(patch_merging_bwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, beta, w, dx, dgamma, dbeta, dw, ntok, D, H, W, D2, H2, W2);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "patch_merging: C=%d is not built (16, 32)", C);
+  IDEE_LAUNCH_CHECK("patch_merging_bwd");
   return IDEE_OK;
 }

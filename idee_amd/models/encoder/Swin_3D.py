@@ -31,6 +31,26 @@ def _check_no_dropout(training, **rates):
         raise NotImplementedError(f"idee_amd: stochastic regularisation {bad} is not built (reference defaults are 0)")
 
 
+class PatchMerging(nn.Module):
+    """Patch merging layer — drop-in for the reference's PatchMerging (Swin_3D.py:290-335): same constructor,
+    same parameters (`reduction.weight` (2*dim, 4*dim), `norm.{weight,bias}` (4*dim)), x (B,D,H,W,C) channels-last in,
+    (B,D',H/2,W/2,2C) out; one HIP kernel per direction (idee_patch_merging_*).  The reference's own encoder never
+    instantiates it (Swin_3D.py:578 passes downsample=PatchEmbed3D); it is provided for hierarchical configurations."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("idee_amd PatchMerging: only nn.LayerNorm is built")
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x):
+        if x.shape[-1] != self.dim:
+            raise ValueError(f"PatchMerging: expected (B,D,H,W,{self.dim}), got {tuple(x.shape)}")
+        return ops.PatchMergingFn.apply(x, self.norm.weight, self.norm.bias, self.reduction.weight)
+
+
 class Swin_3D(_stacked.StackedModule):
     def __init__(self, in_vars: int = 6, in_chans: int = 1, embed_dim: list = None, window_size: list = None,
                  depths: list = None, num_heads: list = None, mlp_ratio: int = 4, drop_rate: float = 0.,

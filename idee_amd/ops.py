@@ -55,6 +55,32 @@ class PatchEmbedLN(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------
 # fused Swin block
 # ----------------------------------------------------------------------------------------
+class PatchMergingFn(torch.autograd.Function):
+    """x (B,D,H,W,C) -> LayerNorm(4C)(gather of 4 neighbours) @ w^T, (B,D',ceil(H/2),ceil(W/2),2C).
+    Reference: PatchMerging.forward, Swin_3D.py:303-335."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w):
+        x, gamma, beta, w = (_f32c(t) for t in (x, gamma, beta, w))
+        B, D, H, W, Cc = x.shape
+        D2 = 1 if D == 1 else (D + 1) // 2
+        y = torch.empty((B, D2, (H + 1) // 2, (W + 1) // 2, 2 * Cc), device=x.device, dtype=torch.float32)
+        L.call("idee_patch_merging_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(w), ptr(y), B, D, H, W, Cc, L.stream())
+        ctx.save_for_backward(x, gamma, beta, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, w = ctx.saved_tensors
+        B, D, H, W, Cc = x.shape
+        dy = _f32c(dy)
+        dx = torch.zeros_like(x)                  # positions the gather never reads keep a zero gradient
+        dg, db, dw = torch.zeros_like(gamma), torch.zeros_like(beta), torch.zeros_like(w)
+        L.call("idee_patch_merging_bwd", ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(w), ptr(dx), ptr(dg), ptr(db), ptr(dw),
+               B, D, H, W, Cc, L.stream())
+        return dx, dg, db, dw
+
+
 def clamp_window(extent, window, shift):
     """get_window_size, Swin_3D.py:77-90."""
     ws, ss = list(window), list(shift)

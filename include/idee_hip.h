@@ -99,6 +99,17 @@ int idee_relpos_bias_scatter(const float* ddense, const int64_t* index, float* d
                              int Nw, idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * PatchMerging (Swin_3D.py:290-335): 2x2 spatial (and, as the reference writes it, d-parity-coupled) gather of 4
+ * neighbours -> LayerNorm(4C) -> Linear(4C -> 2C, no bias).  x (B, D, H, W, C) -> y (B, D2, ceil(H/2), ceil(W/2), 2C),
+ * D2 = 1 if D == 1 else ceil(D/2); odd extents zero-padded (:312-317).  gamma, beta (4C); w (2C, 4C).
+ * bwd: dx must be zero-filled by the caller (positions the gather never reads keep 0); dgamma, dbeta, dw accumulate.
+ * ---------------------------------------------------------------------------------------- */
+int idee_patch_merging_fwd(const float* x, const float* gamma, const float* beta, const float* w, float* y, int B, int D, int H,
+                           int W, int C, idee_stream_t stream);
+int idee_patch_merging_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* w, float* dx,
+                           float* dgamma, float* dbeta, float* dw, int B, int D, int H, int W, int C, idee_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * 3-D convolutions as implicit GEMM on the f32 MFMA.
  *   IDEE_CONV_K333_REPLICATE: Conv3d(k=3, s=1, p=1, padding_mode='replicate')
  *       proj_var (Swin_3D.py:586-592, encoder/CNN_3D.py:185-191), conv_block convs (:99-106)

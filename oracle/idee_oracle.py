@@ -165,6 +165,24 @@ def patch_embed(x, sd, pre, patch_size=(1, 1, 1)):
     return F.layer_norm(x.permute(0, 2, 3, 4, 1), (E,)).permute(0, 4, 1, 2, 3)
 
 
+def patch_merging(x, sd, pre=""):
+    """PatchMerging.forward, Swin_3D.py:303-335 (never instantiated by the reference's configs, :578).
+    x (B,D,H,W,C) -> (B,D',H/2,W/2,2C).  Note the sampling the reference writes for D > 1 (:323-326):
+    x1 and x3 take ODD d together with odd h."""
+    B, D, H, W, C = x.shape
+    if H % 2 == 1 or W % 2 == 1:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    if D % 2 == 1 and D != 1:
+        x = F.pad(x, (0, 0, 0, 0, 0, 0, 0, D % 2))
+    if D == 1:
+        parts = [x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]]
+    else:
+        parts = [x[:, 0::2, 0::2, 0::2], x[:, 1::2, 1::2, 0::2], x[:, 0::2, 0::2, 1::2], x[:, 1::2, 1::2, 1::2]]
+    x = torch.cat(parts, -1)
+    x = F.layer_norm(x, (4 * C,), sd[pre + "norm.weight"], sd[pre + "norm.bias"])
+    return F.linear(x, sd[pre + "reduction.weight"])
+
+
 def proj_var(x, sd, pre):
     """Conv3d 3^3 replicate -> ReLU -> Conv3d 3^3 replicate. Swin_3D.py:586-592."""
     x = F.conv3d(F.pad(x, (1,) * 6, mode="replicate"), sd[pre + "0.weight"], sd[pre + "0.bias"])

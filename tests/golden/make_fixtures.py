@@ -434,8 +434,34 @@ if __name__ == "__main__" and "--eval-only" in sys.argv:
     fx_evaluators()
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only")):
+def fx_patch_merging(tag, C, B, D, H, W, seed):
+    """PatchMerging (Swin_3D.py:290-335) called directly (the reference's configs never instantiate it)."""
+    pm = ref_swin.PatchMerging(C)
+    rerandomise(pm, seed)
+    x = rand((B, D, H, W, C), seed + 1).requires_grad_()
+    y = pm(x)
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x.detach(), y=y.detach(), r=r, dx=x.grad)
+    out.update(sd_arrays(pm))
+    out.update({"grad/" + k: p.grad for k, p in pm.named_parameters()})
+    save("patch_merging_" + tag, **out)
+
+
+def fx_patch_mergings():
+    fx_patch_merging("c16_even", 16, 2, 4, 6, 8, 950)
+    fx_patch_merging("c16_odd", 16, 2, 3, 5, 7, 960)
+    fx_patch_merging("c16_d1", 16, 1, 1, 6, 5, 970)
+    fx_patch_merging("c32_even", 32, 1, 2, 4, 6, 980)
+
+
+if __name__ == "__main__" and "--pm-only" in sys.argv:
+    fx_patch_mergings()
+
+
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only")):
     main()
+    fx_patch_mergings()
     fx_vq("k2_train", 2, True, 800)
     fx_vq("k2_eval", 2, False, 810)
     fx_vq("k8_train", 8, True, 820)

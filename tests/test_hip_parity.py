@@ -88,6 +88,23 @@ def _swin_params(sd, V=1):
     return [dev(sd[n]).unsqueeze(0).contiguous().requires_grad_() for n in names], names
 
 
+@pytest.mark.parametrize("tag", ["c16_even", "c16_odd", "c16_d1", "c32_even"])
+def test_patch_merging_golden(tag):
+    from idee_amd.models.encoder.Swin_3D import PatchMerging
+    a, sd, grads = load_golden("patch_merging_" + tag)
+    C = a["x"].shape[-1]
+    pm = PatchMerging(C)
+    pm.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    pm = pm.to(DEV)
+    x = dev(a["x"]).requires_grad_()
+    y = pm(x)
+    close("y", y, a["y"])
+    (y * dev(a["r"])).sum().backward()
+    gclose("dx", x.grad, a["dx"])
+    for k, p in pm.named_parameters():
+        gclose("d" + k, p.grad, grads[k])
+
+
 @pytest.mark.parametrize("tag", ["w244_noshift", "w244_shift", "w244_shift_pad", "w244_noshift_pad", "w811",
                                  "w811_T16_shift", "w244_c32"])
 def test_swin_block_golden(tag):

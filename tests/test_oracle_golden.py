@@ -56,6 +56,18 @@ def test_patch_embed(tag):
     check_grads(sd, grads)
 
 
+@pytest.mark.parametrize("tag", ["c16_even", "c16_odd", "c16_d1", "c32_even"])
+def test_patch_merging(tag):
+    a, sd, grads = load_golden("patch_merging_" + tag)
+    sd = leaf(sd)
+    x = a["x"].clone().requires_grad_()
+    y = O.patch_merging(x, sd)
+    close(y, a["y"])
+    (y * a["r"]).sum().backward()
+    close(x.grad, a["dx"], 1e-5, 1e-3)
+    check_grads(sd, grads)
+
+
 @pytest.mark.parametrize("tag,cin", [("1_16", 1), ("16_16", 16)])
 def test_conv_block(tag, cin):
     a, sd, grads = load_golden("conv_block_" + tag)
