@@ -1,0 +1,168 @@
+"""Input pipeline for the training hot path.
+
+`ClipWindowDataset` restates the item contract of the reference's `Synthetic_Dataset.__getitem__`
+(dataset/Synthetic_dataset.py:310-376: sliding delta_t window, time axis flipped to "newest first", the
+extreme / extreme-loss / anomaly masks, rot180 + flip augmentation) on an in-memory data cube; the cube is
+either handed in by the caller (e.g. read from the reference's NetCDF files with xarray where that is
+installed — not needed, and not importable, here) or generated (`synthetic_cube`) with the value range the
+reference's normalisation produces (clip to [-10, 10], Synthetic_dataset.py:215).  Golden parity of the
+item logic: tests/test_data_pipeline.py against items produced by the reference's own `__getitem__`
+(tests/golden/dataset_items.npz).
+
+`PrefetchLoader` replaces torch's DataLoader + per-iteration `.to(device)` (train_synthetic.py:79-90,175-182):
+a worker thread collates batches into a ring of PINNED host buffers and copies them to the GPU on a side HIP
+stream, so the training stream never waits for PCIe (30.7 MB per 4-clip batch at the headline config).
+It yields exactly what `harness.train_epoch` consumes.  On a CPU-only host it degrades to plain CPU tensors
+(that is a host-side data path, not a compute fallback: the model still refuses CPU tensors)."""
+from __future__ import annotations
+
+import queue
+import threading
+
+import numpy as np
+import torch
+
+
+def synthetic_cube(V=6, T_total=60, H=200, W=200, V_static=0, seed=1234, p_extreme=0.02, p_anomaly=0.05):
+    """A random cube with the shapes / dtypes / ranges the reference's dataset holds after normalisation."""
+    rng = np.random.default_rng(seed)
+    return dict(
+        dynamic=np.clip(rng.standard_normal((V, T_total, H, W), dtype=np.float32), -10.0, 10.0),
+        static=rng.standard_normal((V_static, H, W), dtype=np.float32),
+        time=(np.arange(T_total) % 52).astype(np.float32),
+        timestep=np.arange(1, T_total + 1).astype(np.int64),
+        extreme=(rng.random((T_total, H, W)) < p_extreme).astype(np.uint8),
+        anomaly=(rng.random((V, T_total, H, W)) < p_anomaly).astype(np.uint8),
+    )
+
+
+class ClipWindowDataset(torch.utils.data.Dataset):
+    """Items as Synthetic_Dataset.__getitem__ returns them (Synthetic_dataset.py:310-376):
+        dynamic (V, 1, delta_t, H, W) f32   newest time step first
+        static (Vs, H, W), t (delta_t) week numbers + 1, newest first
+        mask_extreme (H, W)        last time step's extreme mask, labels > 1 zeroed
+        mask_extreme_loss (H, W)   uint8: any extreme inside the window
+        mask_anomaly (V, delta_t, H, W), tstep (1,)"""
+
+    def __init__(self, dynamic, static, time, timestep, extreme, anomaly, delta_t=8, is_aug=False, rng=None):
+        self.dynamic, self.static, self.time, self.timestep = dynamic, static, time, timestep
+        self.extreme, self.anomaly = extreme, anomaly
+        self.delta_t, self.is_aug = int(delta_t), bool(is_aug)
+        self.rng = rng if rng is not None else np.random          # the reference draws from the global numpy RNG
+        if dynamic.shape[1] < self.delta_t:
+            raise ValueError(f"cube has {dynamic.shape[1]} time steps, fewer than delta_t={self.delta_t}")
+
+    def __len__(self):
+        return self.dynamic.shape[1] - self.delta_t + 1                                     # :378-385
+
+    def __getitem__(self, index):
+        dt = self.delta_t
+        dyn = np.flip(self.dynamic[:, index:index + dt], 1)[:, None]                        # :331-332
+        sta = self.static
+        t = np.flip(self.time[index:index + dt] + 1)                                        # :336
+        tstep = np.array([self.timestep[index + dt - 1]])                                   # :338
+        m_ext = self.extreme[index + dt - 1].copy()                                         # :342-343
+        m_ext[m_ext > 1] = 0
+        m_loss = self.extreme[index:index + dt].sum(axis=0)                                 # :346-349 (flip is sum-invariant)
+        m_loss[m_loss > 1] = 1
+        m_loss = m_loss.astype(np.uint8)
+        m_an = np.flip(self.anomaly[:, index:index + dt], 1)                                # :352
+        if self.is_aug:                                                                     # :355-372
+            if self.rng.choice(2):
+                dyn, sta, m_ext, m_loss, m_an = (np.rot90(a, k=2, axes=(-1, -2)) for a in (dyn, sta, m_ext, m_loss, m_an))
+            if self.rng.choice(2):
+                ax = self.rng.randint(1, 3)
+                dyn, sta, m_ext, m_loss, m_an = (np.flip(a, axis=-ax) for a in (dyn, sta, m_ext, m_loss, m_an))
+        return tuple(np.ascontiguousarray(a) for a in (dyn, sta, t, m_ext, m_loss, m_an, tstep))
+
+
+class PrefetchLoader:
+    """Batches of (x_d (B,V,1,T,H,W) f32, mask_extreme (B,H,W) f32, mask_extreme_loss (B,H,W) f32, timestep (B,) int64)
+    on `device`, produced `depth` batches ahead by a worker thread through pinned buffers and a side stream.
+    rank / world shard the (shuffled) index list like a DistributedSampler with drop_last over ranks."""
+
+    def __init__(self, dataset, batch_size, device, shuffle=True, drop_last=True, seed=0, rank=0, world=1, depth=2):
+        self.ds, self.bs, self.device = dataset, int(batch_size), torch.device(device)
+        self.shuffle, self.drop_last, self.seed, self.rank, self.world, self.depth = shuffle, drop_last, seed, rank, world, depth
+        self.epoch = 0
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _indices(self):
+        idx = np.arange(len(self.ds))
+        if self.shuffle:
+            np.random.default_rng(self.seed + self.epoch).shuffle(idx)
+        per = len(idx) // self.world
+        return idx[self.rank * per:(self.rank + 1) * per] if self.world > 1 else idx
+
+    def __len__(self):
+        n = len(self._indices())
+        return n // self.bs if self.drop_last else -(-n // self.bs)
+
+    def _collate(self, ids, bufs):
+        items = [self.ds[int(i)] for i in ids]
+        n = len(items)
+        x, me, ml, ts = bufs
+        for k, it in enumerate(items):
+            x[k].copy_(torch.from_numpy(it[0]))
+            me[k].copy_(torch.from_numpy(it[3].astype(np.float32)))
+            ml[k].copy_(torch.from_numpy(it[4].astype(np.float32)))
+            ts[k] = int(it[6][0])
+        return n
+
+    def __iter__(self):
+        idx = self._indices()
+        nb = len(self)
+        V, _, T, H, W = self.ds[0][0].shape
+        ring = [(torch.empty((self.bs, V, 1, T, H, W), dtype=torch.float32, pin_memory=self.cuda),
+                 torch.empty((self.bs, H, W), dtype=torch.float32, pin_memory=self.cuda),
+                 torch.empty((self.bs, H, W), dtype=torch.float32, pin_memory=self.cuda),
+                 torch.empty((self.bs,), dtype=torch.int64, pin_memory=self.cuda)) for _ in range(self.depth + 1)]
+        free, ready = queue.Queue(), queue.Queue(maxsize=self.depth)
+        for r in range(len(ring)):
+            free.put(r)
+        stop = threading.Event()
+
+        def work():
+            try:
+                for b in range(nb):
+                    r = free.get()
+                    if stop.is_set():
+                        return
+                    n = self._collate(idx[b * self.bs:(b + 1) * self.bs], ring[r])
+                    if self.cuda:
+                        with torch.cuda.stream(self.stream):
+                            dev = tuple(t[:n].to(self.device, non_blocking=True) for t in ring[r])
+                            ev = torch.cuda.Event()
+                            ev.record(self.stream)
+                    else:
+                        dev, ev = tuple(t[:n].clone() for t in ring[r]), None
+                    ready.put((r, dev, ev))
+                ready.put(None)
+            except BaseException as e:      # surface worker errors in the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        try:
+            while True:
+                got = ready.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                r, dev, ev = got
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)     # the training stream waits for THIS batch only
+                    for t in dev:
+                        t.record_stream(torch.cuda.current_stream(self.device))
+                    ev.synchronize()                                          # the pinned buffer may be refilled now
+                free.put(r)
+                yield dev
+        finally:
+            stop.set()
+            free.put(0)
+            th.join(timeout=5)

@@ -459,9 +459,47 @@ if __name__ == "__main__" and "--pm-only" in sys.argv:
     fx_patch_mergings()
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only")):
+def fx_dataset_items(seed=1000):
+    """Synthetic_Dataset.__getitem__ (dataset/Synthetic_dataset.py:310-376) on an in-memory cube.  The module imports
+    xarray (absent here) at its top and the constructor reads NetCDF files; __getitem__ itself touches neither, so the
+    class is imported with an empty in-memory `xarray` module object and an instance is made WITHOUT running __init__
+    (object.__new__), with only the attributes __getitem__ / __len__ read set by hand."""
+    sys.modules.setdefault("xarray", types.ModuleType("xarray"))
+    from dataset.Synthetic_dataset import Synthetic_Dataset
+    rng = np.random.default_rng(seed)
+    V, Tt, H, W, Vs, dt = 3, 14, 6, 9, 2, 8
+    cube = dict(dynamic=np.clip(rng.standard_normal((V, Tt, H, W)).astype(np.float32) * 4, -10, 10),
+                static=rng.standard_normal((Vs, H, W)).astype(np.float32),
+                time=((np.arange(Tt) + 47) % 52).astype(np.float32), timestep=(np.arange(Tt) + 100).astype(np.int64),
+                extreme=rng.integers(0, 3, (Tt, H, W)).astype(np.uint8),        # 0 none, 1 extreme, 2 = "other" class
+                anomaly=(rng.random((V, Tt, H, W)) < 0.2).astype(np.uint8))
+    out = {"cube/" + k: v for k, v in cube.items()}
+    out["delta_t"] = np.array(dt)
+    names = ("dynamic", "static", "t", "mask_extreme", "mask_extreme_loss", "mask_anomaly", "tstep")
+    for is_aug in (False, True):
+        ds = object.__new__(Synthetic_Dataset)
+        ds._datacube_dynamic, ds._datacube_static = cube["dynamic"], cube["static"]
+        ds._datacube_time, ds._datacube_timestep = cube["time"], cube["timestep"]
+        ds._extreme, ds._anomaly = cube["extreme"], cube["anomaly"]
+        ds.delta_t, ds.is_aug = dt, is_aug
+        out["len"] = np.array(len(ds))
+        for index in (0, 3, len(ds) - 1):
+            for rs in ((0,) if not is_aug else (0, 1, 2, 3, 4, 5)):
+                np.random.seed(1234 + rs)
+                item = ds[index]
+                for n, v in zip(names, item):
+                    out[f"item/aug{int(is_aug)}/i{index}/s{rs}/{n}"] = np.ascontiguousarray(v)
+    save("dataset_items", **out)
+
+
+if __name__ == "__main__" and "--data-only" in sys.argv:
+    fx_dataset_items()
+
+
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only")):
     main()
     fx_patch_mergings()
+    fx_dataset_items()
     fx_vq("k2_train", 2, True, 800)
     fx_vq("k2_eval", 2, False, 810)
     fx_vq("k8_train", 8, True, 820)
