@@ -52,8 +52,8 @@ def synthetic_batch(cfg, n, T, H, W, rank, device):
 
 # ---- algorithmic FLOPs per launch of each convolution entry point (2 * MACs of the reference conv) ----
 def conv_flops(desc):
-    taps = 27 if desc.mode == 0 else 18
-    To = desc.T if desc.mode == 0 else (desc.T - 2) // 2 + 1
+    taps = {0: 27, 1: 18, 2: 9}[desc.mode]                 # K333_REPLICATE, K233_S2_ZERO, K133_ZERO
+    To = (desc.T - 2) // 2 + 1 if desc.mode == 1 else desc.T
     return 2.0 * desc.B * To * desc.H * desc.W * taps * desc.Cin * desc.Cout
 
 
@@ -84,7 +84,7 @@ def pmc_traffic(key):
     nw = "32" if "w244" in key else "8"
     want = None
     if name == "idee_swin_block_bwd":       # two kernels per launch
-        want = ["swin_mlp_bwd_kernel<16>", f"swin_attn_bwd_kernel<16, 2, {nw}, 4>"]
+        want = ["swin_mlp_bwd_kernel<16, 2>", f"swin_attn_bwd_kernel<16, 2, {nw}, 8, 2>"]
     elif name == "idee_swin_block_fwd":
         want = [f"swin_fwd_mfma_kernel<16, 2, {nw}, true>"]
     elif "k333 16->16" in key:
@@ -191,7 +191,7 @@ def main():
             key, flops = name, 0.0
             if name.startswith("idee_conv_"):
                 d = ctypes.cast(args[0], ctypes.POINTER(_lib.ConvDesc)).contents
-                key = f"{name}[{'k333' if d.mode == 0 else 'k233'} {d.Cin}->{d.Cout} B{d.B} T{d.T}]"
+                key = f"{name}[{('k333', 'k233', 'k133')[d.mode]} {d.Cin}->{d.Cout} B{d.B} T{d.T}]"
                 flops = conv_flops(d)
             elif name.startswith("idee_swin_block_"):
                 g = ctypes.cast(args[-2], ctypes.POINTER(_lib.SwinGeom)).contents
@@ -215,6 +215,19 @@ def main():
                     frac=round(fl / avg_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(k), avg_launch_ms=round(avg_ms, 4),
                     flops_per_launch=fl, share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
 
+    # ---- second half of BASELINE.json's metric: forward ms per clip (eval mode, no autograd), outside the timed region ----
+    ts.model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            ts.model(x)
+        barrier()
+        f0 = time.perf_counter()
+        for _ in range(5):
+            ts.model(x)
+        barrier()
+        fwd_ms_clip = (time.perf_counter() - f0) / 5 / a.batch * 1e3
+    ts.model.train()
+
     if rank != 0:
         return
     out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * a.batch * a.steps / dt, 3),
@@ -223,7 +236,7 @@ def main():
                config=dict(workload=f"Synthetic CERRA {H}x{W}, T={T}, V={cfg.in_channels_dynamic}, {a.encoder} tiny "
                                     f"(reference defaults), batch {a.batch}/GPU", global_batch=world * a.batch,
                            parallelism=f"dp{world}"),
-               roofline=roof)
+               roofline=roof, fwd_ms_per_clip=round(fwd_ms_clip, 3))
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, ts.model, T, H, W)
     print(json.dumps(out), flush=True)
