@@ -159,8 +159,15 @@ __device__ __forceinline__ void lfq_probs(const float (&s)[D], float (&p)[1 << D
 // sum over the QE = E/4 adjacent lanes that share a token
 template <int QE>
 __device__ __forceinline__ float tok_sum(float v) {
+  // lane xor 1 / xor 2 inside a quad are DPP quad permutations (one VALU slot each) — __shfl_xor would go through
+  // ds_bpermute and the LDS pipe
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
 #pragma unroll
-  for (int o = 1; o < QE; o <<= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 4; o < QE; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -276,9 +283,21 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
     wo[i] = f32x4{w_out[(4 * q) * D + i], w_out[(4 * q + 1) * D + i], w_out[(4 * q + 2) * D + i], w_out[(4 * q + 3) * D + i]};
     gwi[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gwo[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gbi[i] = 0.f;
   }
-  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
-    const long tok = u / QE;
-    const f32x4 zi = ld4(z + tok * E + 4 * q), go = ld4(dzq + tok * E + 4 * q);
+  // two tokens per lane and trip: four 16-byte loads in flight before the first dependent instruction
+  const long total = M * QE, stride = (long)gridDim.x * 256;
+  for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += 2 * stride) {
+   const bool two = u0 + stride < total;
+   const long tokA = u0 / QE, tokB = two ? (u0 + stride) / QE : tokA;
+   const f32x4 ziA = ld4(z + tokA * E + 4 * q), goA = ld4(dzq + tokA * E + 4 * q);
+   const f32x4 ziB = ld4(z + tokB * E + 4 * q), goB = ld4(dzq + tokB * E + 4 * q);
+   float dqA[D], dqB[D];
+#pragma unroll
+   for (int i = 0; i < D; ++i) { dqA[i] = dqs ? dqs[tokA * D + i] : 0.f; dqB[i] = dqs ? dqs[tokB * D + i] : 0.f; }
+#pragma unroll
+   for (int half = 0; half < 2; ++half) {
+    if (half == 1 && !two) break;
+    const long tok = half ? tokB : tokA;
+    const f32x4 zi = half ? ziB : ziA, go = half ? goB : goA;
     float s[D], qv[D], ds[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
       s[i] = a; qv[i] = a > 0.f ? 1.f : -1.f;
       // straight-through: d x_ste = W_out^T dz_q
       const float d = tok_sum<QE>(go[0] * wo[i][0] + go[1] * wo[i][1] + go[2] * wo[i][2] + go[3] * wo[i][3]);
-      ds[i] = d + (dqs ? dqs[tok * D + i] : 0.f) + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
+      ds[i] = d + (half ? dqB[i] : dqA[i]) + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
     }
     float p[K];
     lfq_probs<D>(s, p);
@@ -314,6 +333,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
     }
     gbo += go;
     st4(dz + tok * E + 4 * q, o);
+   }
   }
   // lanes with equal q hold partials of the same 4 channels: reduce over them, lanes 0..QE-1 publish
   auto same_q_sum = [](float v) {
