@@ -34,6 +34,21 @@ __device__ __forceinline__ void block_sum(float (&v)[R], float* smem /* >= R * 4
 // PatchEmbed3D with patch (1,1,1): 1x1x1 conv (optional bias) + non-affine LN over channels.
 // Swin_3D.py:473-491 ; encoder/CNN_3D.py:44-71.   x (N,V,CIN,L) -> y (N,V,L,E)
 // -------------------------------------------------------------------------------------------
+// sum over the QE = E/4 adjacent lanes that share a token
+template <int QE>
+__device__ __forceinline__ float tok_sum(float v) {
+  // lane xor 1 / xor 2 inside a quad are DPP quad permutations (one VALU slot each) — __shfl_xor would go through
+  // ds_bpermute and the LDS pipe
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int o = 4; o < QE; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 template <int E, int CIN>
 __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
@@ -71,59 +86,67 @@ template <int E, int CIN>
 __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, const float* __restrict__ dy,
                                                               float* __restrict__ dw, float* __restrict__ db, int V, long L) {
+  // E/4 adjacent lanes per token, 4 channels each: dy is read as one contiguous stream of 16-byte pieces
+  constexpr int QE = E / 4;
   const int b = blockIdx.y, v = b % V;
   const float* wv = w + (long)v * E * CIN;
-  const float* bv = bias ? bias + v * E : nullptr;
   const float* xb = x + (long)b * CIN * L;
   const float* dyb = dy + (long)b * L * E;
-  float gw[E][CIN], gb[E];
+  const int q = threadIdx.x % QE;
+  float wl[4][CIN], bl[4], gw[4][CIN], gb[4];
 #pragma unroll
-  for (int o = 0; o < E; ++o) { gb[o] = 0.f;
+  for (int k = 0; k < 4; ++k) {
+    bl[k] = bias ? bias[v * E + 4 * q + k] : 0.f;
+    gb[k] = 0.f;
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) gw[o][c] = 0.f; }
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < L; tok += (long)gridDim.x * 256) {
+    for (int c = 0; c < CIN; ++c) { wl[k][c] = wv[(4 * q + k) * CIN + c]; gw[k][c] = 0.f; }
+  }
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const f32x4 g = ld4(dyb + tok * E + 4 * q);
     float xi[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; ++c) xi[c] = xb[c * L + tok];
-    float e[E], mean = 0.f;
+    float e[4], sm = 0.f;
 #pragma unroll
-    for (int o = 0; o < E; ++o) {
-      float a = bv ? bv[o] : 0.f;
+    for (int k = 0; k < 4; ++k) {
+      float a = bl[k];
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) a = fmaf(wv[o * CIN + c], xi[c], a);
-      e[o] = a; mean += a;
+      for (int c = 0; c < CIN; ++c) a = fmaf(wl[k][c], xi[c], a);
+      e[k] = a; sm += a;
     }
-    mean *= (1.f / E);
+    const float mean = tok_sum<QE>(sm) * (1.f / E);
     float var = 0.f;
 #pragma unroll
-    for (int o = 0; o < E; ++o) { const float d = e[o] - mean; var = fmaf(d, d, var); }
-    const float rstd = rsqrtf(var * (1.f / E) + kLnEps);
-    float g[E], s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int o = 0; o < E; o += 4) {
-      const f32x4 d4 = ld4(dyb + tok * E + o);
-      g[o] = d4[0]; g[o + 1] = d4[1]; g[o + 2] = d4[2]; g[o + 3] = d4[3];
-    }
+    for (int k = 0; k < 4; ++k) { e[k] = (e[k] - mean) * rstd; s1 += g[k]; s2 = fmaf(g[k], e[k], s2); }
+    s1 = tok_sum<QE>(s1) * (1.f / E); s2 = tok_sum<QE>(s2) * (1.f / E);
 #pragma unroll
-    for (int o = 0; o < E; ++o) { e[o] = (e[o] - mean) * rstd; s1 += g[o]; s2 = fmaf(g[o], e[o], s2); }
-    s1 *= (1.f / E); s2 *= (1.f / E);
+    for (int k = 0; k < 4; ++k) {
+      const float de = rstd * (g[k] - s1 - e[k] * s2);
+      gb[k] += de;
 #pragma unroll
-    for (int o = 0; o < E; ++o) {
-      const float de = rstd * (g[o] - s1 - e[o] * s2);
-      gb[o] += de;
-#pragma unroll
-      for (int c = 0; c < CIN; ++c) gw[o][c] = fmaf(de, xi[c], gw[o][c]);
+      for (int c = 0; c < CIN; ++c) gw[k][c] = fmaf(de, xi[c], gw[k][c]);
     }
   }
+  // lanes with equal q hold partials of the same 4 channels
+  auto same_q_sum = [](float val) {
+#pragma unroll
+    for (int o = QE; o < 64; o <<= 1) val += __shfl_xor(val, o, 64);
+    return val;
+  };
   const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int o = 0; o < E; ++o) {
-    const float sb = wave_sum(gb[o]);
-    if (lane == 0 && db) atomicAdd(db + v * E + o, sb);
+  for (int k = 0; k < 4; ++k) {
+    const float sb = same_q_sum(gb[k]);
+    if (lane < QE && db) atomicAdd(db + v * E + 4 * q + k, sb);
 #pragma unroll
     for (int c = 0; c < CIN; ++c) {
-      const float sw = wave_sum(gw[o][c]);
-      if (lane == 0) atomicAdd(dw + ((long)v * E + o) * CIN + c, sw);
+      const float sw = same_q_sum(gw[k][c]);
+      if (lane < QE) atomicAdd(dw + ((long)v * E + 4 * q + k) * CIN + c, sw);
     }
   }
 }
@@ -156,20 +179,6 @@ __device__ __forceinline__ void lfq_probs(const float (&s)[D], float (&p)[1 << D
   for (int k = 0; k < K; ++k) p[k] *= inv;
 }
 
-// sum over the QE = E/4 adjacent lanes that share a token
-template <int QE>
-__device__ __forceinline__ float tok_sum(float v) {
-  // lane xor 1 / xor 2 inside a quad are DPP quad permutations (one VALU slot each) — __shfl_xor would go through
-  // ds_bpermute and the LDS pipe
-  auto dpp = [](float x, auto ctrl) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
-#pragma unroll
-  for (int o = 4; o < QE; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 // E/4 adjacent lanes per token, each owning 4 channels: every access is a 16-byte piece of a contiguous stream
 template <int E, int D>
@@ -1032,7 +1041,7 @@ extern "C" int idee_patch_embed_ln_fwd(const float* x, const float* w, const flo
 extern "C" int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dw, float* db,
                                        int N, int V, int Cin, long L, int E, idee_stream_t stream) {
   IDEE_CHECK_ARG(x && w && dy && dw && N > 0 && V > 0 && L > 0, "patch_embed_ln_bwd: bad argument");
-  const dim3 grid(imin(cdiv(L, 256), cdiv((long)kCUs * 4, (long)N * V)), N * V);
+  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, (long)N * V)), N * V);
 #define PE(E_, C_) hipLaunchKernelGGL((patch_embed_bwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, dy, dw, db, V, L)
   if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
   else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
