@@ -984,6 +984,20 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
   }
 }
 
+// the replicate-mode data gradient accumulates its two edge columns (w = 0, W-1) with atomics: clear just those
+__global__ void zero_w_edges_kernel(float* __restrict__ dx, int B, int T, int H, int W, int Cin, long sB, long sT, long sH,
+                                    long sW) {
+  const int q4 = Cin / 4;
+  const long total = (long)B * T * H * 2 * q4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(e % q4); long r = e / q4;
+    const int side = (int)(r % 2); r /= 2;
+    const int h = (int)(r % H); r /= H;
+    const int t = (int)(r % T); const long b = r / T;
+    st4(dx + b * sB + t * sT + h * sH + (side ? W - 1 : 0) * sW + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight packing (reference layout (wsets, Cout, Cin, kt, kh, kw) -> MFMA fragment order)
 // ---------------------------------------------------------------------------------------------
@@ -1420,6 +1434,12 @@ extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const f
   if (d->mode == IDEE_CONV_K333_REPLICATE) {
     IDEE_CHECK_ARG(!cin1, "conv_dgrad: Cout == 1 is only built for the (2,3,3) mode");
     split_tiles(a, a.Wo + 2);
+    if (!accumulate) {   // interior columns are plain stores; the two edge columns are atomics and start from zero
+      IDEE_CHECK_ARG(d->x_sG == 16 && d->x_gpu <= 0, "conv_dgrad (replicate): grouped dx layouts are not built");
+      const long total = (long)d->B * d->T * d->H * 2 * (d->Cin / 4);
+      hipLaunchKernelGGL(zero_w_edges_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, dx, d->B,
+                         d->T, d->H, d->W, d->Cin, d->x_sB, d->x_sT, d->x_sH, d->x_sW);
+    }
     launch_conv<DGRAD_REP>(a, false, (hipStream_t)stream);
   } else {
     split_tiles(a, a.Wo);

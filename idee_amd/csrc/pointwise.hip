@@ -376,9 +376,21 @@ __global__ void bce_counts_kernel(const float* __restrict__ target, const float*
                                   float* __restrict__ counts) {
   __shared__ float smem[3 * 16];
   float v[3] = {3.4e38f, -3.4e38f, 0.f};
-  for (long i = threadIdx.x; i < M; i += blockDim.x) {
-    if (valid && valid[i] == 0.f) continue;
-    v[0] = fminf(v[0], target[i]); v[1] = fmaxf(v[1], target[i]);
+  // one workgroup (the two passes are dependent and M is a mask-sized array): 16-byte loads when the layout allows
+  const bool vec = (M % 4 == 0) && (((size_t)target | (size_t)(valid ? valid : target)) % 16 == 0);
+  if (vec) {
+    for (long i = threadIdx.x; i < M / 4; i += blockDim.x) {
+      const f32x4 t4 = ld4(target + 4 * i);
+      const f32x4 m4 = valid ? ld4(valid + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (m4[k] != 0.f) { v[0] = fminf(v[0], t4[k]); v[1] = fmaxf(v[1], t4[k]); }
+    }
+  } else {
+    for (long i = threadIdx.x; i < M; i += blockDim.x) {
+      if (valid && valid[i] == 0.f) continue;
+      v[0] = fminf(v[0], target[i]); v[1] = fmaxf(v[1], target[i]);
+    }
   }
   // min / max reduce
   for (int o = 32; o > 0; o >>= 1) { v[0] = fminf(v[0], __shfl_xor(v[0], o, 64)); v[1] = fmaxf(v[1], __shfl_xor(v[1], o, 64)); }
@@ -389,11 +401,24 @@ __global__ void bce_counts_kernel(const float* __restrict__ target, const float*
   for (int w = 1; w < nw; ++w) { mn = fminf(mn, smem[w]); mx = fmaxf(mx, smem[16 + w]); }
   if (mn == mx) { mn -= 1.f; mx += 1.f; }
   float c1 = 0.f, c0 = 0.f;
-  for (long i = threadIdx.x; i < M; i += blockDim.x) {
-    if (valid && valid[i] == 0.f) continue;
-    int bin = (int)((target[i] - mn) / (mx - mn) * 2.f);
+  auto count = [&](float t) {
+    int bin = (int)((t - mn) / (mx - mn) * 2.f);
     bin = bin > 1 ? 1 : bin;
     if (bin == 1) c1 += 1.f; else c0 += 1.f;
+  };
+  if (vec) {
+    for (long i = threadIdx.x; i < M / 4; i += blockDim.x) {
+      const f32x4 t4 = ld4(target + 4 * i);
+      const f32x4 m4 = valid ? ld4(valid + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (m4[k] != 0.f) count(t4[k]);
+    }
+  } else {
+    for (long i = threadIdx.x; i < M; i += blockDim.x) {
+      if (valid && valid[i] == 0.f) continue;
+      count(target[i]);
+    }
   }
   c0 = wave_sum(c0); c1 = wave_sum(c1);
   __syncthreads();

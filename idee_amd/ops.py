@@ -15,6 +15,17 @@ from . import _lib as L
 from ._lib import ptr
 
 
+def _zeros_like_many(*ts):
+    """Zero-filled f32 tensors shaped like `ts`, carved (16-byte aligned) out of ONE buffer: one fill kernel instead of len(ts)."""
+    sizes = [(t.numel() + 3) // 4 * 4 for t in ts]
+    flat = torch.zeros(sum(sizes), device=ts[0].device, dtype=torch.float32)
+    out, o = [], 0
+    for t, n in zip(ts, sizes):
+        out.append(flat[o:o + t.numel()].view(t.shape))
+        o += n
+    return out
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
@@ -127,13 +138,12 @@ class SwinBlock(torch.autograd.Function):
         dy = _f32c(dy)
         dx = torch.empty_like(x)
         dh = torch.empty_like(x)
-        grads = [torch.zeros_like(t) for t in params]
-        ddense = torch.zeros_like(dense)
+        zs = _zeros_like_many(*params, dense, table)     # one fill for all accumulating gradient buffers
+        grads, ddense, dtable = list(zs[:8]), zs[8], zs[9]
         sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense))
         sg = L.SwinGrads(*[ptr(t) for t in grads], ptr(ddense))
         L.call("idee_swin_block_bwd", ptr(x), ptr(hs), ptr(dy), ptr(dx), ptr(dh), C.byref(sp), C.byref(sg), C.byref(geom),
                L.stream())
-        dtable = torch.zeros_like(table)
         V, heads, Nw, _ = dense.shape
         L.call("idee_relpos_bias_scatter", ptr(ddense), ptr(idx), ptr(dtable), V, table.shape[1], heads, Nw, L.stream())
         return (dx, *grads, dtable, None, None, None, None, None)
@@ -172,9 +182,11 @@ class ConvLayer:
     def wgrad(self, x, dy, w_like, want_bias=True):
         """-> (dw in the reference layout of w_like, dbias (wsets, Cout) | None)."""
         dev = x.device
-        dwp = torch.zeros(self.wgrad_floats, device=dev, dtype=torch.float32)
         cpad = ((self.Cout + 15) // 16) * 16
-        dbp = torch.zeros((self.wsets, cpad), device=dev, dtype=torch.float32) if want_bias else None
+        nw = (self.wgrad_floats + 3) // 4 * 4
+        flat = torch.zeros(nw + (self.wsets * cpad if want_bias else 0), device=dev, dtype=torch.float32)   # one fill
+        dwp = flat[:self.wgrad_floats]
+        dbp = flat[nw:].view(self.wsets, cpad) if want_bias else None
         L.call("idee_conv_wgrad", C.byref(self.desc), ptr(x), ptr(dy), ptr(dwp), ptr(dbp), L.stream())
         dw = torch.empty_like(w_like)
         L.call("idee_conv_unpack_wgrad", C.byref(self.desc), ptr(dwp), ptr(dw), L.stream())
@@ -214,12 +226,12 @@ class ProjVar(torch.autograd.Function):
         c1, c2 = ctx.convs
         dy = _f32c(dy)
         dw2, db2 = c2.wgrad(a1, dy, w2)
-        da1 = torch.zeros_like(a1)
+        da1 = torch.empty_like(a1)
         c2.dgrad(dy, p2d, a1, da1)              # masked by ReLU'(a1)
         dw1, db1 = c1.wgrad(x, da1, w1)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.zeros_like(x)
+            dx = torch.empty_like(x)
             c1.dgrad(da1, p1d, None, dx)
         return dx, dw1, db1, dw2, db2
 

@@ -149,8 +149,8 @@ int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, float* packe
 int idee_conv_fwd(const idee_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
                   idee_stream_t stream);
 /* dx = conv^T(dy) [* (relu_ref > 0) if relu_ref != NULL; same layout as x]; accumulate != 0: dx += ...
- * REPLICATE mode: the two edge columns are accumulated with atomics, so dx must be initialised by the caller:
- * zeros with accumulate == 0, or any addend (e.g. a residual gradient) with accumulate != 0. */
+ * accumulate == 0: dx need not be initialised (REPLICATE mode: the two edge columns, which are accumulated with atomics,
+ * are cleared by the call itself); accumulate != 0: dx holds the addend (e.g. a residual gradient). */
 int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
                     float* dx, int accumulate, idee_stream_t stream);
 /* dw_packed (wsets, taps, Cin, CoutPad) and dbias (wsets, CoutPad) | NULL accumulate */
