@@ -541,12 +541,13 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
   const int j = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
   float* s_x = s_xw[wave];
+  // wr[(ot*3+oh)*3+ow] = fragment of the weight tap that (ot, oh, ow) uses under the CURRENT edge pattern: the forward
+  // conv always uses tap (ot, oh, ow); the data gradient flips a T / H tap where the replicate padding folds a source
+  // row back (first / last frame, first / last row) — the 27 fragments are re-read (27 KB from L2) when that pattern
+  // changes, so the tap loop below indexes registers statically and stays one straight-line, software-pipelined block
   f32x4 wr[27];
-  {
-    const float* wp = a.wp + (long)wset * 27 * 256;
-#pragma unroll
-    for (int tp = 0; tp < 27; ++tp) wr[tp] = ld4(wp + tp * 256 + lane * 4);
-  }
+  int wkey = -1;
+  const float* wp = a.wp + (long)wset * 27 * 256;
   const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
   const int nsub = (Wframe + 15) / 16;
   const int nb = a.B / a.wsets;
@@ -617,33 +618,47 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
       }
       wave_fence();
 
+      {
+        const int key = ((((st[0].tap * 3 + st[1].tap) * 3 + st[2].tap) * 3 + sh[0].tap) * 3 + sh[1].tap) * 3 + sh[2].tap;
+        if (key != wkey) {
+          wkey = key;
+#pragma unroll
+          for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+            for (int oh = 0; oh < 3; ++oh)
+#pragma unroll
+              for (int ow = 0; ow < 3; ++ow)
+                wr[(ot * 3 + oh) * 3 + ow] = ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * 256 + lane * 4);
+        }
+      }
       f32x4 acc[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* rowq[3];
 #pragma unroll
-      for (int ot = 0; ot < 3; ++ot) {
+      for (int oh = 0; oh < 3; ++oh) rowq[oh] = s_x + (long)slot_of[oh] * kC16Row * 16 + kq * (kC16Row * 4) + j * 4;
+      // LDS fragment reads of tap tp+1 are issued before the MFMAs of tap tp (two register sets)
+      f32x4 xb[2][2];
+      auto rd = [&](int tp, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
+        const int ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
+        // staged index of the source pixel: fwd p + ow ; dgrad p - ow + 2   (p = column inside the strip)
+        const int sh_px = (MODE == FWD_REP) ? ow : 2 - ow;
+        const float* rp = rowq[oh] + ot * 3 * kC16Row * 16 + sh_px * 4;
+        x0 = ld4(rp);
+        x1 = ld4(rp + blk1 * 4);
+      };
+      rd(0, xb[0][0], xb[0][1]);
 #pragma unroll
-        for (int oh = 0; oh < 3; ++oh) {
-          const float* rowp = s_x + (long)(ot * 3 + slot_of[oh]) * kC16Row * 16 + kq * (kC16Row * 4) + j * 4;
-          const int sel = st[ot].tap * 3 + sh[oh].tap;               // weight row (uniform; differs from ot*3+oh only at edges of the dgrad)
+      for (int tp = 0; tp < 27; ++tp) {
+        if (tp + 1 < 27) rd(tp + 1, xb[(tp + 1) & 1][0], xb[(tp + 1) & 1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 wf = wr[tp];
 #pragma unroll
-          for (int gs = 0; gs < 9; ++gs) {
-            if (MODE == FWD_REP ? (gs != ot * 3 + oh) : (gs != sel)) continue;
-#pragma unroll
-            for (int ow = 0; ow < 3; ++ow) {
-              // staged index of the source pixel: fwd p + ow ; dgrad p - ow + 2   (p = column inside the strip)
-              const int sh_px = (MODE == FWD_REP) ? ow : 2 - ow;
-              const f32x4 x0 = ld4(rowp + sh_px * 4);
-              const f32x4 x1 = ld4(rowp + (sh_px + blk1) * 4);
-              const f32x4 wf = wr[gs * 3 + ow];
-#pragma unroll
-              for (int s = 0; s < 4; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], x0[s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], x1[s], acc[1], 0, 0, 0);
-              }
-            }
-          }
+        for (int s = 0; s < 4; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][0][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][1][s], acc[1], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // epilogue
       float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
