@@ -1091,6 +1091,9 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
   const int QC = a.C / 4, Gi = a.C / 16;
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
   const long npix = (long)a.B * a.H * a.W;
+  // this lane's 4 channels of all 18 taps stay in registers (re-read when the weight set changes: per-variable heads)
+  f32x4 wr[18];
+  int wcur = -1;
   for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
     const long p = p0 + pl;
     float acc = 0.f;
@@ -1098,23 +1101,36 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
     if (p < npix && q < QC) {
       const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H);
       b = (int)(p / ((long)a.W * a.H));
-      const float* wp = a.w + (long)(b % a.wsets) * 18 * Gi * 256;
+      const int wset = b % a.wsets;
+      if (wset != wcur) {
+        wcur = wset;
+        const float* wp = a.w + (long)wset * 18 * Gi * 256;
+#pragma unroll
+        for (int tap = 0; tap < 18; ++tap) wr[tap] = c1_w4_fwd(wp, Gi, tap, q);
+      }
       const float* xb = a.x + (long)b * a.x_sB + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
+      // all 18 loads are issued before the first fma (taps outside the frame load the clamped pixel and weigh it 0):
+      // a branch per tap would serialise 18 memory round trips
+      f32x4 xv[18];
+      float on[18];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int oh = 0; oh < 3; ++oh) {
-          const int hs = h + oh - 1;
-          if (hs < 0 || hs >= a.H) continue;
+        for (int oh = 0; oh < 3; ++oh)
 #pragma unroll
           for (int ow = 0; ow < 3; ++ow) {
-            const int ws = w + ow - 1;
-            if (ws < 0 || ws >= a.W) continue;
-            const f32x4 xv = ld4(xb + (long)kt * a.x_sT + (long)hs * a.x_sH + (long)ws * a.x_sW);
-            const f32x4 wv = c1_w4_fwd(wp, Gi, (kt * 3 + oh) * 3 + ow, q);
-            acc = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc))));
+            const int hs = h + oh - 1, ws = w + ow - 1;
+            const bool ok = hs >= 0 && hs < a.H && ws >= 0 && ws < a.W;
+            const int hc = min(max(hs, 0), a.H - 1), wc = min(max(ws, 0), a.W - 1);
+            const int tap = (kt * 3 + oh) * 3 + ow;
+            xv[tap] = ld4(xb + (long)kt * a.x_sT + (long)hc * a.x_sH + (long)wc * a.x_sW);
+            on[tap] = ok ? 1.f : 0.f;
           }
-        }
+#pragma unroll
+      for (int tap = 0; tap < 18; ++tap) {
+        const f32x4 pr = xv[tap] * wr[tap];
+        acc = fmaf(on[tap], (pr[0] + pr[1]) + (pr[2] + pr[3]), acc);
+      }
     }
 #pragma unroll
     for (int o = 1; o < LPP; o <<= 1) acc += __shfl_xor(acc, o, 64);
