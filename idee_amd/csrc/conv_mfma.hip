@@ -693,6 +693,124 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
 }
 
 // ---------------------------------------------------------------------------------------------
+// weight gradient of the 16 -> 16 3x3x3 replicate convolution, every WAVE on its own (the structure of
+// conv16_lds_kernel): a wave owns a strip of 2 column blocks (32 pixels) and walks a run of rows of one (batch item, t),
+// keeping a private LDS ring of 3 source rows x 3 T-slots (pixel-major [pixel][16 channels]: the A operand of a
+// K = pixels MFMA is 64 consecutive floats, conflict-free).  dy fragments come straight from global memory (one
+// coalesced 256-byte load per 4 pixels).  All 27 tap accumulators (16 x 16 each) stay in registers for the wave's
+// whole share and are flushed once with atomics.  No workgroup barrier anywhere.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
+  __shared__ __attribute__((aligned(16))) float s_xw[4][9 * kC16Row * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  float* s_x = s_xw[wave];
+  f32x4 acc[27];
+#pragma unroll
+  for (int tp = 0; tp < 27; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const int nsub = (a.W + 15) / 16;
+  const int nb = a.B / a.wsets;
+  const long nunits = (long)nb * a.T * nhrun * nstrip;
+
+  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+    long r = un;
+    const int sp = (int)(r % nstrip); r /= nstrip;
+    const int hr = (int)(r % nhrun); r /= nhrun;
+    const int t = (int)(r % a.T);
+    const int b = (int)(r / a.T) * a.wsets + wset;
+    const int my_sub = min(2, nsub - sp * 2);
+    const int p0 = sp * 32;
+    const int rowlen = my_sub * 16 + 2;
+    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;
+    const float* x_b = a.x + (long)b * a.x_sB;
+    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
+    int tsrc[3];
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot) tsrc[ot] = min(max(t + ot - 1, 0), a.T - 1);
+
+    for (int h = h0; h < h1; ++h) {
+      wave_fence();   // previous row's reads are ordered before this row's staging writes
+      // dy fragments of this row: lane (cout = r16, pixel 4*kb + kq); pixels past the row end contribute zero
+      float bf[8];
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const int p = p0 + 4 * kb + kq;
+        bf[kb] = (kb < 4 * my_sub && p < a.W) ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW + r16] : 0.f;
+      }
+      int slot_of[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const int hs = min(max(h + oh - 1, 0), a.H - 1);
+        const int slot = hs % 3;
+        slot_of[oh] = slot;
+        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+        if (cur == hs) continue;
+        if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
+        f32x4 stg[3][3];      // all loads of the 3 T-slots first, then the LDS writes
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) {
+          const float* src = x_b + (long)tsrc[ot] * a.x_sT + (long)hs * a.x_sH;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < rowlen * 4) {
+              const int w = min(max(p0 + (u >> 2) - 1, 0), a.W - 1);
+              v = ld4(src + (long)w * a.x_sW + 4 * (u & 3));
+            }
+            stg[ot][k] = v;
+          }
+        }
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) {
+          float* dst = s_x + (long)(ot * 3 + slot) * kC16Row * 16;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            if (u < kC16Row * 4) st4(dst + u * 4, stg[ot][k]);     // pixels past a one-block strip are written as zeros
+          }
+        }
+      }
+      wave_fence();
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) bsum += bf[kb];
+      // acc[tap][cin][cout] += sum over the strip's pixels of x[pixel + tap offset][cin] dy[pixel][cout]
+      const float* rowq[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) rowq[oh] = s_x + ((long)slot_of[oh] * kC16Row + kq) * 16 + r16;
+      // (a one-block strip multiplies its absent second block by zero dy fragments: branch-free tap loop)
+#pragma unroll
+      for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+        for (int oh = 0; oh < 3; ++oh)
+#pragma unroll
+          for (int ow = 0; ow < 3; ++ow) {
+            const float* ap = rowq[oh] + (ot * 3 * kC16Row + ow) * 16;
+            const int tp = (ot * 3 + oh) * 3 + ow;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb)
+              acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kb * 64], bf[kb], acc[tp], 0, 0, 0);
+          }
+    }
+  }
+  float* dw = a.dwp + (long)wset * 27 * 16 * 16;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * 16 + col, acc[tp][r]);
+  if (a.dbias) {
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 16) atomicAdd(a.dbias + (long)wset * 16 + lane, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient of the 16 -> 16 convolutions, LDS-staged.
 // A workgroup walks a run of output rows (fixed batch item and t).  Per row it keeps in LDS the
 // source rows of x it needs — a ring of 3 h-rows for each of the 2-3 t-slots, with a one-pixel halo
@@ -1523,8 +1641,15 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const int nhrun = cdiv(d->H, hrun);
     const long nchunks = bt * nhrun * nseg;
     if (rep) {
-      auto kern = wgrad16_lds_kernel<FWD_REP, 8>;
-      hipLaunchKernelGGL(kern, dim3(one_round(nchunks, d->wsets, wg_per_cu(kern, 512)), d->wsets), dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
+      const int nstrip = cdiv(cdiv(d->W, 16), 2);
+      const long btr = (long)(d->B / d->wsets) * a.To;
+      int hr2 = d->H;                                       // runs short enough for ~5 work units per resident wave
+      while (hr2 > 8 && btr * cdiv(d->H, hr2) * nstrip * d->wsets < 5L * kCUs * 8) hr2 = (hr2 + 1) / 2;
+      const int nhr2 = cdiv(d->H, hr2);
+      const long nunits = btr * nhr2 * nstrip;
+      auto kern = wgrad16_strip_kernel;
+      hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), d->wsets, wg_per_cu(kern, 256)), d->wsets), dim3(256), 0, st, a,
+                         nstrip, hr2, nhr2);
     } else {
       auto kern = wgrad16_lds_kernel<FWD_S2, 8>;
       hipLaunchKernelGGL(kern, dim3(one_round(nchunks, d->wsets, wg_per_cu(kern, 512)), d->wsets), dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
