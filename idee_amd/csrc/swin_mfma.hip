@@ -499,7 +499,12 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
   constexpr int HP = 2;                 // hidden 16-blocks per pass (keeps the live set within 256 registers)
   constexpr int TOK = 16 * M;           // tokens per wave and iteration
   static_assert(HT % HP == 0, "hidden blocks per pass");
-  __shared__ __attribute__((aligned(16))) float s_img[4][(2 * CT + 2) * 16 * VS];
+  constexpr int VSM = TOK + 4;          // image row stride (floats)
+  __shared__ __attribute__((aligned(16))) float s_img[4][(2 * CT + 2) * 16 * VSM];
+  // weight fragments in lane-fragment order (fragment i, lane l -> 16 bytes at (i * 64 + l) * 4), shared by the 4 waves:
+  // one ds_read_b128 where used instead of four strided global loads per fragment and pass
+  constexpr int F_W1 = 0, F_W2T = HT * CT, F_W1T = 2 * HT * CT, F_B1 = 3 * HT * CT, NF = 3 * HT * CT + HT;
+  __shared__ __attribute__((aligned(16))) float s_wf[NF * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y, v = b % V;
@@ -517,11 +522,25 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
 #pragma unroll
   for (int k = 0; k < CT; ++k) pb2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  {
+    int i = 0;
+#pragma unroll
+    for (int ho = 0; ho < HT; ++ho) {
+      if ((i++) % 4 == wave) st4(s_wf + (F_B1 + ho) * 256 + lane * 4, vfrag<1>(fc1_b, 16 * ho, lane));
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if ((i++) % 4 == wave) st4(s_wf + (F_W1 + ho * CT + c) * 256 + lane * 4, wfrag<false, 1, 1>(fc1_w, C, 16 * ho, 16 * c, lane));
+        if ((i++) % 4 == wave) st4(s_wf + (F_W2T + ho * CT + c) * 256 + lane * 4, wfrag<true, 1, 1>(fc2_w, HID, 16 * ho, 16 * c, lane));   // [hid][c] = fc2_w[c][hid]
+        if ((i++) % 4 == wave) st4(s_wf + (F_W1T + c * HT + ho) * 256 + lane * 4, wfrag<true, 1, 1>(fc1_w, C, 16 * c, 16 * ho, lane));     // [c][hid] = fc1_w[hid][c]
+      }
+    }
+    __syncthreads();
+  }
   float* img = s_img[wave];
   float* imgHN = img;                       // CT images
-  float* imgDY = img + CT * 16 * VS;        // CT images
-  float* imgA = img + 2 * CT * 16 * VS;     // dA1 tile
-  float* imgB = imgA + 16 * VS;             // gelu tile
+  float* imgDY = img + CT * 16 * VSM;        // CT images
+  float* imgA = img + 2 * CT * 16 * VSM;     // dA1 tile
+  float* imgB = imgA + 16 * VSM;             // gelu tile
   const long items = (L + TOK - 1) / TOK;
 
   for (long it0 = (long)blockIdx.x * 4; it0 < items; it0 += (long)gridDim.x * 4) {
@@ -549,8 +568,8 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
     wave_sync();   // previous iteration's image readers are done
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-      put_img<1>(imgHN + c * 16 * VS, HN[c], lane);
-      put_img<1>(imgDY + c * 16 * VS, DY[c], lane);
+      put_img<1, M, VSM>(imgHN + c * 16 * VSM, HN[c], lane);
+      put_img<1, M, VSM>(imgDY + c * 16 * VSM, DY[c], lane);
 #pragma unroll
       for (int m = 0; m < M; ++m) pb2[c] += DY[c][m];
     }
@@ -562,21 +581,17 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
 
 #pragma unroll
     for (int hp = 0; hp < HT / HP; ++hp) {
-      // fragments of this pass (L1/L2-resident; re-read each pass instead of pinning 48 registers)
+      // fragments of this pass come from LDS (re-read each pass instead of pinning 48 registers)
       f32x4 w1[HP][CT], w2t[HP][CT], w1t[CT][HP], A1[HP][M], dG[HP][M];
-      int oz;   // opaque zero: pins this pass's fragment loads inside the pass (no hoisting across passes)
-      asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
-      const float* fc1_w_ = fc1_w + oz;
-      const float* fc2_w_ = fc2_w + oz;
 #pragma unroll
       for (int o = 0; o < HP; ++o) {
         const int ho = hp * HP + o;
-        const f32x4 b1 = vfrag<1>(fc1_b + oz, 16 * ho, lane);
+        const f32x4 b1 = ld4(s_wf + (F_B1 + ho) * 256 + lane * 4);
 #pragma unroll
         for (int k = 0; k < CT; ++k) {
-          w1[o][k] = wfrag<false, 1, 1>(fc1_w_, C, 16 * ho, 16 * k, lane);
-          w2t[o][k] = wfrag<true, 1, 1>(fc2_w_, HID, 16 * ho, 16 * k, lane);   // [hid][c] = fc2_w[c][hid]
-          w1t[k][o] = wfrag<true, 1, 1>(fc1_w_, C, 16 * k, 16 * ho, lane);     // [c][hid] = fc1_w[hid][c]
+          w1[o][k] = ld4(s_wf + (F_W1 + ho * CT + k) * 256 + lane * 4);
+          w2t[o][k] = ld4(s_wf + (F_W2T + ho * CT + k) * 256 + lane * 4);
+          w1t[k][o] = ld4(s_wf + (F_W1T + k * HT + ho) * 256 + lane * 4);
         }
 #pragma unroll
         for (int m = 0; m < M; ++m) { A1[o][m] = b1; dG[o][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -599,13 +614,13 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
       for (int o = 0; o < HP; ++o) {
         const int ho = hp * HP + o;
         if (hp + o) wave_sync();
-        put_img<1>(imgA, dG[o], lane);
-        put_img<1>(imgB, A1[o], lane);
+        put_img<1, M, VSM>(imgA, dG[o], lane);
+        put_img<1, M, VSM>(imgB, A1[o], lane);
         wave_sync();
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          gemm_tok<M>(aW1[ho][c], imgA, imgHN + c * 16 * VS, lane);
-          gemm_tok<M>(aW2[c][ho], imgDY + c * 16 * VS, imgB, lane);
+          gemm_tok<M, VSM>(aW1[ho][c], imgA, imgHN + c * 16 * VSM, lane);
+          gemm_tok<M, VSM>(aW2[c][ho], imgDY + c * 16 * VSM, imgB, lane);
         }
       }
     }
