@@ -700,26 +700,28 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
 // coalesced 256-byte load per 4 pixels).  All 27 tap accumulators (16 x 16 each) stay in registers for the wave's
 // whole share and are flushed once with atomics.  No workgroup barrier anywhere.
 // ---------------------------------------------------------------------------------------------
+template <int MODE /*FWD_REP: 3x3x3 replicate ; FWD_S2: (2,3,3) stride (2,1,1) zero padding*/>
 __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
-  __shared__ __attribute__((aligned(16))) float s_xw[4][9 * kC16Row * 16];
+  constexpr int TSL = MODE == FWD_REP ? 3 : 2, NTAPS = TSL * 9;
+  __shared__ __attribute__((aligned(16))) float s_xw[4][TSL * 3 * kC16Row * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
   float* s_x = s_xw[wave];
-  f32x4 acc[27];
+  f32x4 acc[NTAPS];
 #pragma unroll
-  for (int tp = 0; tp < 27; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tp = 0; tp < NTAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   const int nsub = (a.W + 15) / 16;
   const int nb = a.B / a.wsets;
-  const long nunits = (long)nb * a.T * nhrun * nstrip;
+  const long nunits = (long)nb * a.To * nhrun * nstrip;
 
   for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
     long r = un;
     const int sp = (int)(r % nstrip); r /= nstrip;
     const int hr = (int)(r % nhrun); r /= nhrun;
-    const int t = (int)(r % a.T);
-    const int b = (int)(r / a.T) * a.wsets + wset;
+    const int t = (int)(r % a.To);
+    const int b = (int)(r / a.To) * a.wsets + wset;
     const int my_sub = min(2, nsub - sp * 2);
     const int p0 = sp * 32;
     const int rowlen = my_sub * 16 + 2;
@@ -727,9 +729,9 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
     int res0 = -1, res1 = -1, res2 = -1;
     const float* x_b = a.x + (long)b * a.x_sB;
     const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
-    int tsrc[3];
+    int tsrc[TSL];
 #pragma unroll
-    for (int ot = 0; ot < 3; ++ot) tsrc[ot] = min(max(t + ot - 1, 0), a.T - 1);
+    for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : 2 * t + ot;
 
     for (int h = h0; h < h1; ++h) {
       wave_fence();   // previous row's reads are ordered before this row's staging writes
@@ -743,29 +745,32 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
       int slot_of[3];
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) {
-        const int hs = min(max(h + oh - 1, 0), a.H - 1);
-        const int slot = hs % 3;
+        // replicate: the clamped row ; zero padding: rows -1 and H are staged as zeros (ring key hs + 1 >= 0)
+        const int hs = MODE == FWD_REP ? min(max(h + oh - 1, 0), a.H - 1) : h + oh - 1;
+        const bool inside = hs >= 0 && hs < a.H;
+        const int slot = (hs + 3) % 3;
         slot_of[oh] = slot;
         const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
-        if (cur == hs) continue;
-        if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
-        f32x4 stg[3][3];      // all loads of the 3 T-slots first, then the LDS writes
+        if (cur == hs + 1) continue;
+        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
+        f32x4 stg[TSL][3];      // all loads of the T-slots first, then the LDS writes
 #pragma unroll
-        for (int ot = 0; ot < 3; ++ot) {
+        for (int ot = 0; ot < TSL; ++ot) {
           const float* src = x_b + (long)tsrc[ot] * a.x_sT + (long)hs * a.x_sH;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int u = lane + 64 * k;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (u < rowlen * 4) {
-              const int w = min(max(p0 + (u >> 2) - 1, 0), a.W - 1);
-              v = ld4(src + (long)w * a.x_sW + 4 * (u & 3));
+            if (u < rowlen * 4 && inside) {
+              const int w = p0 + (u >> 2) - 1;
+              if (MODE == FWD_REP) v = ld4(src + (long)min(max(w, 0), a.W - 1) * a.x_sW + 4 * (u & 3));
+              else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * (u & 3));
             }
             stg[ot][k] = v;
           }
         }
 #pragma unroll
-        for (int ot = 0; ot < 3; ++ot) {
+        for (int ot = 0; ot < TSL; ++ot) {
           float* dst = s_x + (long)(ot * 3 + slot) * kC16Row * 16;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
       for (int oh = 0; oh < 3; ++oh) rowq[oh] = s_x + ((long)slot_of[oh] * kC16Row + kq) * 16 + r16;
       // (a one-block strip multiplies its absent second block by zero dy fragments: branch-free tap loop)
 #pragma unroll
-      for (int ot = 0; ot < 3; ++ot)
+      for (int ot = 0; ot < TSL; ++ot)
 #pragma unroll
         for (int oh = 0; oh < 3; ++oh)
 #pragma unroll
@@ -796,188 +801,13 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
           }
     }
   }
-  float* dw = a.dwp + (long)wset * 27 * 16 * 16;
-  const int col = lane & 15, r0 = (lane >> 4) * 4;
-#pragma unroll
-  for (int tp = 0; tp < 27; ++tp)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * 16 + col, acc[tp][r]);
-  if (a.dbias) {
-    float v = bsum;
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (lane < 16) atomicAdd(a.dbias + (long)wset * 16 + lane, v);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// weight gradient of the 16 -> 16 convolutions, LDS-staged.
-// A workgroup walks a run of output rows (fixed batch item and t).  Per row it keeps in LDS the
-// source rows of x it needs — a ring of 3 h-rows for each of the 2-3 t-slots, with a one-pixel halo
-// so replicate / zero padding is resolved at staging time — plus the dy row.  Moving to the next
-// row stages only the one new h-row per t-slot.  The taps are dealt round-robin to the waves; a
-// k-step (4 pixels) costs each wave one conflict-free 4-byte LDS read per operand fragment.
-// ---------------------------------------------------------------------------------------------
-constexpr int kSegMax = 100;   // widest row segment held in LDS (65 KB for the 3x3x3 mode: two workgroups per CU,
-                               // so one stages rows while the other computes)
-
-template <int MODE /*FWD_REP or FWD_S2*/, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void wgrad16_lds_kernel(WgradArgs a, int seg, int nseg, int hrun, int nhrun) {
-  constexpr int NTAPS = MODE == FWD_REP ? 27 : 18;
-  constexpr int TSL = MODE == FWD_REP ? 3 : 2;
-  constexpr int TPWV = (NTAPS + WAVES - 1) / WAVES;
-  __shared__ __attribute__((aligned(16))) float s_x[TSL * 3 * (kSegMax + 2) * 16];
-  __shared__ __attribute__((aligned(16))) float s_dy[kSegMax * 16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int wset = blockIdx.y;
-  const int rowlen = seg + 2;                 // staged pixels per source row
-  const int segp = (seg + 3) & ~3;
-
-  f32x4 acc[TPWV];
-  float bsum = 0.f;
-#pragma unroll
-  for (int k = 0; k < TPWV; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nb = a.B / a.wsets;
-  const long nchunks = (long)nb * a.To * nhrun * nseg;
-  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    long r = ch;
-    const int sg = (int)(r % nseg); r /= nseg;
-    const int hr = (int)(r % nhrun); r /= nhrun;
-    const int t = (int)(r % a.To);
-    const int b = (int)(r / a.To) * a.wsets + wset;
-    const int w0 = sg * seg;
-    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
-    int res0 = -1, res1 = -1, res2 = -1;     // source h-row resident in ring slot 0/1/2
-    const float* x_b = a.x + (long)b * a.x_sB;
-    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
-
-    // Row pipeline: while the MFMAs of row h run out of LDS, the global loads of row h+1 (its new source rows of all
-    // T-slots and its dy row) are already in flight into registers; they are written to LDS after the barrier that
-    // ends row h.  Every load of a row step is issued before any LDS write (a load/wait/write loop would pay one L2
-    // round trip per piece; rowlen * 4 <= 512 = one piece per thread).
-    const int px_ = tid >> 2, q4_ = tid & 3;
-    int slot_of[3] = {0, 0, 0};
-    bool ok_h[3] = {false, false, false};
-    // iteration h = h0 - 1 only stages the first row
-    for (int h = h0 - 1; h < h1; ++h) {
-      const bool more = h + 1 < h1;
-      int n_slot[3] = {0, 0, 0}, n_hsrc[3] = {0, 0, 0};
-      bool n_ok[3] = {false, false, false}, n_fresh[3] = {false, false, false};
-      f32x4 stg[3][TSL], stg_dy = {0.f, 0.f, 0.f, 0.f};
-      if (more) {
-        const int hn = h + 1;
-#pragma unroll
-        for (int oh = 0; oh < 3; ++oh) {
-          int hs = hn + oh - 1;
-          if (MODE == FWD_REP) { hs = min(max(hs, 0), a.H - 1); n_ok[oh] = true; }
-          else n_ok[oh] = hs >= 0 && hs < a.H;
-          const int slot = ((hs % 3) + 3) % 3;
-          n_slot[oh] = slot;
-          n_hsrc[oh] = hs;
-          if (!n_ok[oh]) continue;
-          const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
-          if (cur == hs) continue;
-          if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
-          n_fresh[oh] = true;
-        }
-#pragma unroll
-        for (int oh = 0; oh < 3; ++oh) {
-#pragma unroll
-          for (int ts = 0; ts < TSL; ++ts) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n_fresh[oh] && tid < rowlen * 4) {
-              const int tsrc = MODE == FWD_REP ? min(max(t + ts - 1, 0), a.T - 1) : 2 * t + ts;
-              const float* src = x_b + (long)tsrc * a.x_sT + (long)n_hsrc[oh] * a.x_sH;
-              int w = w0 + px_ - 1;
-              if (MODE == FWD_REP) { w = min(max(w, 0), a.W - 1); v = ld4(src + (long)w * a.x_sW + 4 * q4_); }
-              else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * q4_);
-            }
-            stg[oh][ts] = v;
-          }
-        }
-        if (tid < segp * 4) {
-          const int w = w0 + px_;
-          if (px_ < seg && w < a.W) stg_dy = ld4(dy_b + (long)hn * a.y_sH + (long)w * a.y_sW + 4 * q4_);
-        }
-      }
-      if (h >= h0) {
-      int base[TPWV];
-      bool okt[TPWV];
-#pragma unroll
-      for (int k = 0; k < TPWV; ++k) {
-        const int tap = wave + k * WAVES;
-        const int ot = tap / 9, oh = (tap / 3) % 3, ow = tap % 3;
-        const bool okh = oh == 0 ? ok_h[0] : oh == 1 ? ok_h[1] : ok_h[2];              // selects: a runtime index would
-        const int slot = oh == 0 ? slot_of[0] : oh == 1 ? slot_of[1] : slot_of[2];     // put the arrays in scratch
-        okt[k] = tap < NTAPS && okh;
-        base[k] = ((ot * 3 + slot) * rowlen + ow + kq) * 16 + r16;
-      }
-      const int steps = segp >> 2;
-      // branch-free inner loops when this wave's taps are all live (always in the replicate mode, interior rows otherwise)
-      int nlive = 0;
-      bool prefix = true;
-#pragma unroll
-      for (int k = 0; k < TPWV; ++k) {
-        const bool in_range = wave + k * WAVES < NTAPS;
-        if (in_range && !okt[k]) prefix = false;
-        if (in_range) nlive = k + 1;
-      }
-      const float* dyp = s_dy + kq * 16 + r16;
-      if (prefix && nlive == TPWV) {
-#pragma unroll 2
-        for (int s = 0; s < steps; ++s) {
-          const float bf = dyp[s * 64];
-          bsum += bf;
-#pragma unroll
-          for (int k = 0; k < TPWV; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_x[base[k] + s * 64], bf, acc[k], 0, 0, 0);
-        }
-      } else if (prefix && nlive == TPWV - 1) {
-#pragma unroll 2
-        for (int s = 0; s < steps; ++s) {
-          const float bf = dyp[s * 64];
-          bsum += bf;
-#pragma unroll
-          for (int k = 0; k < TPWV - 1; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_x[base[k] + s * 64], bf, acc[k], 0, 0, 0);
-        }
-      } else {
-        for (int s = 0; s < steps; ++s) {
-          const float bf = dyp[s * 64];
-          bsum += bf;
-#pragma unroll
-          for (int k = 0; k < TPWV; ++k) {
-            if (!okt[k]) continue;
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_x[base[k] + s * 64], bf, acc[k], 0, 0, 0);
-          }
-        }
-      }
-      }
-      if (more) {
-        __syncthreads();   // this row's readers are done: the ring slot of row h-1 and the dy row may be overwritten
-#pragma unroll
-        for (int oh = 0; oh < 3; ++oh) {
-          if (!n_fresh[oh] || tid >= rowlen * 4) continue;
-#pragma unroll
-          for (int ts = 0; ts < TSL; ++ts) st4(s_x + ((long)(ts * 3 + n_slot[oh]) * rowlen + px_) * 16 + 4 * q4_, stg[oh][ts]);
-        }
-        if (tid < segp * 4) st4(s_dy + px_ * 16 + 4 * q4_, stg_dy);
-        __syncthreads();
-      }
-#pragma unroll
-      for (int oh = 0; oh < 3; ++oh) { slot_of[oh] = n_slot[oh]; ok_h[oh] = n_ok[oh]; }
-    }
-  }
   float* dw = a.dwp + (long)wset * NTAPS * 16 * 16;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
-  for (int k = 0; k < TPWV; ++k) {
-    const int tap = wave + k * WAVES;
-    if (tap >= NTAPS) continue;
+  for (int tp = 0; tp < NTAPS; ++tp)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tap * 16 + r0 + r) * 16 + col, acc[k][r]);
-  }
-  if (a.dbias && wave == 0) {
+    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * 16 + col, acc[tp][r]);
+  if (a.dbias) {
     float v = bsum;
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -1632,27 +1462,23 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     hipLaunchKernelGGL((wgrad_kernel<MODE_, TPW_, NTA_, NTB_>), dim3(gx, gy, d->wsets), dim3(256), 0, st, a); \
   } while (0)
   if (Ga == 1 && Gb == 1 && d->Cout == 16 && d->mode != IDEE_CONV_K133_ZERO) {
-    // LDS-staged kernel: row segments of <= kSegMax pixels, runs of hrun rows per (b, t)
-    const int nseg = cdiv(d->W, kSegMax);
-    const int seg = ((cdiv(d->W, nseg) + 3) / 4) * 4 > kSegMax ? kSegMax : ((cdiv(d->W, nseg) + 3) / 4) * 4;
-    const long bt = (long)(d->B / d->wsets) * a.To;
-    int hrun = d->H;                       // shrink the run until the chip is covered ~3 times
-    while (hrun > 8 && bt * cdiv(d->H, hrun) * nseg * d->wsets < 6L * kCUs) hrun = (hrun + 1) / 2;
-    const int nhrun = cdiv(d->H, hrun);
-    const long nchunks = bt * nhrun * nseg;
-    if (rep) {
+    // wave-private strip kernel: strips of 32 pixels, runs of rows per (b, t)
+    {
       const int nstrip = cdiv(cdiv(d->W, 16), 2);
       const long btr = (long)(d->B / d->wsets) * a.To;
       int hr2 = d->H;                                       // runs short enough for ~5 work units per resident wave
       while (hr2 > 8 && btr * cdiv(d->H, hr2) * nstrip * d->wsets < 5L * kCUs * 8) hr2 = (hr2 + 1) / 2;
       const int nhr2 = cdiv(d->H, hr2);
       const long nunits = btr * nhr2 * nstrip;
-      auto kern = wgrad16_strip_kernel;
-      hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), d->wsets, wg_per_cu(kern, 256)), d->wsets), dim3(256), 0, st, a,
-                         nstrip, hr2, nhr2);
-    } else {
-      auto kern = wgrad16_lds_kernel<FWD_S2, 8>;
-      hipLaunchKernelGGL(kern, dim3(one_round(nchunks, d->wsets, wg_per_cu(kern, 512)), d->wsets), dim3(512), 0, st, a, seg, nseg, hrun, nhrun);
+      if (rep) {
+        auto kern = wgrad16_strip_kernel<FWD_REP>;
+        hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), d->wsets, wg_per_cu(kern, 256)), d->wsets), dim3(256), 0, st, a,
+                           nstrip, hr2, nhr2);
+      } else {
+        auto kern = wgrad16_strip_kernel<FWD_S2>;
+        hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), d->wsets, wg_per_cu(kern, 256)), d->wsets), dim3(256), 0, st, a,
+                           nstrip, hr2, nhr2);
+      }
     }
   }
   else if (!rep && (Ga == Gb || Ga == 1) && (Gb == 6 || Gb == 3 || Gb == 2) && d->Cout % 16 == 0) {
