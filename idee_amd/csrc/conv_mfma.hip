@@ -533,9 +533,11 @@ __device__ __forceinline__ void wave_fence() {   // LDS hand-off inside one wave
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int MODE /*FWD_REP or DGRAD_REP*/>
+template <int MODE /*FWD_REP, DGRAD_REP: 3x3x3 replicate ; FWD_S2, DGRAD_S2: (kt,3,3) zero padding, 16 -> 16*/>
 __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
   constexpr int MT = 2;
+  constexpr bool REP = MODE == FWD_REP || MODE == DGRAD_REP;
+  constexpr int TSN = REP ? 3 : (MODE == FWD_S2 ? 2 : 1);      // T-slots a row step reads
   __shared__ __attribute__((aligned(16))) float s_xw[4][9 * kC16Row * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -545,9 +547,9 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
   // conv always uses tap (ot, oh, ow); the data gradient flips a T / H tap where the replicate padding folds a source
   // row back (first / last frame, first / last row) — the 27 fragments are re-read (27 KB from L2) when that pattern
   // changes, so the tap loop below indexes registers statically and stays one straight-line, software-pipelined block
-  f32x4 wr[27];
+  f32x4 wr[TSN * 9];
   int wkey = -1;
-  const float* wp = a.wp + (long)wset * 27 * 256;
+  const float* wp = a.wp + (long)wset * a.ntaps * 256;
   const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
   const int nsub = (Wframe + 15) / 16;
   const int nb = a.B / a.wsets;
@@ -577,29 +579,31 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) {
         sh[oh] = slot_h<MODE>(oh, h, a.Hi);
-        const int hs = sh[oh].src;
-        const int slot = hs % 3;
+        const int hs = sh[oh].src;                    // zero-padded modes: -1 and Hi are staged as rows of zeros
+        const bool inside = sh[oh].ok;
+        const int slot = (hs + 3) % 3;
         slot_of[oh] = slot;
         const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
-        if (cur == hs) continue;
-        if (slot == 0) res0 = hs; else if (slot == 1) res1 = hs; else res2 = hs;
+        if (cur == hs + 1) continue;                  // ring key hs + 1 >= 0
+        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
         // all 9 loads of the 3 T-slots first (up to 3 x 16 bytes per lane and slot), then the LDS writes: a
         // load -> wait -> write loop would serialise 9 L2 round trips per row
-        f32x4 stg[3][3];
+        f32x4 stg[TSN][3];
 #pragma unroll
-        for (int ot = 0; ot < 3; ++ot) {
+        for (int ot = 0; ot < TSN; ++ot) {
           const float* src = in_b + (long)st[ot].src * a.i_sT + (long)hs * a.i_sH;
+          const bool live = inside && st[ot].ok;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int u = lane + 64 * k;
             const int px = u >> 2, q4 = u & 3;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (u < rowlen * 4) {
+            if (u < rowlen * 4 && live) {
               if (MODE == FWD_REP) {
                 const int w = min(max(p0 + px - 1, 0), a.Wi - 1);
                 v = ld4(src + (long)w * a.i_sW + 4 * q4);
               } else {
-                const int w = p0 + px - 2;
+                const int w = p0 + px - (MODE == DGRAD_REP ? 2 : 1);     // the replicate dgrad walks a frame padded by one
                 if (w >= 0 && w < a.Wi) v = ld4(src + (long)w * a.i_sW + 4 * q4);
               }
             }
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
           }
         }
 #pragma unroll
-        for (int ot = 0; ot < 3; ++ot) {
+        for (int ot = 0; ot < TSN; ++ot) {
           float* dst = s_x + (long)(ot * 3 + slot) * kC16Row * 16;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
         if (key != wkey) {
           wkey = key;
 #pragma unroll
-          for (int ot = 0; ot < 3; ++ot)
+          for (int ot = 0; ot < TSN; ++ot)
 #pragma unroll
             for (int oh = 0; oh < 3; ++oh)
 #pragma unroll
@@ -642,15 +646,15 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
       auto rd = [&](int tp, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
         const int ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
         // staged index of the source pixel: fwd p + ow ; dgrad p - ow + 2   (p = column inside the strip)
-        const int sh_px = (MODE == FWD_REP) ? ow : 2 - ow;
+        const int sh_px = (MODE == FWD_REP || MODE == FWD_S2) ? ow : 2 - ow;
         const float* rp = rowq[oh] + ot * 3 * kC16Row * 16 + sh_px * 4;
         x0 = ld4(rp);
         x1 = ld4(rp + blk1 * 4);
       };
       rd(0, xb[0][0], xb[0][1]);
 #pragma unroll
-      for (int tp = 0; tp < 27; ++tp) {
-        if (tp + 1 < 27) rd(tp + 1, xb[(tp + 1) & 1][0], xb[(tp + 1) & 1][1]);
+      for (int tp = 0; tp < TSN * 9; ++tp) {
+        if (tp + 1 < TSN * 9) rd(tp + 1, xb[(tp + 1) & 1][0], xb[(tp + 1) & 1][1]);
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 wf = wr[tp];
 #pragma unroll
@@ -1275,8 +1279,8 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   const bool wlds = (a.GnTot == 1 && a.Gk == 1 && !cin1);
   const int gz = a.GnTot / NT;
   const dim3 block(256);
-  if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
-    if (wlds && a.cout_real == 16) {
+  {
+    if (wlds && a.cout_real == 16 && (MODE == FWD_REP || MODE == DGRAD_REP || a.kt == 2)) {
       const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
       const int nstrip = cdiv(cdiv(Wframe, 16), 2);
       const long bt = (long)(a.B / a.wsets) * a.To;
