@@ -34,13 +34,40 @@ class Adam:
         self.grad_scale = 1.0      # parallel.py sets 1/world after a SUM all-reduce
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
 
-    def zero_grad(self, set_to_none: bool = False):
-        """Zero the flat gradient buffer.  `set_to_none` is accepted for call compatibility with
-        train_synthetic.py:175 but the views are kept (autograd accumulates into them)."""
+    def zero_grad(self, set_to_none: bool = True):
+        """set_to_none=True (what train_synthetic.py:175 passes): drop the gradients, so autograd hands each parameter
+        its gradient tensor as is (no `grad += new` kernel per parameter, no fill); `gather_grads` then copies them into
+        the flat buffer with one multi-tensor copy.  set_to_none=False: zero the flat buffer and keep the parameters'
+        .grad as views of it (autograd accumulates in place)."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+            self._gathered = False
+            return
         self.flat_g.zero_()
         for p, g in zip(self.params, self._grad_views()):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g
+        self._gathered = True
+
+    @torch.no_grad()
+    def gather_grads(self):
+        """Bring every parameter's gradient into the flat buffer (idempotent); afterwards p.grad is the flat view."""
+        if getattr(self, "_gathered", True):
+            return
+        views = list(self._grad_views())
+        src, dst = [], []
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad if p.grad.dtype == torch.float32 else p.grad.float())
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, views):
+            p.grad = v
+        self._gathered = True
 
     def _grad_views(self):
         off = 0
@@ -51,6 +78,7 @@ class Adam:
 
     @torch.no_grad()
     def step(self):
+        self.gather_grads()
         g = self.param_groups[0]
         self.step_count += 1
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),

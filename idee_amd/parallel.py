@@ -60,6 +60,8 @@ def broadcast_parameters(flat_p, src=0):
 def sync_gradients(optimizer):
     """SUM all-reduce of the flat gradient bucket; the Adam kernel applies the 1/world."""
     w = world_size()
+    if hasattr(optimizer, "gather_grads"):      # flat-buffer optimizers that let autograd own the per-parameter grads
+        optimizer.gather_grads()
     if w > 1:
         dist.all_reduce(optimizer.flat_g, op=dist.ReduceOp.SUM)
     optimizer.grad_scale = 1.0 / w
