@@ -51,3 +51,5 @@ int main() {
   printf("both, 1 wave   %.3f ms\n", run<3>(out, iters));
   return 0;
 }
+// build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o tools/micro/coexec tools/micro/coexec.hip && ./tools/micro/coexec
+// measured (MI355X):  mfma only 4.626 ms | valu only 2.469 ms | both, 2 waves 6.806 ms | both, 1 wave 12.551 ms
