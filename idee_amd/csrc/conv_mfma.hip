@@ -704,18 +704,26 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
 // coalesced 256-byte load per 4 pixels).  All 27 tap accumulators (16 x 16 each) stay in registers for the wave's
 // whole share and are flushed once with atomics.  No workgroup barrier anywhere.
 // ---------------------------------------------------------------------------------------------
-template <int MODE /*FWD_REP: 3x3x3 replicate ; FWD_S2: (2,3,3) stride (2,1,1) zero padding*/>
+// TSL T-slots per output row: 3 (3x3x3 replicate), 2 ((2,3,3) stride 2) or 1 ((1,3,3)); NB 16-channel output blocks per
+// wave (blockIdx.z picks the group of NB blocks): 16 -> 16*NB*gridDim.z channels, TSL*9*NB accumulator tiles
+template <int MODE /*FWD_REP: 3x3x3 replicate ; FWD_S2: (kt,3,3) zero padding*/, int TSL, int NB>
 __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
-  constexpr int TSL = MODE == FWD_REP ? 3 : 2, NTAPS = TSL * 9;
+  constexpr int NTAPS = TSL * 9;
+  static_assert(NTAPS * NB <= 27, "accumulator tiles must fit the register file");
   __shared__ __attribute__((aligned(16))) float s_xw[4][TSL * 3 * kC16Row * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
   float* s_x = s_xw[wave];
-  f32x4 acc[NTAPS];
+  const int gb0 = blockIdx.z * NB;            // first output block of this workgroup
+  f32x4 acc[NTAPS][NB];
+  float bsum[NB];
 #pragma unroll
-  for (int tp = 0; tp < NTAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  for (int n = 0; n < NB; ++n) {
+    bsum[n] = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < NTAPS; ++tp) acc[tp][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int nsub = (a.W + 15) / 16;
   const int nb = a.B / a.wsets;
   const long nunits = (long)nb * a.To * nhrun * nstrip;
@@ -735,16 +743,19 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
     const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
     int tsrc[TSL];
 #pragma unroll
-    for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : 2 * t + ot;
+    for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : a.kt * t + ot;
 
     for (int h = h0; h < h1; ++h) {
       wave_fence();   // previous row's reads are ordered before this row's staging writes
       // dy fragments of this row: lane (cout = r16, pixel 4*kb + kq); pixels past the row end contribute zero
-      float bf[8];
+      float bf[8][NB];
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
         const int p = p0 + 4 * kb + kq;
-        bf[kb] = (kb < 4 * my_sub && p < a.W) ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW + r16] : 0.f;
+        const bool on = kb < 4 * my_sub && p < a.W;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          bf[kb][n] = on ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW + goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16] : 0.f;
       }
       int slot_of[3];
 #pragma unroll
@@ -785,7 +796,9 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
       }
       wave_fence();
 #pragma unroll
-      for (int kb = 0; kb < 8; ++kb) bsum += bf[kb];
+      for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bsum[n] += bf[kb][n];
       // acc[tap][cin][cout] += sum over the strip's pixels of x[pixel + tap offset][cin] dy[pixel][cout]
       const float* rowq[3];
 #pragma unroll
@@ -800,22 +813,30 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
             const float* ap = rowq[oh] + (ot * 3 * kC16Row + ow) * 16;
             const int tp = (ot * 3 + oh) * 3 + ow;
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb)
-              acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kb * 64], bf[kb], acc[tp], 0, 0, 0);
+            for (int kb = 0; kb < 8; ++kb) {
+              const float af = ap[kb * 64];
+#pragma unroll
+              for (int n = 0; n < NB; ++n) acc[tp][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[kb][n], acc[tp][n], 0, 0, 0);
+            }
           }
     }
   }
-  float* dw = a.dwp + (long)wset * NTAPS * 16 * 16;
+  float* dw = a.dwp + (long)wset * NTAPS * 16 * a.CoutPad;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
   for (int tp = 0; tp < NTAPS; ++tp)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * 16 + col, acc[tp][r]);
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + (gb0 + n) * 16 + col, acc[tp][n][r]);
   if (a.dbias) {
-    float v = bsum;
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (lane < 16) atomicAdd(a.dbias + (long)wset * 16 + lane, v);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      float v = bsum[n];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + (gb0 + n) * 16 + lane, v);
+    }
   }
 }
 
@@ -1465,25 +1486,27 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     a.row_chunks = gx;                                                                                       \
     hipLaunchKernelGGL((wgrad_kernel<MODE_, TPW_, NTA_, NTB_>), dim3(gx, gy, d->wsets), dim3(256), 0, st, a); \
   } while (0)
-  if (Ga == 1 && Gb == 1 && d->Cout == 16 && d->mode != IDEE_CONV_K133_ZERO) {
-    // wave-private strip kernel: strips of 32 pixels, runs of rows per (b, t)
-    {
-      const int nstrip = cdiv(cdiv(d->W, 16), 2);
-      const long btr = (long)(d->B / d->wsets) * a.To;
-      int hr2 = d->H;                                       // runs short enough for ~5 work units per resident wave
-      while (hr2 > 8 && btr * cdiv(d->H, hr2) * nstrip * d->wsets < 5L * kCUs * 8) hr2 = (hr2 + 1) / 2;
-      const int nhr2 = cdiv(d->H, hr2);
-      const long nunits = btr * nhr2 * nstrip;
-      if (rep) {
-        auto kern = wgrad16_strip_kernel<FWD_REP>;
-        hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), d->wsets, wg_per_cu(kern, 256)), d->wsets), dim3(256), 0, st, a,
-                           nstrip, hr2, nhr2);
-      } else {
-        auto kern = wgrad16_strip_kernel<FWD_S2>;
-        hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), d->wsets, wg_per_cu(kern, 256)), d->wsets), dim3(256), 0, st, a,
-                           nstrip, hr2, nhr2);
-      }
-    }
+  if (Ga == 1 && d->Cout % 16 == 0 && (Gb == 1 || (d->mode == IDEE_CONV_K133_ZERO && Gb % 3 == 0))) {
+    // wave-private strip kernel: strips of 32 pixels, runs of rows per (b, t); 16 -> 16 in every mode, and the
+    // (1,3,3) sign-field convs 16 -> 48k with 3 output blocks per wave
+    const int nstrip = cdiv(cdiv(d->W, 16), 2);
+    const int gz = (d->mode == IDEE_CONV_K133_ZERO && Gb > 1) ? Gb / 3 : 1;
+    const long btr = (long)(d->B / d->wsets) * a.To;
+    int hr2 = d->H;                                       // runs short enough for ~5 work units per resident wave
+    while (hr2 > 8 && btr * cdiv(d->H, hr2) * nstrip * d->wsets * gz < 5L * kCUs * 8) hr2 = (hr2 + 1) / 2;
+    const int nhr2 = cdiv(d->H, hr2);
+    const long nunits = btr * nhr2 * nstrip;
+#define LSTRIP(KERN)                                                                                          \
+  do {                                                                                                        \
+    auto kern = KERN;                                                                                         \
+    hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), (long)d->wsets * gz, wg_per_cu(kern, 256)), d->wsets, gz), \
+                       dim3(256), 0, st, a, nstrip, hr2, nhr2);                                               \
+  } while (0)
+    if (rep) LSTRIP((wgrad16_strip_kernel<FWD_REP, 3, 1>));
+    else if (d->mode == IDEE_CONV_K233_S2_ZERO) LSTRIP((wgrad16_strip_kernel<FWD_S2, 2, 1>));
+    else if (Gb == 1) LSTRIP((wgrad16_strip_kernel<FWD_S2, 1, 1>));
+    else LSTRIP((wgrad16_strip_kernel<FWD_S2, 1, 3>));
+#undef LSTRIP
   }
   else if (!rep && (Ga == Gb || Ga == 1) && (Gb == 6 || Gb == 3 || Gb == 2) && d->Cout % 16 == 0) {
     // wide LDS-staged kernel: segment width from the LDS budget (ring of 3 x rows + dy row, padded pixel strides)
