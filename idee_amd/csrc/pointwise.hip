@@ -53,32 +53,39 @@ template <int E, int CIN>
 __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
                                                               int V, long L) {
+  // E/4 adjacent lanes per token, 4 channels each: the output is one contiguous stream of 16-byte pieces
+  constexpr int QE = E / 4;
   const int b = blockIdx.y, v = b % V;
   const float* wv = w + (long)v * E * CIN;
-  const float* bv = bias ? bias + v * E : nullptr;
   const float* xb = x + (long)b * CIN * L;
   float* yb = y + (long)b * L * E;
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < L; tok += (long)gridDim.x * 256) {
+  const int q = threadIdx.x % QE;
+  float wl[4][CIN], bl[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bl[k] = bias ? bias[v * E + 4 * q + k] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) wl[k][c] = wv[(4 * q + k) * CIN + c];
+  }
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
     float xi[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; ++c) xi[c] = xb[c * L + tok];
-    float e[E], mean = 0.f;
+    float e[4], sm = 0.f;
 #pragma unroll
-    for (int o = 0; o < E; ++o) {
-      float a = bv ? bv[o] : 0.f;
+    for (int k = 0; k < 4; ++k) {
+      float a = bl[k];
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) a = fmaf(wv[o * CIN + c], xi[c], a);
-      e[o] = a;
-      mean += a;
+      for (int c = 0; c < CIN; ++c) a = fmaf(wl[k][c], xi[c], a);
+      e[k] = a; sm += a;
     }
-    mean *= (1.f / E);
+    const float mean = tok_sum<QE>(sm) * (1.f / E);
     float var = 0.f;
 #pragma unroll
-    for (int o = 0; o < E; ++o) { const float d = e[o] - mean; var = fmaf(d, d, var); }
-    const float rstd = rsqrtf(var * (1.f / E) + kLnEps);
-#pragma unroll
-    for (int o = 0; o < E; o += 4)
-      st4(yb + tok * E + o, f32x4{(e[o] - mean) * rstd, (e[o + 1] - mean) * rstd, (e[o + 2] - mean) * rstd, (e[o + 3] - mean) * rstd});
+    for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+    st4(yb + tok * E + 4 * q, f32x4{(e[0] - mean) * rstd, (e[1] - mean) * rstd, (e[2] - mean) * rstd, (e[3] - mean) * rstd});
   }
 }
 
@@ -1053,7 +1060,7 @@ int stream_grid(long items) { return imin(cdiv(items, 256), kCUs * 8); }
 extern "C" int idee_patch_embed_ln_fwd(const float* x, const float* w, const float* b, float* y, int N, int V, int Cin,
                                        long L, int E, idee_stream_t stream) {
   IDEE_CHECK_ARG(x && w && y && N > 0 && V > 0 && L > 0, "patch_embed_ln_fwd: bad argument");
-  const dim3 grid(imin(cdiv(L, 256), cdiv((long)kCUs * 8, (long)N * V)), N * V);
+  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, (long)N * V)), N * V);
 #define PE(E_, C_) hipLaunchKernelGGL((patch_embed_fwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, V, L)
   if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
   else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
