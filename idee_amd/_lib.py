@@ -54,6 +54,7 @@ _SIGS = {
     "idee_conv_pack_weights": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "idee_conv_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "idee_conv_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P]),
+    "idee_conv_dgrad_add": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "idee_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "idee_conv_unpack_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P]),
     "idee_ln_relu_res_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P]),

@@ -36,7 +36,7 @@ struct ConvArgs {
   int GnTot;              // output channel groups in total
   int cout_real;          // real output channels (1 => scalar store)
   int relu;
-  int accumulate;         // out += result (plain-store path)
+  const float* addend;    // out = result + addend (same layout as out; may BE out) or null
   int ntaps;
   int kt;                 // temporal taps of the (kt,3,3) zero-padded modes: 2 (stride 2 in T) or 1 (stride 1)
   long i_sB, i_sT, i_sH, i_sW, i_sG, i_sU;
@@ -197,12 +197,12 @@ __global__ __launch_bounds__(256, NT >= 6 ? 2 : 1) void conv_kernel(ConvArgs a) 
           v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
         }
         if (a.cout_real == 1) {
-          if (kq == 0) out_r[(long)wdst * a.o_sW] = a.accumulate ? out_r[(long)wdst * a.o_sW] + v[0] : v[0];
+          if (kq == 0) out_r[(long)wdst * a.o_sW] = a.addend ? (a.addend + (out_r - a.out))[(long)wdst * a.o_sW] + v[0] : v[0];
         } else if (atomic) {
           atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
           atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
         } else {
-          if (a.accumulate) v += ld4(out_r + o);
+          if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
           st4(out_r + o, v);
         }
       }
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
           v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
         }
-        if (a.accumulate) v += ld4(out_r + o);
+        if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
         st4(out_r + o, v);
       }
     }
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
           atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
           atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
         } else {
-          if (a.accumulate) v += ld4(out_r + o);
+          if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
           st4(out_r + o, v);
         }
       }
@@ -972,9 +972,10 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
   }
 }
 
-// the replicate-mode data gradient accumulates its two edge columns (w = 0, W-1) with atomics: clear just those
-__global__ void zero_w_edges_kernel(float* __restrict__ dx, int B, int T, int H, int W, int Cin, long sB, long sT, long sH,
-                                    long sW) {
+// the replicate-mode data gradient accumulates its two edge columns (w = 0, W-1) with atomics: they start from zero,
+// or from the addend's edge columns
+__global__ void init_w_edges_kernel(float* __restrict__ dx, const float* __restrict__ addend, int B, int T, int H, int W, int Cin,
+                                    long sB, long sT, long sH, long sW) {
   const int q4 = Cin / 4;
   const long total = (long)B * T * H * 2 * q4;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -982,7 +983,8 @@ __global__ void zero_w_edges_kernel(float* __restrict__ dx, int B, int T, int H,
     const int side = (int)(r % 2); r /= 2;
     const int h = (int)(r % H); r /= H;
     const int t = (int)(r % T); const long b = r / T;
-    st4(dx + b * sB + t * sT + h * sH + (side ? W - 1 : 0) * sW + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
+    const long o = b * sB + t * sT + h * sH + (side ? W - 1 : 0) * sW + 4 * q;
+    st4(dx + o, addend ? ld4(addend + o) : f32x4{0.f, 0.f, 0.f, 0.f});
   }
 }
 
@@ -1415,9 +1417,16 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const float* x, const floa
 
 extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
                                float* dx, int accumulate, idee_stream_t stream) {
+  return idee_conv_dgrad_add(d, dy, w_packed_dgrad, relu_ref, accumulate ? dx : nullptr, dx, stream);
+}
+
+extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
+                                   const float* addend, float* dx, idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   IDEE_CHECK_ARG(dy && w_packed_dgrad && dx, "conv_dgrad: null argument");
   if (is_c1(d) && d->y_sW == 1 && d->y_sH == d->W && d->y_sB == (long)d->H * d->W) {
+    IDEE_CHECK_ARG(!addend || addend == dx, "conv_dgrad (Cout = 1): a separate addend is not built");
+    const int accumulate = addend != nullptr;
     C1Args c; fill_c1(c, d);
     c.dy = dy; c.w = w_packed_dgrad; c.relu_ref = relu_ref; c.dx = dx; c.accumulate = accumulate;
     if (int rc = launch_c1(1, c, (hipStream_t)stream)) return rc;
@@ -1426,7 +1435,7 @@ extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const f
   }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.in = dy; a.wp = w_packed_dgrad; a.bias = nullptr; a.relu_ref = relu_ref; a.out = dx; a.accumulate = accumulate;
+  a.in = dy; a.wp = w_packed_dgrad; a.bias = nullptr; a.relu_ref = relu_ref; a.out = dx; a.addend = addend;
   a.B = d->B; a.wsets = d->wsets;
   a.Ti = out_T(d); a.Hi = d->H; a.Wi = d->W;
   a.To = d->T; a.Ho = d->H; a.Wo = d->W;
@@ -1438,11 +1447,11 @@ extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const f
   if (d->mode == IDEE_CONV_K333_REPLICATE) {
     IDEE_CHECK_ARG(!cin1, "conv_dgrad: Cout == 1 is only built for the (2,3,3) mode");
     split_tiles(a, a.Wo + 2);
-    if (!accumulate) {   // interior columns are plain stores; the two edge columns are atomics and start from zero
+    if (addend != dx) {   // interior columns are plain stores; the two edge columns are atomics on top of 0 / the addend
       IDEE_CHECK_ARG(d->x_sG == 16 && d->x_gpu <= 0, "conv_dgrad (replicate): grouped dx layouts are not built");
       const long total = (long)d->B * d->T * d->H * 2 * (d->Cin / 4);
-      hipLaunchKernelGGL(zero_w_edges_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, dx, d->B,
-                         d->T, d->H, d->W, d->Cin, d->x_sB, d->x_sT, d->x_sH, d->x_sW);
+      hipLaunchKernelGGL(init_w_edges_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, dx, addend,
+                         d->B, d->T, d->H, d->W, d->Cin, d->x_sB, d->x_sT, d->x_sH, d->x_sW);
     }
     launch_conv<DGRAD_REP>(a, false, (hipStream_t)stream);
   } else {

@@ -584,85 +584,73 @@ template <int E>
 __global__ __launch_bounds__(256) void ln_relu_res_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ sc,
                                                               float* __restrict__ y, int V, long L) {
-  const int b = blockIdx.y, v = b % V;
-  const float* gv = gamma + v * E;
-  const float* bv = beta + v * E;
+  // E/4 adjacent lanes per token, 4 channels each (contiguous 16-byte streams in and out)
+  constexpr int QE = E / 4;
+  const int b = blockIdx.y, v = b % V, q = threadIdx.x % QE;
+  const f32x4 gv = ld4(gamma + v * E + 4 * q), bv = ld4(beta + v * E + 4 * q);
   const long base = (long)b * L * E;
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < L; tok += (long)gridDim.x * 256) {
-    float x[E], mean = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; e += 4) { const f32x4 t = ld4(c + base + tok * E + e); x[e] = t[0]; x[e + 1] = t[1]; x[e + 2] = t[2]; x[e + 3] = t[3]; }
-#pragma unroll
-    for (int e = 0; e < E; ++e) mean += x[e];
-    mean *= (1.f / E);
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
+    const long off = base + (u / QE) * E + 4 * q;
+    const f32x4 x = ld4(c + off), s4 = ld4(sc + off);
+    const float mean = tok_sum<QE>((x[0] + x[1]) + (x[2] + x[3])) * (1.f / E);
     float var = 0.f;
 #pragma unroll
-    for (int e = 0; e < E; ++e) { const float d = x[e] - mean; var = fmaf(d, d, var); }
-    const float rstd = rsqrtf(var * (1.f / E) + kLnEps);
+    for (int k = 0; k < 4; ++k) { const float d = x[k] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+    f32x4 o;
 #pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      const f32x4 s4 = ld4(sc + base + tok * E + e);
-      f32x4 o;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) o[u] = s4[u] + fmaxf(fmaf((x[e + u] - mean) * rstd, gv[e + u], bv[e + u]), 0.f);
-      st4(y + base + tok * E + e, o);
-    }
+    for (int k = 0; k < 4; ++k) o[k] = s4[k] + fmaxf(fmaf((x[k] - mean) * rstd, gv[k], bv[k]), 0.f);
+    st4(y + off, o);
   }
 }
 
-// dc = LN'(gamma * dy * [u > 0]) ; dgamma += sum dy*[u>0]*xn ; dbeta += sum dy*[u>0]   (d shortcut = dy: the caller's)
 template <int E>
 __global__ __launch_bounds__(256) void ln_relu_res_bwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ dy,
                                                               float* __restrict__ dc, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int V, long L) {
-  const int b = blockIdx.y, v = b % V;
-  const float* gv = gamma + v * E;
-  const float* bv = beta + v * E;
+  constexpr int QE = E / 4;
+  const int b = blockIdx.y, v = b % V, q = threadIdx.x % QE;
+  const f32x4 gv = ld4(gamma + v * E + 4 * q), bv = ld4(beta + v * E + 4 * q);
   const long base = (long)b * L * E;
-  float gg[E], gb[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) { gg[e] = 0.f; gb[e] = 0.f; }
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < L; tok += (long)gridDim.x * 256) {
-    float x[E], g[E], mean = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      const f32x4 t = ld4(c + base + tok * E + e), d4 = ld4(dy + base + tok * E + e);
-      x[e] = t[0]; x[e + 1] = t[1]; x[e + 2] = t[2]; x[e + 3] = t[3];
-      g[e] = d4[0]; g[e + 1] = d4[1]; g[e + 2] = d4[2]; g[e + 3] = d4[3];
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) mean += x[e];
-    mean *= (1.f / E);
+  f32x4 gg = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
+    const long off = base + (u / QE) * E + 4 * q;
+    const f32x4 x = ld4(c + off), g = ld4(dy + off);
+    const float mean = tok_sum<QE>((x[0] + x[1]) + (x[2] + x[3])) * (1.f / E);
     float var = 0.f;
 #pragma unroll
-    for (int e = 0; e < E; ++e) { const float d = x[e] - mean; var = fmaf(d, d, var); }
-    const float rstd = rsqrtf(var * (1.f / E) + kLnEps);
+    for (int k = 0; k < 4; ++k) { const float d = x[k] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+    f32x4 xn, dxn;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      x[e] = (x[e] - mean) * rstd;                              // xn
-      const float du = fmaf(x[e], gv[e], bv[e]) > 0.f ? g[e] : 0.f;
-      gg[e] = fmaf(du, x[e], gg[e]);
-      gb[e] += du;
-      g[e] = du * gv[e];                                        // d xn
-      s1 += g[e];
-      s2 = fmaf(g[e], x[e], s2);
+    for (int k = 0; k < 4; ++k) {
+      xn[k] = (x[k] - mean) * rstd;
+      const float du = fmaf(xn[k], gv[k], bv[k]) > 0.f ? g[k] : 0.f;
+      gg[k] = fmaf(du, xn[k], gg[k]);
+      gb[k] += du;
+      dxn[k] = du * gv[k];
+      s1 += dxn[k];
+      s2 = fmaf(dxn[k], xn[k], s2);
     }
-    s1 *= (1.f / E); s2 *= (1.f / E);
-#pragma unroll
-    for (int e = 0; e < E; e += 4)
-      st4(dc + base + tok * E + e, f32x4{rstd * (g[e] - s1 - x[e] * s2), rstd * (g[e + 1] - s1 - x[e + 1] * s2),
-                                         rstd * (g[e + 2] - s1 - x[e + 2] * s2), rstd * (g[e + 3] - s1 - x[e + 3] * s2)});
+    s1 = tok_sum<QE>(s1) * (1.f / E); s2 = tok_sum<QE>(s2) * (1.f / E);
+    st4(dc + off, f32x4{rstd * (dxn[0] - s1 - xn[0] * s2), rstd * (dxn[1] - s1 - xn[1] * s2),
+                        rstd * (dxn[2] - s1 - xn[2] * s2), rstd * (dxn[3] - s1 - xn[3] * s2)});
   }
+  // lanes with equal q hold partials of the same 4 channels
+  auto same_q_sum = [](float val) {
+#pragma unroll
+    for (int o = QE; o < 64; o <<= 1) val += __shfl_xor(val, o, 64);
+    return val;
+  };
   const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const float a = wave_sum(gg[e]), bb = wave_sum(gb[e]);
-    if (lane == 0) { atomicAdd(dgamma + v * E + e, a); atomicAdd(dbeta + v * E + e, bb); }
+  for (int k = 0; k < 4; ++k) {
+    const float a = same_q_sum(gg[k]), bb = same_q_sum(gb[k]);
+    if (lane < QE) { atomicAdd(dgamma + v * E + 4 * q + k, a); atomicAdd(dbeta + v * E + 4 * q + k, bb); }
   }
 }
-
 // -------------------------------------------------------------------------------------------
 // Euclidean nearest-neighbour vector quantisation (models/codebook/VQ.py: cdist :44-48, argmax of -dist
 // in EuclideanCodebook.forward :477-555, straight-through :986, commitment mse :1056), reference defaults:
@@ -1207,7 +1195,7 @@ extern "C" int idee_adam_step(float* p, const float* g, float* m, float* v, long
 extern "C" int idee_ln_relu_res_fwd(const float* c, const float* gamma, const float* beta, const float* shortcut, float* y,
                                     int B, int V, long L, int E, idee_stream_t stream) {
   IDEE_CHECK_ARG(c && gamma && beta && shortcut && y && B > 0 && V > 0 && L > 0, "ln_relu_res_fwd: bad argument");
-  const dim3 grid(imin(cdiv(L, 256), cdiv((long)kCUs * 8, B)), B);
+  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, B)), B);
   if (E == 16) hipLaunchKernelGGL((ln_relu_res_fwd_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, shortcut, y, V, L);
   else if (E == 32) hipLaunchKernelGGL((ln_relu_res_fwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, shortcut, y, V, L);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "ln_relu_res: E=%d not built", E);
@@ -1218,7 +1206,7 @@ extern "C" int idee_ln_relu_res_fwd(const float* c, const float* gamma, const fl
 extern "C" int idee_ln_relu_res_bwd(const float* c, const float* gamma, const float* beta, const float* dy, float* dc,
                                     float* dgamma, float* dbeta, int B, int V, long L, int E, idee_stream_t stream) {
   IDEE_CHECK_ARG(c && gamma && beta && dy && dc && dgamma && dbeta && B > 0 && V > 0 && L > 0, "ln_relu_res_bwd: bad argument");
-  const dim3 grid(imin(cdiv(L, 256), cdiv((long)kCUs * 4, B)), B);
+  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, B)), B);
   if (E == 16) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L);
   else if (E == 32) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "ln_relu_res: E=%d not built", E);

@@ -179,6 +179,10 @@ class ConvLayer:
     def dgrad(self, dy, pd, relu_ref, dx, accumulate=False):
         L.call("idee_conv_dgrad", C.byref(self.desc), ptr(dy), ptr(pd), ptr(relu_ref), ptr(dx), int(accumulate), L.stream())
 
+    def dgrad_add(self, dy, pd, addend, dx):
+        """dx = addend + conv^T(dy) (no copy of the addend)."""
+        L.call("idee_conv_dgrad_add", C.byref(self.desc), ptr(dy), ptr(pd), None, ptr(addend), ptr(dx), L.stream())
+
     def wgrad(self, x, dy, w_like, want_bias=True):
         """-> (dw in the reference layout of w_like, dbias (wsets, Cout) | None)."""
         dev = x.device
@@ -581,8 +585,8 @@ class ConvLNUnit(torch.autograd.Function):
         dw, _ = conv.wgrad(x, dc, w, want_bias=False)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = dy.clone()                      # the shortcut's gradient; the conv's data gradient is added to it
-            conv.dgrad(dc, pd, None, dx, accumulate=True)
+            dx = torch.empty_like(dy)            # shortcut gradient (dy) + the conv's data gradient, without a copy of dy
+            conv.dgrad_add(dc, pd, dy, dx)
         return dx, dw, dgamma, dbeta
 
 

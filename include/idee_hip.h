@@ -153,6 +153,10 @@ int idee_conv_fwd(const idee_conv_desc* d, const float* x, const float* w_packed
  * are cleared by the call itself); accumulate != 0: dx holds the addend (e.g. a residual gradient). */
 int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
                     float* dx, int accumulate, idee_stream_t stream);
+/* dx = addend + conv^T(dy) [masked like idee_conv_dgrad]: the shortcut gradient of a residual unit added without a copy.
+ * addend has dx's layout and may be dx itself (== accumulate) or NULL (== plain). */
+int idee_conv_dgrad_add(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
+                        const float* addend, float* dx, idee_stream_t stream);
 /* dw_packed (wsets, taps, Cin, CoutPad) and dbias (wsets, CoutPad) | NULL accumulate */
 int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
                     idee_stream_t stream);
