@@ -1041,6 +1041,14 @@ __global__ __launch_bounds__(256) void patch_merging_bwd_kernel(const float* __r
 }
 
 int stream_grid(long items) { return imin(cdiv(items, 256), kCUs * 8); }
+// resident 256-thread workgroups per CU of a kernel (occupancy API): a grid of kCUs * that many workgroups runs in ONE
+// round — a fixed "8 per CU" leaves a second, mostly empty round behind for kernels that fit fewer
+template <class K>
+int wg_per_cu(K kernel) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) n = 8;
+  return n > 8 ? 8 : n;
+}
 
 }  // namespace
 
@@ -1061,8 +1069,11 @@ extern "C" int idee_patch_embed_ln_fwd(const float* x, const float* w, const flo
 extern "C" int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dw, float* db,
                                        int N, int V, int Cin, long L, int E, idee_stream_t stream) {
   IDEE_CHECK_ARG(x && w && dy && dw && N > 0 && V > 0 && L > 0, "patch_embed_ln_bwd: bad argument");
-  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, (long)N * V)), N * V);
-#define PE(E_, C_) hipLaunchKernelGGL((patch_embed_bwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, dy, dw, db, V, L)
+#define PE(E_, C_)                                                                                                  \
+  do {                                                                                                              \
+    const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * wg_per_cu(patch_embed_bwd_kernel<E_, C_>), (long)N * V)), N * V); \
+    hipLaunchKernelGGL((patch_embed_bwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, dy, dw, db, V, L); \
+  } while (0)
   if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
   else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "patch_embed_ln: (E=%d, Cin=%d) not built", E, Cin);
@@ -1112,8 +1123,8 @@ extern "C" int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in,
                  "lfq_bwd: bad argument");
   const int D = log2i(codebook_size);
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
-  const int nb = imin(cdiv(M * 4, 256), kCUs * 8);
 #define CALL(E_, D_)                                                                                               \
+  const int nb = imin(cdiv(M * 4, 256), kCUs * wg_per_cu(lfq_bwd_kernel<E_, D_>));                                 \
   hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in, w_out, \
                      stats, gloss, dsigns, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
   LFQ_DISPATCH(CALL)
@@ -1206,7 +1217,8 @@ extern "C" int idee_ln_relu_res_fwd(const float* c, const float* gamma, const fl
 extern "C" int idee_ln_relu_res_bwd(const float* c, const float* gamma, const float* beta, const float* dy, float* dc,
                                     float* dgamma, float* dbeta, int B, int V, long L, int E, idee_stream_t stream) {
   IDEE_CHECK_ARG(c && gamma && beta && dy && dc && dgamma && dbeta && B > 0 && V > 0 && L > 0, "ln_relu_res_bwd: bad argument");
-  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, B)), B);
+  const int per_cu = E == 16 ? wg_per_cu(ln_relu_res_bwd_kernel<16>) : wg_per_cu(ln_relu_res_bwd_kernel<32>);
+  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * per_cu, B)), B);
   if (E == 16) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L);
   else if (E == 32) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "ln_relu_res: E=%d not built", E);
