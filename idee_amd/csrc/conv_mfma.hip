@@ -403,39 +403,56 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
       return s;
     };
     if constexpr (NT == 1 && RES) {
-      // one output block per wave (the data gradient into a 16-channel tensor): only 16 MFMAs per channel block, so the
-      // activations are prefetched a whole TAP ahead: block g of the next tap is requested as soon as block g of the
-      // current one has been multiplied (Gk <= 6, weights resident: no barriers)
-      constexpr int GKM = 6;
-      TapSrc cur = tap_src(0);
-      f32x4 xq[GKM][MT];
+      // one output block per wave (the data gradient into a 16-channel tensor): only 16 MFMAs per (tap, channel block)
+      // step.  Channel blocks OUTSIDE, taps inside: the three `ow` taps of a source row re-read the same cache lines one
+      // pixel apart, and with the taps innermost that 32 KB working set per workgroup stays in L1 (taps outermost streamed
+      // 196 KB per tap and re-fetched every row through L2: 5.9 TB/s of L2 fill, the bound of this launch).  Loads run
+      // three steps ahead through a register ring; per step the address is a lane base + a wave-uniform tap offset and
+      // the validity one bit of a per-tile mask.
+      long lbase[MT];
+      unsigned okbits[MT];
 #pragma unroll
-      for (int g = 0; g < GKM; ++g)
-        if (g < a.Gk)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            xq[g][m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(g, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int it = 0; it < ntap_it; ++it) {
-        const float* wcur = s_wd + tap_of(it) * slab;
-        const bool more = it + 1 < ntap_it;
-        TapSrc nxt = cur;
-        if (more) nxt = tap_src(it + 1);
-#pragma unroll
-        for (int g = 0; g < GKM; ++g) {
-          if (g < a.Gk) {
-            const f32x4 wf = ld4(wcur + g * 256 + lane * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xq[g][m][s], acc[m][0], 0, 0, 0);
-            if (more)
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                xq[g][m] = nxt.okm[m] ? ld4(in_b + nxt.off[m] + goff(g, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+      for (int m = 0; m < MT; ++m) {
+        lbase[m] = (long)hm[m] * a.i_sH + (long)wm[m] * a.i_sW;
+        unsigned bits = 0;
+        for (int it = 0; it < ntap_it; ++it) {
+          const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
+          const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
+          const Slot sh = slot_h<MODE>(oh, hm[m], a.Hi);
+          bool okw;
+          (void)src_w<MODE>(ow, wm[m], a.Wi, okw);
+          if (vm[m] && st.ok && sh.ok && okw) bits |= 1u << it;
         }
-        cur = nxt;
+        okbits[m] = bits;
+      }
+      auto tap_delta = [&](int it) {      // wave-uniform: source offset of tap `it` relative to (h, w) of the output pixel
+        const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
+        const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
+        const int dh = (MODE == FWD_S2) ? oh - 1 : 1 - oh, dw = (MODE == FWD_S2) ? ow - 1 : 1 - ow;
+        return (long)st.src * a.i_sT + (long)dh * a.i_sH + (long)dw * a.i_sW;
+      };
+      const int total = a.Gk * ntap_it;                       // ntap_it is 9 or 18: a multiple of the ring depth
+      f32x4 xq[3][MT];
+      auto issue = [&](int step, f32x4 (&dst)[MT]) __attribute__((always_inline)) {
+        const int g = step / ntap_it, it = step - g * ntap_it;
+        const long d = tap_delta(it) + goff(g, a.i_gpu, a.i_sU, a.i_sG);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) dst[m] = ((okbits[m] >> it) & 1u) ? ld4(in_b + lbase[m] + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+      };
+      issue(0, xq[0]); issue(1, xq[1]); issue(2, xq[2]);
+      for (int st0 = 0; st0 < total; st0 += 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int step = st0 + r;
+          const int g = step / ntap_it, it = step - g * ntap_it;
+          const f32x4 wf = ld4(s_wd + tap_of(it) * slab + g * 256 + lane * 4);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xq[r][m][s], acc[m][0], 0, 0, 0);
+          if (step + 3 < total) issue(step + 3, xq[r]);
+        }
       }
     } else {
       TapSrc cur = tap_src(0);
