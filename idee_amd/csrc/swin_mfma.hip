@@ -665,7 +665,6 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
   // per wave, images [channel][token]: [0,CT) K  [CT,2CT) Q  [2CT,3CT) V  [3CT,4CT) dO  [4CT,5CT) scratch B  [5CT] scratch A
   __shared__ __attribute__((aligned(16))) float s_img[WPB][(5 * CT + 1) * IMG];
   __shared__ __attribute__((aligned(16))) int s_rid[WPB][16 * MTK];
-  __shared__ __attribute__((aligned(16))) float s_stat[WPB][3][16 * MTK];   // per query: max, 1/l, D  (current group/head)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -675,13 +674,13 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
   g_qkv_w += (long)v * 3 * C * C;  g_qkv_b += v * 3 * C;  g_proj_w += (long)v * C * C;  g_proj_b += v * C;
   g_rel_bias += (long)v * NH * NW * NW;
 
-  // Weight fragments and the relative-position bias tiles (both orientations) live in LDS in lane-fragment order
+  // Weight fragments and the relative-position bias tiles live in LDS in lane-fragment order
   // (tile i, lane l -> 16 bytes at (i * 64 + l) * 4): the same for every wave of the workgroup, read with one
   // ds_read_b128 where used.  Keeping them in registers (136 per lane at C = 16) forced the accumulators of this
   // kernel through AGPR copies and scratch.
   constexpr int NRB = NH * TPW * TPW;
   constexpr int W_Q = 0, W_QT = 3 * CT * CT, W_PT = 6 * CT * CT, W_BQ = 7 * CT * CT, NWF = 7 * CT * CT + 3 * CT;
-  __shared__ __attribute__((aligned(16))) float s_rb[2 * NRB * 256];
+  __shared__ __attribute__((aligned(16))) float s_rb[NRB * 256];
   __shared__ __attribute__((aligned(16))) float s_wf[NWF * 256];
   {
     int i = 0;
@@ -701,7 +700,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < CT; ++k)   // [c'][c] = proj_w[c][c']
         if ((i++) % WPB == wave) st4(s_wf + (W_PT + o * CT + k) * 256 + lane * 4, wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane));
-    // bias in both orientations: rb rows = keys, col = query ; rbT rows = queries, col = key
+    // relative-position bias tiles: rows = keys, col = query
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -709,23 +708,18 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
         for (int qt = 0; qt < TPW; ++qt) {
           if ((i++) % WPB != wave) continue;
-          f32x4 f, fT;
+          f32x4 f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
             f[r] = (key / NW) == (qry / NW) ? rel_bias[(h * NW + qry % NW) * NW + key % NW] : -1e30f;
-            const int qry2 = 16 * qt + 4 * kq + r, key2 = 16 * kt + j;
-            fT[r] = (key2 / NW) == (qry2 / NW) ? rel_bias[(h * NW + qry2 % NW) * NW + key2 % NW] : -1e30f;
           }
-          const int ti = (h * TPW + kt) * TPW + qt;
-          st4(s_rb + ti * 256 + lane * 4, f);
-          st4(s_rb + (NRB + ti) * 256 + lane * 4, fT);
+          st4(s_rb + ((h * TPW + kt) * TPW + qt) * 256 + lane * 4, f);
         }
     __syncthreads();
   }
   auto WF = [&](int i) { return ld4(s_wf + i * 256 + lane * 4); };
   auto RB = [&](int h, int kt, int qt) { return ld4(s_rb + ((h * TPW + kt) * TPW + qt) * 256 + lane * 4); };
-  auto RBT = [&](int h, int kt, int qt) { return ld4(s_rb + (NRB + (h * TPW + kt) * TPW + qt) * 256 + lane * 4); };
   f32x4 dB[NH][TPW][TPW];
 #pragma unroll
   for (int h = 0; h < NH; ++h)
@@ -755,9 +749,6 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
   float* imgB = img + 4 * CT * IMG;
   float* imgA = img + 5 * CT * IMG;
   int* rid_l = s_rid[wave];
-  float* st_m = s_stat[wave][0];
-  float* st_il = s_stat[wave][1];
-  float* st_D = s_stat[wave][2];
 
   for (int it0 = blockIdx.x * WPB; it0 < g.items; it0 += gridDim.x * WPB) {
     Tok t[MTK];
@@ -832,7 +823,6 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
             }
             P[kt][qt] = acc; dP[kt][qt] = accd;
           }
-        wave_sync();   // stats of the previous (group, head) fully consumed
 #pragma unroll
         for (int qt = 0; qt < TPW; ++qt) {
           float mx = -3.0e38f;
@@ -856,7 +846,6 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
             D4 = fma4(P[kt][qt], dP[kt][qt], D4);
           }
           const float D = chan_sum(hsum(D4));
-          if (kq == 0) { const int q = 16 * (grp * TPW + qt) + j; st_m[q] = mxl; st_il[q] = inv; st_D[q] = D; }   // max stored pre-scaled
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) {
             dP[kt][qt] = P[kt][qt] * (dP[kt][qt] - splat(D));   // dP now holds dS
@@ -879,33 +868,23 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
           for (int r = 0; r < SP; ++r) { O[c][grp * TPW + qt][s0 + r] = acco[s0 + r]; DQ[c][grp * TPW + qt][s0 + r] = accq[s0 + r]; }
         }
-        wave_sync();   // stats visible
-        // ---- column pass: S^T, P^T, dS^T with queries on rows, key on the column ----
+        // ---- column pass: P^T and dS^T (queries on rows, key on the column) are the row-pass tiles TRANSPOSED across
+        // lanes through two wave-private scratch images — 8 four-byte LDS writes and 2 sixteen-byte reads per tile
+        // instead of recomputing S^T (4 MFMAs), its mask, 4 exponentials and the softmax algebra; bit-identical to P
         f32x4 PT[TPW][TPW], dST[TPW][TPW];   // [qt][kt]
 #pragma unroll
         for (int qt = 0; qt < TPW; ++qt)
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) {
-            f32x4 acc = RBT(h, kt, qt), accd = {0.f, 0.f, 0.f, 0.f};
+            wave_sync();   // the previous tile's readers are done
 #pragma unroll
-            for (int s = 0; s < SP; ++s) {
-              acc = MFMA(QKV[c][grp * TPW + qt][s0 + s], QKV[CT + c][grp * TPW + kt][s0 + s], acc);
-              accd = MFMA(DO[c][grp * TPW + qt][s0 + s], QKV[2 * CT + c][grp * TPW + kt][s0 + s], accd);
+            for (int r = 0; r < 4; ++r) {
+              imgA[(4 * kq + r) * VSK + j] = P[kt][qt][r];      // [key][query]
+              imgB[(4 * kq + r) * VSK + j] = dP[kt][qt][r];
             }
-            const int q0 = 16 * (grp * TPW + qt) + 4 * kq;
-            if (g.shifted) {
-              const int4 rq = *reinterpret_cast<const int4*>(rid_l + q0);
-              const int rk = t[grp * TPW + kt].rid;
-              acc[0] += rq.x != rk ? -100.f : 0.f; acc[1] += rq.y != rk ? -100.f : 0.f;
-              acc[2] += rq.z != rk ? -100.f : 0.f; acc[3] += rq.w != rk ? -100.f : 0.f;
-            }
-            const f32x4 m4 = ld4(st_m + q0), il4 = ld4(st_il + q0), D4 = ld4(st_D + q0);   // m4 = -max * log2e
-            const f32x4 ea = fma4(acc, splat(kLog2e), m4);
-            f32x4 e;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(ea[r]);
-            PT[qt][kt] = e * il4;
-            dST[qt][kt] = PT[qt][kt] * (accd - D4);
+            wave_sync();
+            PT[qt][kt] = ld4(imgA + j * VSK + 4 * kq);           // lane (key j, query group kq)
+            dST[qt][kt] = ld4(imgB + j * VSK + 4 * kq);
           }
 #pragma unroll
         for (int kt = 0; kt < TPW; ++kt) {
