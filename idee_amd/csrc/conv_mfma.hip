@@ -1080,19 +1080,25 @@ __device__ __forceinline__ float c1_w_dgrad(const float* wp, int Gi, int tap, in
 // LPP lanes per pixel (power of two >= C/4); lanes q >= C/4 idle
 template <int LPP>
 __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
+  // LPP lanes (4 channels each) own FOUR consecutive output pixels of a row: per (kt, kh) they load the 6 source pixels
+  // once (9 loads per output instead of 18) and keep f32x4 partial products, summed over channels only at the end
+  constexpr int PXT = 4;
   const int QC = a.C / 4, Gi = a.C / 16;
-  const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
-  const long npix = (long)a.B * a.H * a.W;
+  const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, GPB = 256 / LPP;
+  const int WG = (a.W + PXT - 1) / PXT;
+  const long ngrp = (long)a.B * a.H * WG;
   // this lane's 4 channels of all 18 taps stay in registers (re-read when the weight set changes: per-variable heads)
   f32x4 wr[18];
   int wcur = -1;
-  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
-    const long p = p0 + pl;
-    float acc = 0.f;
-    int b = 0;
-    if (p < npix && q < QC) {
-      const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H);
-      b = (int)(p / ((long)a.W * a.H));
+  for (long g0 = (long)blockIdx.x * GPB; g0 < ngrp; g0 += (long)gridDim.x * GPB) {
+    const long g = g0 + pl;
+    f32x4 accv[PXT];
+#pragma unroll
+    for (int o = 0; o < PXT; ++o) accv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int b = 0, h = 0, w0 = 0;
+    if (g < ngrp && q < QC) {
+      w0 = (int)(g % WG) * PXT; h = (int)((g / WG) % a.H);
+      b = (int)(g / ((long)WG * a.H));
       const int wset = b % a.wsets;
       if (wset != wcur) {
         wcur = wset;
@@ -1101,32 +1107,36 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
         for (int tap = 0; tap < 18; ++tap) wr[tap] = c1_w4_fwd(wp, Gi, tap, q);
       }
       const float* xb = a.x + (long)b * a.x_sB + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
-      // all 18 loads are issued before the first fma (taps outside the frame load the clamped pixel and weigh it 0):
-      // a branch per tap would serialise 18 memory round trips
-      f32x4 xv[18];
-      float on[18];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int oh = 0; oh < 3; ++oh)
+        for (int oh = 0; oh < 3; ++oh) {
+          const int hs = h + oh - 1;
+          const bool rok = hs >= 0 && hs < a.H;
+          const float* row = xb + (long)kt * a.x_sT + (long)min(max(hs, 0), a.H - 1) * a.x_sH;
+          f32x4 xv[PXT + 2];
 #pragma unroll
-          for (int ow = 0; ow < 3; ++ow) {
-            const int hs = h + oh - 1, ws = w + ow - 1;
-            const bool ok = hs >= 0 && hs < a.H && ws >= 0 && ws < a.W;
-            const int hc = min(max(hs, 0), a.H - 1), wc = min(max(ws, 0), a.W - 1);
-            const int tap = (kt * 3 + oh) * 3 + ow;
-            xv[tap] = ld4(xb + (long)kt * a.x_sT + (long)hc * a.x_sH + (long)wc * a.x_sW);
-            on[tap] = ok ? 1.f : 0.f;
+          for (int i = 0; i < PXT + 2; ++i) {            // source pixels w0-1 .. w0+PXT: clamped address, zeroed outside the frame
+            const int ws = w0 - 1 + i;
+            xv[i] = ld4(row + (long)min(max(ws, 0), a.W - 1) * a.x_sW);
+            if (!(rok && ws >= 0 && ws < a.W)) xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
-      for (int tap = 0; tap < 18; ++tap) {
-        const f32x4 pr = xv[tap] * wr[tap];
-        acc = fmaf(on[tap], (pr[0] + pr[1]) + (pr[2] + pr[3]), acc);
-      }
+          for (int ow = 0; ow < 3; ++ow) {
+            const f32x4 wv = wr[(kt * 3 + oh) * 3 + ow];
+#pragma unroll
+            for (int o = 0; o < PXT; ++o) accv[o] = __builtin_elementwise_fma(xv[o + ow], wv, accv[o]);
+          }
+        }
     }
 #pragma unroll
-    for (int o = 1; o < LPP; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    if (p < npix && q == 0) a.y[p] = acc + (a.bias ? a.bias[b % a.wsets] : 0.f);
+    for (int o = 0; o < PXT; ++o) {
+      float acc = (accv[o][0] + accv[o][1]) + (accv[o][2] + accv[o][3]);
+#pragma unroll
+      for (int sft = 1; sft < LPP; sft <<= 1) acc += __shfl_xor(acc, sft, 64);
+      if (g < ngrp && q == 0 && w0 + o < a.W)
+        a.y[((long)b * a.H + h) * a.W + w0 + o] = acc + (a.bias ? a.bias[b % a.wsets] : 0.f);
+    }
   }
 }
 
@@ -1254,7 +1264,7 @@ int launch_c1(int which, C1Args& a, hipStream_t st) {
   if (QC > 64) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): Cin %d > 256 is not built", a.C);
   const int PPB = 256 / LPP;
   const long nbw = a.B / a.wsets;
-  const long npix = which == 1 ? nbw * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * a.W : nbw * a.H * a.W);
+  const long npix = which == 1 ? nbw * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * ((a.W + 3) / 4) : nbw * a.H * a.W);
   const int per = which == 0 ? 1 : a.wsets;                       // dgrad / wgrad: one weight set per grid column
   const int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : 8), per));
   const dim3 grid(gx < 1 ? 1 : gx, per);
