@@ -108,35 +108,49 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
 #pragma unroll
     for (int c = 0; c < CIN; ++c) { wl[k][c] = wv[(4 * q + k) * CIN + c]; gw[k][c] = 0.f; }
   }
-  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
-    const long tok = u / QE;
-    const f32x4 g = ld4(dyb + tok * E + 4 * q);
-    float xi[CIN];
+  // four tokens per lane and trip: their loads are all in flight before the first dependent instruction
+  constexpr int UN = 4;
+  const long total = L * QE, stride = (long)gridDim.x * 256;
+  for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += UN * stride) {
+    f32x4 gq[UN];
+    float xq[UN][CIN];
+    bool on[UN];
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) xi[c] = xb[c * L + tok];
-    float e[4], sm = 0.f;
+    for (int r = 0; r < UN; ++r) {
+      const long u = u0 + r * stride;
+      on[r] = u < total;
+      const long tok = (on[r] ? u : u0) / QE;
+      gq[r] = ld4(dyb + tok * E + 4 * q);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float a = bl[k];
-#pragma unroll
-      for (int c = 0; c < CIN; ++c) a = fmaf(wl[k][c], xi[c], a);
-      e[k] = a; sm += a;
+      for (int c = 0; c < CIN; ++c) xq[r][c] = xb[c * L + tok];
     }
-    const float mean = tok_sum<QE>(sm) * (1.f / E);
-    float var = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
-    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
-    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < UN; ++r) {
+      const f32x4 g = on[r] ? gq[r] : f32x4{0.f, 0.f, 0.f, 0.f};     // a zero gradient contributes nothing
+      float e[4], sm = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { e[k] = (e[k] - mean) * rstd; s1 += g[k]; s2 = fmaf(g[k], e[k], s2); }
-    s1 = tok_sum<QE>(s1) * (1.f / E); s2 = tok_sum<QE>(s2) * (1.f / E);
+      for (int k = 0; k < 4; ++k) {
+        float a = bl[k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float de = rstd * (g[k] - s1 - e[k] * s2);
-      gb[k] += de;
+        for (int c = 0; c < CIN; ++c) a = fmaf(wl[k][c], xq[r][c], a);
+        e[k] = a; sm += a;
+      }
+      const float mean = tok_sum<QE>(sm) * (1.f / E);
+      float var = 0.f;
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) gw[k][c] = fmaf(de, xi[c], gw[k][c]);
+      for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
+      const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { e[k] = (e[k] - mean) * rstd; s1 += g[k]; s2 = fmaf(g[k], e[k], s2); }
+      s1 = tok_sum<QE>(s1) * (1.f / E); s2 = tok_sum<QE>(s2) * (1.f / E);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float de = rstd * (g[k] - s1 - e[k] * s2);
+        gb[k] += de;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) gw[k][c] = fmaf(de, xq[r][c], gw[k][c]);
+      }
     }
   }
   // lanes with equal q hold partials of the same 4 channels
