@@ -313,21 +313,26 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
     wo[i] = f32x4{w_out[(4 * q) * D + i], w_out[(4 * q + 1) * D + i], w_out[(4 * q + 2) * D + i], w_out[(4 * q + 3) * D + i]};
     gwi[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gwo[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gbi[i] = 0.f;
   }
-  // two tokens per lane and trip: four 16-byte loads in flight before the first dependent instruction
+  // UN tokens per lane and trip: 2 UN sixteen-byte loads in flight before the first dependent instruction
+  constexpr int UN = 4;
   const long total = M * QE, stride = (long)gridDim.x * 256;
-  for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += 2 * stride) {
-   const bool two = u0 + stride < total;
-   const long tokA = u0 / QE, tokB = two ? (u0 + stride) / QE : tokA;
-   const f32x4 ziA = ld4(z + tokA * E + 4 * q), goA = ld4(dzq + tokA * E + 4 * q);
-   const f32x4 ziB = ld4(z + tokB * E + 4 * q), goB = ld4(dzq + tokB * E + 4 * q);
-   float dqA[D], dqB[D];
+  for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += UN * stride) {
+   long tokq[UN];
+   f32x4 ziq[UN], goq[UN];
+   float dqq[UN][D];
 #pragma unroll
-   for (int i = 0; i < D; ++i) { dqA[i] = dqs ? dqs[tokA * D + i] : 0.f; dqB[i] = dqs ? dqs[tokB * D + i] : 0.f; }
+   for (int r = 0; r < UN; ++r) {
+     const long u = u0 + r * stride;
+     tokq[r] = (u < total ? u : u0) / QE;
+     ziq[r] = ld4(z + tokq[r] * E + 4 * q); goq[r] = ld4(dzq + tokq[r] * E + 4 * q);
 #pragma unroll
-   for (int half = 0; half < 2; ++half) {
-    if (half == 1 && !two) break;
-    const long tok = half ? tokB : tokA;
-    const f32x4 zi = half ? ziB : ziA, go = half ? goB : goA;
+     for (int i = 0; i < D; ++i) dqq[r][i] = dqs ? dqs[tokq[r] * D + i] : 0.f;
+   }
+#pragma unroll
+   for (int half = 0; half < UN; ++half) {
+    if (u0 + half * stride >= total) break;
+    const long tok = tokq[half];
+    const f32x4 zi = ziq[half], go = goq[half];
     float s[D], qv[D], ds[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
       s[i] = a; qv[i] = a > 0.f ? 1.f : -1.f;
       // straight-through: d x_ste = W_out^T dz_q
       const float d = tok_sum<QE>(go[0] * wo[i][0] + go[1] * wo[i][1] + go[2] * wo[i][2] + go[3] * wo[i][3]);
-      ds[i] = d + (half ? dqB[i] : dqA[i]) + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
+      ds[i] = d + dqq[half][i] + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
     }
     float p[K];
     lfq_probs<D>(s, p);
