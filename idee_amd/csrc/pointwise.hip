@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
     for (int c = 0; c < CIN; ++c) { wl[k][c] = wv[(4 * q + k) * CIN + c]; gw[k][c] = 0.f; }
   }
   // four tokens per lane and trip: their loads are all in flight before the first dependent instruction
-  constexpr int UN = 4;
+  constexpr int UN = 8;
   const long total = L * QE, stride = (long)gridDim.x * 256;
   for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += UN * stride) {
     f32x4 gq[UN];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
     gwi[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gwo[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gbi[i] = 0.f;
   }
   // UN tokens per lane and trip: 2 UN sixteen-byte loads in flight before the first dependent instruction
-  constexpr int UN = 4;
+  constexpr int UN = 8;
   const long total = M * QE, stride = (long)gridDim.x * 256;
   for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += UN * stride) {
    long tokq[UN];
