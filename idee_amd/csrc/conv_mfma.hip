@@ -1202,27 +1202,39 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
-    const long p = p0 + pl;
-    if (p >= npix || q >= QC) continue;
-    const int ws = (int)(p % a.W), hs = (int)((p / a.W) % a.H);
-    const int b = (int)(p / ((long)a.W * a.H)) * a.wsets + wset;
-    const float* dyb = a.dy + (long)b * a.H * a.W;
-    float g[9];
+  // four source pixels per lane and trip: their x and dy loads are all in flight before the first fma
+  constexpr int UN = 4;
+  const long pstride = (long)gridDim.x * PPB;
+  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += UN * pstride) {
+    f32x4 xq[UN][2];
+    float gq[UN][9];
+    bool on[UN];
 #pragma unroll
-    for (int oh = 0; oh < 3; ++oh)
+    for (int r = 0; r < UN; ++r) {
+      const long p = p0 + r * pstride + pl;
+      on[r] = p < npix && q < QC;
+      const long pc = on[r] ? p : 0;
+      const int ws = (int)(pc % a.W), hs = (int)((pc / a.W) % a.H);
+      const int b = (int)(pc / ((long)a.W * a.H)) * a.wsets + wset;
+      const float* dyb = a.dy + (long)b * a.H * a.W;
 #pragma unroll
-      for (int ow = 0; ow < 3; ++ow) {
-        const int h = hs - (oh - 1), w = ws - (ow - 1);      // output pixel this source feeds through tap (oh, ow)
-        g[oh * 3 + ow] = (h >= 0 && h < a.H && w >= 0 && w < a.W) ? dyb[(long)h * a.W + w] : 0.f;
-      }
-    if (q == 0) bsum += g[4];
-    const float* xb = a.x + (long)b * a.x_sB + (long)hs * a.x_sH + (long)ws * a.x_sW + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
+      for (int oh = 0; oh < 3; ++oh)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const f32x4 xv = ld4(xb + (long)kt * a.x_sT);
+        for (int ow = 0; ow < 3; ++ow) {
+          const int h = hs - (oh - 1), w = ws - (ow - 1);      // output pixel this source feeds through tap (oh, ow)
+          gq[r][oh * 3 + ow] = (on[r] && h >= 0 && h < a.H && w >= 0 && w < a.W) ? dyb[(long)h * a.W + w] : 0.f;
+        }
+      const float* xb = a.x + (long)b * a.x_sB + (long)hs * a.x_sH + (long)ws * a.x_sW + goff((on[r] ? q : 0) / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * ((on[r] ? q : 0) % 4);
 #pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] += xv * g[t9];
+      for (int kt = 0; kt < 2; ++kt) xq[r][kt] = ld4(xb + (long)kt * a.x_sT);
+    }
+#pragma unroll
+    for (int r = 0; r < UN; ++r) {
+      if (q == 0) bsum += gq[r][4];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] += xq[r][kt] * gq[r][t9];      // dy is zero for pixels that do not exist
     }
   }
   // reduce over the lanes of a wave that own the same channels, then over the 4 waves, then one atomic per value
