@@ -336,13 +336,15 @@ def test_classifier_sign_field_vs_oracle(V, D, H, W):
         gclose_relu("d" + key, g if idx is None else g[idx], sdl[key].grad)
 
 
-def test_sign_field_switch_matches_plain_path(monkeypatch):
-    """VQ_model with and without the rank-d classifier input: same outputs, same gradients (to f32 rounding)."""
+@pytest.mark.parametrize("T,H,W", [(8, 10, 20), (9, 6, 17), (16, 5, 33)])
+def test_sign_field_switch_matches_plain_path(monkeypatch, T, H, W):
+    """VQ_model with and without the rank-d classifier input: same outputs, same gradients (to f32 rounding);
+    T = 9 leaves an unpaired last frame (never read by the stride-2 conv), T = 16 keeps two output frames."""
     from idee_amd.config import default_config
     from idee_amd.models.build import VQ_model
     cfg = default_config(in_channels_dynamic=3, in_channels=1, encoder="Swin_3D")
     torch.manual_seed(5)
-    x = torch.randn(2, 3, 1, 8, 10, 20, device=DEV)
+    x = torch.randn(2, 3, 1, T, H, W, device=DEV)
     outs = []
     sd = None
     for flag in ("1", "0"):
