@@ -76,3 +76,7 @@ int main() {
   printf("(alone, 1 accumulator)  %.3f ms\n", run<5>(out, src, iters));
   return 0;
 }
+// build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip && ./tools/micro/mfma_mix
+// measured (MI355X), [duration of MFMA wave 0] / kernel:
+//   nothing 4.276 / 4.291 ms | same MFMA chain 5.045 / 8.574 | 8 ds_read_b128 4.270 / 6.580 | 8 global loads 4.261 / 8.665
+//   64 s_add 4.285 / 4.308 | alone with ONE accumulator (dependent chain) 4.283 / 4.309
