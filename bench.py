@@ -238,7 +238,10 @@ def main():
                            parallelism=f"dp{world}"),
                roofline=roof, fwd_ms_per_clip=round(fwd_ms_clip, 3))
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, ts.model, T, H, W)
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, ts.model, T, H, W)
+        except Exception as e:  # noqa: BLE001  (the GPU measurement above must still be reported)
+            out["cpu_baseline"] = dict(value=None, unit="samples/s", cores=host_cores(), kind="port", sample=f"failed: {e!r}")
     print(json.dumps(out), flush=True)
 
 
