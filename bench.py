@@ -3,51 +3,105 @@
 
 One "step" = zero_grad -> VQ_model forward -> BCE(joint) + lambda*anomaly-L1 + sum_v BCE(head_v)
 + loss_z_q -> backward -> (gradient all-reduce) -> Adam, on one batch of synthetic clips already
-resident in HBM.  Workload at every N: BASELINE config #2/#3 — Swin_3D "tiny" (the reference's
-default sizes), V=6, C=1, T=8, 200x200, 4 clips per GPU, fp32 (weak scaling).
+resident in HBM.  Default workload (--config 2): BASELINE config #2/#3 — Swin_3D "tiny" (the reference's
+default sizes), V=6, C=1, T=8, 200x200, 4 clips per GPU, fp32 (weak scaling).  --config 5: the same with the
+CNN_3D encoder; --config 4: ERA5-Land-shaped 412x424, T=16, C=2, Swin "small" (embed [32,32], depths [2,2]) through
+the train_ERA5_Land.py loss sequence; --config 1: the CNN_3D 64x64 plumbing case (at T=8: the reference's classifier
+cannot run T=4).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--hw H] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--batch B] [--no-cpu-baseline] [--breakdown]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (duration from
-HIP events recorded on the launch stream inside the timed region) and `cpu_baseline` (the CPU
-oracle, oracle/idee_oracle.py, timed on this box's host cores on one clip — rank 0, N=1 only).
+With --gpus N > 1 and no torchrun environment, this script starts the N ranks itself (child processes, created
+BEFORE this process touches the GPU; rendezvous on 127.0.0.1) and exits with their status; it never prints a line
+for fewer ranks than were asked for.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel FAMILY (all launches of the entry
+point with the largest share of the step; duration from HIP events recorded on the launch stream inside the timed
+region) and `cpu_baseline` (the CPU oracle, oracle/idee_oracle.py, timed on this box's host cores — rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+CONFIGS = {
+    # id: (encoder, H, W, T, C_in, per-GPU batch, model overrides, step kind, label)
+    "1": ("CNN_3D", 64, 64, 8, 1, 2, {}, "synthetic", "Synthetic_dataset 64x64, T=8 (reference-valid stand-in for T=4), CNN_3D"),
+    "2": ("Swin_3D", 200, 200, 8, 1, 4, {}, "synthetic", "Synthetic CERRA 200x200, T=8, Swin_3D tiny (reference defaults)"),
+    "4": ("Swin_3D", 412, 424, 16, 2, 1, dict(en_embed_dim=[32, 32], en_depths=[2, 2], codebook_dim=32, cls_dim=32, delta_t=16),
+          "era5", "ERA5-Land-shaped synthetic 412x424 (EUR-11 grid), T=16, C=2, Swin_3D small (embed [32,32], depths [2,2]), "
+                  "train_ERA5_Land.py losses"),
+    "5": ("CNN_3D", 200, 200, 8, 1, 4, {}, "synthetic", "Synthetic CERRA 200x200, T=8, CNN_3D encoder (reference defaults)"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="clips per GPU")
-    ap.add_argument("--hw", type=int, default=200, help="grid height = width")
-    ap.add_argument("--encoder", default="Swin_3D")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS), help="BASELINE.json config number")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
+    ap.add_argument("--hw", type=int, default=None, help="override grid height = width")
+    ap.add_argument("--encoder", default=None, help="override the config's encoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--breakdown", action="store_true", help="also print a per-entry-point time table (stderr)")
+    ap.add_argument("--breakdown", action="store_true", help="also print a per-entry-point / per-shape time table (stderr)")
     return ap.parse_args()
 
 
-def synthetic_batch(cfg, n, T, H, W, rank, device):
-    """seeded randn clamped to the dataset's [-10, 10], 10 % / 20 % masks."""
+# ---------------------------------------------------------------------------------------------
+# multi-rank launch (no GPU call may precede this in the parent)
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(a):
+    """Start a.gpus child ranks of this script (one per GPU), wait, propagate their status."""
+    import socket
+    import torch   # importing torch and counting devices does not initialise the GPU on this image
+    forced = "IDEE_FORCE_DEVICE" in os.environ
+    have = torch.cuda.device_count()
+    if have < a.gpus and not forced:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible; refusing to report a smaller run\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   IDEE_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        sys.stderr.write(f"bench.py: a rank exited with status {rc}\n")
+    return rc
+
+
+def synthetic_batch(cfg, kind, n, T, H, W, rank, device):
+    """seeded randn clamped to the dataset's [-10, 10], 10 % / 20 % masks (+5 % cold-surface masks)."""
+    import torch
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn((n, cfg.in_channels_dynamic, cfg.in_channels, T, H, W), generator=g).clamp_(-10, 10)
     me = (torch.rand((n, H, W), generator=g) < 0.10).float()
     ml = (torch.rand((n, H, W), generator=g) < 0.20).float()
-    return x.to(device), me.to(device), ml.to(device)
+    if kind == "era5":
+        cold = (torch.rand((n, H, W), generator=g) < 0.05).float()
+        cold_t = (torch.rand((n, T, H, W), generator=g) < 0.05).float()
+        return x.to(device), (me.to(device), ml.to(device), cold.to(device), cold_t.to(device))
+    return x.to(device), (me.to(device), ml.to(device))
 
 
 # ---- algorithmic FLOPs per launch of each convolution entry point (2 * MACs of the reference conv) ----
@@ -65,34 +119,33 @@ def swin_flops(geom, backward):
     return 2 * f if backward else f
 
 
-_HEADLINE = False   # set in main(): the PMC summary was taken at the headline workload only
+# which device kernels run inside one launch of a C-ABI entry point (for the PMC traffic lookup)
+FAMILY_KERNELS = {
+    "idee_swin_block_fwd": ("swin_fwd_mfma_kernel",),
+    "idee_swin_block_bwd": ("swin_mlp_bwd_kernel", "swin_attn_bwd_kernel"),
+    "idee_conv_fwd": ("conv16_lds_kernel<0", "conv16_lds_kernel<2", "conv_wide_kernel<0", "conv_wide_kernel<2", "c1_fwd", "conv_kernel<0"),
+    "idee_conv_dgrad": ("conv16_lds_kernel<1", "conv16_lds_kernel<3", "conv_wide_kernel<1", "conv_wide_kernel<3", "c1_dgrad", "conv_kernel<1"),
+    "idee_conv_wgrad": ("wgrad16_strip_kernel", "wgrad_wide_lds_kernel", "c1_wgrad", "wgrad_kernel"),
+}
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes of this same command, corrected as MI355X_MICROARCH.md prescribes; see
-    profiles/collect_pmc.py) — or None when the summary has no unambiguous row for this entry point (e.g. the joint
-    head's two convolutions share one kernel name but have different shapes)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not _HEADLINE or not os.path.exists(path):
-        return None
+def pmc_traffic(family, launches_per_step, headline):
+    """Average HBM bytes per launch of the family from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes of this same command, corrected as MI355X_MICROARCH.md prescribes; profiles/collect_pmc.py) — or None
+    when the summary is absent, was taken at another workload, or lists no kernel of the family.  -> (bytes, source)."""
+    if not headline or not os.path.exists(PMC_SUMMARY) or family not in FAMILY_KERNELS:
+        return None, None
     try:
-        rows = {r["kernel"]: r["hbm_bytes_per_launch"] for r in json.load(open(path))["kernels"]}
+        doc = json.load(open(PMC_SUMMARY))
+        tot = 0.0
+        for r in doc["kernels"]:
+            if any(r["kernel"].startswith(p) for p in FAMILY_KERNELS[family]):
+                tot += r["hbm_bytes_per_launch"] * r["launches_per_step"]
     except Exception:  # noqa: BLE001
-        return None
-    name = key.split("[")[0]
-    nw = "32" if "w244" in key else "8"
-    want = None
-    if name == "idee_swin_block_bwd":       # two kernels per launch
-        want = ["swin_mlp_bwd_kernel<16, 2>", f"swin_attn_bwd_kernel<16, 2, {nw}, 8, 2>"]
-    elif name == "idee_swin_block_fwd":
-        want = [f"swin_fwd_mfma_kernel<16, 2, {nw}, true>"]
-    elif "k333 16->16" in key:
-        want = [{"idee_conv_fwd": "conv16_lds_kernel<0>", "idee_conv_dgrad": "conv16_lds_kernel<1>",
-                 "idee_conv_wgrad": "wgrad16_lds_kernel<0, 8>"}[name]]
-    if not want or any(k not in rows for k in want):
-        return None
-    return round(sum(rows[k] for k in want))
+        return None, None
+    if tot <= 0 or not launches_per_step:
+        return None, None
+    return round(tot / launches_per_step), f"profiles/{os.path.basename(PMC_SUMMARY)} @ {doc.get('source_commit', '?')}"
 
 
 def host_cores():
@@ -108,25 +161,51 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cfg, model, T, H, W):
-    """The oracle (CPU restatement, pinned to the reference by tests/golden) on ONE clip of the
-    same workload: forward + losses + backward + Adam, 1 warm-up + 2 timed steps."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, kind, model, T, H, W):
+    """The oracle (CPU restatement, pinned to the reference by tests/golden) on ONE clip of the same workload: forward +
+    losses + backward + Adam, 3 warm-up + 5 timed steps, median; plus the eval-mode forward, median of
+    3.  Workloads too large for one clip on the host (config 4) are timed on a centred crop and scaled by area."""
+    import torch
     from oracle import idee_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    ocfg = O.default_cfg(encoder=cfg.encoder, in_channels_dynamic=cfg.in_channels_dynamic, in_channels=cfg.in_channels)
+    ocfg = O.default_cfg(encoder=cfg.encoder, in_channels_dynamic=cfg.in_channels_dynamic, in_channels=cfg.in_channels,
+                         en_embed_dim=list(cfg.en_embed_dim), en_depths=list(cfg.en_depths), codebook_dim=cfg.codebook_dim,
+                         cls_dim=cfg.cls_dim)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     names = [k for k, v in sd.items() if v.is_floating_point()]
-    x, me, ml = synthetic_batch(cfg, 1, T, H, W, 0, "cpu")
+    scale, Hc, Wc = 1.0, H, W
+    if H * W * T * cfg.en_embed_dim[-1] > 200 * 200 * 8 * 16 * 1.5:
+        Hc, Wc = 104, 104
+        scale = (Hc * Wc) / float(H * W)
+    x, masks = synthetic_batch(cfg, kind, 1, T, Hc, Wc, 0, "cpu")
     state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
     times = []
-    for step in range(1, 4):
+    for step in range(1, 9):
         t0 = time.perf_counter()
         for k in names:
             sd[k] = sd[k].detach().requires_grad_()
         outs = O.vq_model_forward(x, sd, ocfg, training=True)
-        total, _ = O.train_losses_synthetic(outs, me, ml, sd, ocfg)
-        total.backward()
+        if kind == "era5":
+            if outs[0].dim() == 5:      # T=16: two temporal output maps; score both, averaged (SURVEY.md §8(d) config #4)
+                T3 = outs[0].shape[2]
+                total = sum(O.train_losses_era5((outs[0][:, :, i], [p[:, :, i] for p in outs[1]], outs[2], outs[3], outs[4]),
+                                                *masks, sd, ocfg)[0] for i in range(T3)) / T3
+            else:
+                total, _ = O.train_losses_era5(outs, *masks, sd, ocfg)
+        else:
+            total, _ = O.train_losses_synthetic(outs, *masks, sd, ocfg)
+        total.sum().backward()
         with torch.no_grad():
             for k in names:
                 p, m, v = O.adam_step(sd[k].detach(), sd[k].grad, state[k][0], state[k][1], step, cfg.lr, cfg.beta1,
@@ -134,29 +213,52 @@ def cpu_baseline(cfg, model, T, H, W):
                 state[k] = (m, v)
                 sd[k] = p
         times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / len(times[1:])
-    return dict(value=round(1.0 / t, 4), unit="samples/s", cores=cores, kind="port",
-                sample=f"1 clip V={cfg.in_channels_dynamic} T={T} {H}x{W}: oracle fwd+losses+bwd+Adam, 1 warm-up + 2 timed steps")
+    t = statistics.median(times[3:])
+    ft = []
+    with torch.no_grad():
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.vq_model_forward(x, sd, ocfg, training=False)
+            ft.append(time.perf_counter() - t0)
+    crop = "" if scale == 1.0 else f" on a {Hc}x{Wc} crop, rate scaled by area ({scale:.4f})"
+    return dict(value=round(scale / t, 4), unit="samples/s", cores=cores, kind="port", cpu=cpu_model(),
+                fwd_ms_per_clip=round(statistics.median(ft) / scale * 1e3, 1),
+                sample=f"1 clip V={cfg.in_channels_dynamic} T={T} {H}x{W}{crop}: oracle fwd+losses+bwd+Adam, 3 warm-up + 5 timed steps, "
+                       f"median; eval forward median of 3")
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
+    import torch
     from idee_amd import _lib, parallel
     from idee_amd.config import default_config
-    from idee_amd.train import SyntheticTrainStep
+    from idee_amd.train import SyntheticTrainStep, ERA5TrainStep
     rank, world, local = parallel.init_from_env()
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launch environment has WORLD_SIZE={world}; refusing to "
+                         f"report a line for a different rank count")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     _lib.check(_lib.load().idee_check_device(local), "idee_check_device")
-    cfg = default_config(encoder=a.encoder, in_channels=1)
-    T, H, W = 8, a.hw, a.hw
-    global _HEADLINE
-    _HEADLINE = (a.hw == 200 and a.batch == 4 and a.encoder == "Swin_3D")
+    enc, H, W, T, Cin, batch, over, kind, label = CONFIGS[a.config]
+    enc = a.encoder or enc
+    batch = a.batch or batch
+    if a.hw:
+        H = W = a.hw
+    cfg = default_config(encoder=enc, in_channels=Cin, **over)
+    headline = (a.config == "2" and a.hw is None and batch == 4 and enc == "Swin_3D")
     torch.manual_seed(0)
-    ts = SyntheticTrainStep(cfg, device=dev)
-    x, me, ml = synthetic_batch(cfg, a.batch, T, H, W, rank, dev)
+    ts = (ERA5TrainStep if kind == "era5" else SyntheticTrainStep)(cfg, device=dev)
+    x, masks = synthetic_batch(cfg, kind, batch, T, H, W, rank, dev)
+
+    ranks_report = None
+    if world > 1:      # what the communicator itself reports: (rank, device) of every member
+        mine = torch.tensor([torch.distributed.get_rank(), local], device=dev, dtype=torch.int64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        ranks_report = [t.tolist() for t in allr]
 
     def barrier():
         torch.cuda.synchronize()
@@ -165,26 +267,30 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        ts.step(x, me, ml)
+        ts.step(x, *masks)
     timed = ["idee_conv_fwd", "idee_conv_dgrad", "idee_conv_wgrad", "idee_swin_block_fwd", "idee_swin_block_bwd",
              "idee_lfq_fwd", "idee_lfq_bwd", "idee_patch_embed_ln_fwd", "idee_patch_embed_ln_bwd", "idee_anomaly_l1_fwd",
-             "idee_anomaly_l1_bwd", "idee_adam_step"]
+             "idee_anomaly_l1_bwd", "idee_adam_step", "idee_ln_relu_res_fwd", "idee_ln_relu_res_bwd"]
     log = _lib.set_event_log(timed)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ts.step(x, me, ml)
+    for i in range(a.steps):
+        marks[i].record()
+        ts.step(x, *masks)
+    marks[a.steps].record()
     barrier()
     dt = time.perf_counter() - t0
     _lib.set_event_log(None)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
 
-    # ---- per-entry-point durations (HIP events on the launch stream), dominant kernel, roofline ----
+    # ---- per-entry-point durations (HIP events on the launch stream), dominant family, roofline ----
     import ctypes
-    per = {}
+    per, fam = {}, {}
     for name, evs in log.items():
         for e0, e1, args in evs:
             ms = e0.elapsed_time(e1)
@@ -195,25 +301,31 @@ def main():
                 flops = conv_flops(d)
             elif name.startswith("idee_swin_block_"):
                 g = ctypes.cast(args[-2], ctypes.POINTER(_lib.SwinGeom)).contents
-                key = f"{name}[w{g.wd}{g.wh}{g.ww} s{g.sd}{g.sh}{g.sw}]"
+                key = f"{name}[w{g.wd}{g.wh}{g.ww} s{g.sd}{g.sh}{g.sw} C{g.C}]"
                 flops = swin_flops(g, name.endswith("bwd"))
             r = per.setdefault(key, [0.0, 0, 0.0])
             r[0] += ms; r[1] += 1; r[2] = flops
+            f = fam.setdefault(name, [0.0, 0, 0.0])
+            f[0] += ms; f[1] += 1; f[2] += flops
     rows = sorted(per.items(), key=lambda kv: -kv[1][0])
     if a.breakdown and rank == 0:
         tot = sum(v[0] for v in per.values())
-        sys.stderr.write(f"{'entry point':62s} {'ms/step':>9s} {'calls':>6s} {'avg ms':>8s} {'TFLOP/s':>8s}\n")
+        sys.stderr.write(f"{'entry point':66s} {'ms/step':>9s} {'calls':>6s} {'avg ms':>8s} {'TFLOP/s':>8s}\n")
         for k, (ms, n, fl) in rows:
-            sys.stderr.write(f"{k:62s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / (ms / n) / 1e9 if fl else 0:8.2f}\n")
+            sys.stderr.write(f"{k:66s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / (ms / n) / 1e9 if fl else 0:8.2f}\n")
+        sys.stderr.write("-- families --\n")
+        for k, (ms, n, fl) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+            sys.stderr.write(f"{k:66s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / ms / 1e9 if fl else 0:8.2f}\n")
         sys.stderr.write(f"sum of bracketed entry points {tot / a.steps:.3f} ms/step; wall {dt / a.steps * 1e3:.3f} ms/step\n")
     roof = None
-    mfma_rows = [r for r in rows if r[1][2] > 0]
-    if mfma_rows:
-        k, (ms, n, fl) = mfma_rows[0]          # the entry point with the largest total time in the timed region
-        avg_ms = ms / n
-        roof = dict(kernel=k, bound="mfma", achieved=round(fl / avg_ms / 1e9, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(fl / avg_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(k), avg_launch_ms=round(avg_ms, 4),
-                    flops_per_launch=fl, share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
+    mfma_fams = sorted(((k, v) for k, v in fam.items() if v[2] > 0), key=lambda kv: -kv[1][0])
+    if mfma_fams:
+        k, (ms, n, fl) = mfma_fams[0]          # the entry point (all its shapes) with the largest total time in the timed region
+        traffic, src = pmc_traffic(k, n // a.steps, headline)
+        roof = dict(kernel=k + " (all launches of this entry point in the step)", bound="mfma", achieved=round(fl / ms / 1e9, 3),
+                    peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+                    traffic_source=src, avg_launch_ms=round(ms / n, 4), flops_per_launch=fl / n, launches_per_step=n // a.steps,
+                    share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
 
     # ---- second half of BASELINE.json's metric: forward ms per clip (eval mode, no autograd), outside the timed region ----
     ts.model.eval()
@@ -225,21 +337,25 @@ def main():
         for _ in range(5):
             ts.model(x)
         barrier()
-        fwd_ms_clip = (time.perf_counter() - f0) / 5 / a.batch * 1e3
+        fwd_ms_clip = (time.perf_counter() - f0) / 5 / batch * 1e3
     ts.model.train()
 
     if rank != 0:
         return
-    out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * a.batch * a.steps / dt, 3),
+    out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * batch * a.steps / dt, 3),
                unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
-               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=f"Synthetic CERRA {H}x{W}, T={T}, V={cfg.in_channels_dynamic}, {a.encoder} tiny "
-                                    f"(reference defaults), batch {a.batch}/GPU", global_batch=world * a.batch,
+               ms_per_step_median=round(statistics.median(step_ms), 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic",
+               config=dict(workload=f"#{a.config}: {label}, V={cfg.in_channels_dynamic}, batch {batch}/GPU" +
+                                    (f", grid overridden to {H}x{W}" if a.hw else ""), global_batch=world * batch,
                            parallelism=f"dp{world}"),
-               roofline=roof, fwd_ms_per_clip=round(fwd_ms_clip, 3))
+               roofline=roof, fwd_ms_per_clip=round(fwd_ms_clip, 3), peak_hbm_alloc_gb=round(torch.cuda.max_memory_allocated() / 1e9, 2))
+    if world > 1:
+        out["backend"] = torch.distributed.get_backend()
+        out["ranks"] = ranks_report
     if world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(cfg, ts.model, T, H, W)
+            out["cpu_baseline"] = cpu_baseline(cfg, kind, ts.model, T, H, W)
         except Exception as e:  # noqa: BLE001  (the GPU measurement above must still be reported)
             out["cpu_baseline"] = dict(value=None, unit="samples/s", cores=host_cores(), kind="port", sample=f"failed: {e!r}")
     print(json.dumps(out), flush=True)
@@ -249,5 +365,7 @@ if __name__ == "__main__":
     try:
         main()
     finally:
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.destroy_process_group()
+        if "torch" in sys.modules:
+            import torch
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()

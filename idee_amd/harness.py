@@ -51,9 +51,57 @@ class CosineLRScheduler:
     @classmethod
     def from_config(cls, optimizer, config):
         if config.lr_scheduler != "cosine":
-            raise ValueError("Unexpected optimizer {}, supported scheduler is step or cosine".format(config.optimizer))
+            return get_learning_scheduler(optimizer, config)
         return cls(optimizer, t_initial=config.n_epochs, lr_min=config.lr_min, warmup_t=config.lr_warmup_epochs,
                    warmup_lr_init=config.lr_warmup)
+
+
+class StepLRScheduler:
+    """The `lr_scheduler == 'step'` branch of `utils.get_learning_scheduler` (utils_train.py:146-154): timm's
+    StepLRScheduler (timm==1.0.11, absent from this image — PARITY UNPINNED, restated from its published algorithm) with
+    decay_t, decay_rate, linear warm-up from warmup_lr_init over warmup_t, t_in_epochs=True:
+        lr(t) = warmup_lr_init + t * (base - warmup_lr_init) / warmup_t      for t < warmup_t
+              = base * decay_rate ** (t // decay_t)                          otherwise.
+    timm applies a schedule on `step(epoch)` when t_in_epochs is True and on `step_update(n)` when it is False, and
+    ignores the other call.  The reference builds this scheduler with t_in_epochs=True but its drivers only ever call
+    `step_update(epoch)` (train_synthetic.py:331, train_ERA5_Land.py:313) — so under the reference the learning rate
+    stays at the value the constructor set (warmup_lr_init).  Both calls are provided with timm's semantics;
+    `step_update` is therefore a no-op here too, and a caller who wants the decay calls `step(epoch)`."""
+
+    def __init__(self, optimizer, decay_t, decay_rate=1.0, warmup_t=0, warmup_lr_init=0.0, t_in_epochs=True):
+        self.optimizer = optimizer
+        self.decay_t, self.decay_rate, self.warmup_t, self.warmup_lr_init, self.t_in_epochs = decay_t, decay_rate, warmup_t, warmup_lr_init, t_in_epochs
+        self.base_values = [g["lr"] for g in optimizer.param_groups]
+        if warmup_t:
+            self._set([warmup_lr_init for _ in self.base_values])
+
+    def _set(self, values):
+        for g, v in zip(self.optimizer.param_groups, values):
+            g["lr"] = v
+
+    def get_lr(self, t):
+        if t < self.warmup_t:
+            return [self.warmup_lr_init + t * (v - self.warmup_lr_init) / self.warmup_t for v in self.base_values]
+        return [v * (self.decay_rate ** (t // self.decay_t)) for v in self.base_values]
+
+    def step(self, epoch):
+        if self.t_in_epochs:
+            self._set(self.get_lr(epoch))
+
+    def step_update(self, num_updates):
+        if not self.t_in_epochs:
+            self._set(self.get_lr(num_updates))
+
+
+def get_learning_scheduler(optimizer, config):
+    """utils.get_learning_scheduler, utils_train.py:143-172 (same branches, same error text)."""
+    if config.lr_scheduler == "step":
+        return StepLRScheduler(optimizer, decay_t=config.lr_decay_step, decay_rate=config.lr_decay_rate,
+                               warmup_lr_init=config.lr_warmup, warmup_t=config.lr_warmup_epochs, t_in_epochs=True)
+    if config.lr_scheduler == "cosine":
+        return CosineLRScheduler(optimizer, t_initial=config.n_epochs, lr_min=config.lr_min, warmup_t=config.lr_warmup_epochs,
+                                 warmup_lr_init=config.lr_warmup)
+    raise ValueError("Unexpected optimizer {}, supported scheduler is step or cosine".format(config.optimizer))
 
 
 # ----------------------------------------------------------------------------------------
@@ -124,7 +172,8 @@ class AnomalyCollector:
 # ----------------------------------------------------------------------------------------
 def save_model(model, optimizer, epoch, mean_loss_train, mean_loss_val, config, metric):
     """The reference's checkpoint file (utils_train.py:562-584): same path, same dict keys; `model_state_dict` holds the
-    reference's parameter keys, so either code base can load it (models/build.py:120-125)."""
+    reference's parameter keys, so either code base can load it (models/build.py:120-125); `optimizer_state_dict` is in
+    torch.optim.Adam's {state, param_groups} layout (idee_amd.optim.Adam.state_dict)."""
     ckpt_dir = os.path.join(config.dir_log, config.name, "model_checkpoints")
     os.makedirs(ckpt_dir, exist_ok=True)
     name = {"loss": "best_loss_model.pth", "F1": "best_F1_model.pth", "train": "best_train_model.pth"}[metric]
@@ -140,16 +189,22 @@ def save_model(model, optimizer, epoch, mean_loss_train, mean_loss_val, config, 
 # epoch loop (train_synthetic.py:162-233) with deferred metric reads
 # ----------------------------------------------------------------------------------------
 def train_epoch(step, batches, evaluator=None, collector=None):
-    """step: idee_amd.train.SyntheticTrainStep; batches: iterable of (x_d, mask_extreme, mask_extreme_loss, timestep).
+    """step: idee_amd.train.SyntheticTrainStep with batches (x_d, mask_extreme, mask_extreme_loss, timestep), or
+    idee_amd.train.ERA5TrainStep with batches (x_d, mask_drought, mask_drought_loss, mask_cold_surface,
+    mask_cold_surface_loss, timestep | None) — train_ERA5_Land.py:168-211 (evaluator threshold 0.35, `mask_valid`).
     Returns (mean loss, evaluator results | None).  The loss values stay on the device until the epoch ends."""
     if evaluator is not None:
         evaluator.reset()
     losses = []
-    for x_d, mask_extreme, mask_loss, timestep in batches:
-        total, _parts, outs = step.step(x_d, mask_extreme, mask_loss)
+    for batch in batches:
+        x_d, masks, timestep = batch[0], batch[1:-1], batch[-1]
+        total, _parts, outs = step.step(x_d, *masks)
         losses.append(total)
         if evaluator is not None:
-            evaluator.update(outs[0], mask_extreme.unsqueeze(1))
+            if len(masks) == 4:          # real data: valid = max(1 - cold surface, 0), joint logits' first map
+                evaluator.update(outs[0][:, 0], masks[0], (1.0 - masks[2].float()).clamp_min_(0.0))
+            else:
+                evaluator.update(outs[0], masks[0].unsqueeze(1))
         if collector is not None and timestep is not None:
             collector.update(outs[2], timestep)
     mean_loss = float(torch.stack(losses).mean()) if losses else float("nan")     # the single sync of the epoch

@@ -59,7 +59,11 @@ class Adam:
         src, dst = [], []
         for p, v in zip(self.params, views):
             if p.grad is None:
-                v.zero_()
+                # torch.optim.Adam skips parameters without a gradient (no weight decay, no moment update); the flat
+                # kernel cannot skip a span, so an unused parameter is an error here rather than a silent drift
+                raise RuntimeError("idee_amd.optim.Adam: a parameter received no gradient in this step (torch.optim.Adam "
+                                   "would skip it; the flat-buffer step cannot) — freeze it with requires_grad_(False) "
+                                   "before constructing the optimizer")
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad if p.grad.dtype == torch.float32 else p.grad.float())
                 dst.append(v)
@@ -84,12 +88,40 @@ class Adam:
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
                       float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count, float(self.grad_scale))
 
+    def _spans(self):
+        off = 0
+        for p in self.params:
+            yield off, off + p.numel(), p.shape
+            off += p.numel()
+
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
-                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+        """torch.optim.Adam's layout — {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{..., "params":
+        [0..n-1]}]} with per-parameter tensors cut from the flat moment buffers — so the reference's
+        `optimizer.load_state_dict(checkpoint["optimizer_state_dict"])` accepts a checkpoint written here and vice versa
+        (parameter order = model.parameters() order of the module the optimizer was built from)."""
+        state = {}
+        if self.step_count > 0:
+            for i, (a, b, shape) in enumerate(self._spans()):
+                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[a:b].view(shape).clone(),
+                                exp_avg_sq=self.exp_avg_sq[a:b].view(shape).clone())
+        g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        g.update(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                 params=list(range(len(self.params))))
+        return dict(state=state, param_groups=[g])
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups[0].update(sd["param_groups"][0])
+        steps = set()
+        for i, (a, b, shape) in enumerate(self._spans()):
+            st = sd["state"].get(i)
+            if st is None:
+                self.exp_avg[a:b].zero_()
+                self.exp_avg_sq[a:b].zero_()
+                continue
+            self.exp_avg[a:b].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[a:b].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"idee_amd.optim.Adam: per-parameter step counts differ ({sorted(steps)}); the flat step has one")
+        self.step_count = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        self.param_groups[0].update({k: g[k] for k in ("lr", "betas", "eps", "weight_decay") if k in g})

@@ -1,8 +1,17 @@
-"""The per-iteration call sequence of the reference's training loop, train_synthetic.py:175-205
-(zero_grad -> forward -> BCE(joint) + lambda * anomaly-L1 + sum_v BCE(head_v) + loss_z_q ->
-backward -> Adam), as one object.  The 1 + V BCE terms share one target, so they run as ONE
-weighted-BCE kernel over the stacked logits; nothing else differs from calling the drop-in
-modules one by one (tests assert both give the same numbers)."""
+"""The per-iteration call sequences of the reference's training loops as step objects:
+
+  SyntheticTrainStep — train_synthetic.py:175-205 (zero_grad -> forward -> BCE(joint) + lambda * anomaly-L1
+      + sum_v BCE(head_v) + loss_z_q -> backward -> Adam)
+  ERA5TrainStep      — train_ERA5_Land.py:168-198 (the same with BCE_loss / Anomaly_L1_loss: `mask_valid` built from the
+      cold-surface mask, `pred[:, 0]`, the per-time-step cold-surface mask added to the anomaly loss' extreme mask)
+
+The 1 + V BCE terms share one target, so they run as ONE weighted-BCE kernel over the stacked logits; nothing else
+differs from calling the drop-in loss modules one by one (tests assert both give the same numbers).
+
+Data parallel (world > 1, idee_amd/parallel.py): every loss is the GLOBAL-batch loss of the reference (which computes
+its losses on DataParallel-gathered outputs): class counts are all-reduced before the BCE weights are formed, and a
+rank's ratio-type losses num_r / den_r are rescaled by den_r * world / sum_r den_r so that the averaged gradient is the
+gradient of sum_r num_r / sum_r den_r."""
 from __future__ import annotations
 
 import torch
@@ -11,7 +20,7 @@ from . import ops, optim, parallel
 from .models.build import VQ_model
 
 
-class SyntheticTrainStep:
+class _TrainStep:
     def __init__(self, config, device="cuda", model=None):
         self.config = config
         self.model = (model if model is not None else VQ_model(config)).to(device)
@@ -21,28 +30,75 @@ class SyntheticTrainStep:
         parallel.broadcast_parameters(self.opt.flat_p)
         self.code0 = torch.zeros(1, dtype=torch.long, device=device)
 
-    def losses(self, outs, mask_extreme, mask_extreme_loss):
-        """outs of VQ_model.forward; mask_extreme (N,H,W) -> total loss and its parts."""
-        pred, pred_y, _anomaly, z_q, loss_z_q = outs
-        target = mask_extreme.float().reshape(-1)
-        counts = parallel.all_reduce_sum_(ops.bce_class_counts(target))
-        logits = torch.cat([pred.reshape(1, -1)] + [p.reshape(1, -1) for p in pred_y], 0)
-        bce = ops.WeightedBCE.apply(logits, target, None, counts)
-        l_ext, l_var = bce[0], bce[1:].sum()
+    @staticmethod
+    def _stack_logits(pred, pred_y):
+        """joint (N,1,H,W) | (N,1,T3,H,W) and V heads of the same shape -> ((1+V)*T3, N*H*W) rows sharing one target.
+        T3 > 1 only at T = 16, where the reference's own loss is ill-defined: each temporal
+        slice is then scored against the same target and the slices are averaged."""
+        if pred.dim() == 4:
+            return torch.cat([pred.reshape(1, -1)] + [p.reshape(1, -1) for p in pred_y], 0), 1
+        T3 = pred.shape[2]
+        rows = [p[:, 0].permute(1, 0, 2, 3).reshape(T3, -1) for p in [pred] + list(pred_y)]
+        return torch.cat(rows, 0), T3
+
+    def _bce_terms(self, outs, target, valid):
+        pred, pred_y = outs[0], outs[1]
+        target = target.float().reshape(-1)
+        valid = valid.float().reshape(-1) if valid is not None else None
+        counts = parallel.all_reduce_sum_(ops.bce_class_counts(target, valid))
+        logits, T3 = self._stack_logits(pred, pred_y)
+        bce = ops.WeightedBCE.apply(logits, target, valid, counts)
+        if valid is not None and parallel.world_size() > 1:       # denominators (valid pixels) differ between shards
+            bce = bce * parallel.global_anomaly_scale(valid.sum())
+        bce = bce.reshape(-1, T3).mean(1)
+        return bce[0], bce[1:].sum()
+
+    def _anomaly_term(self, z_q, mask_loss, mask_valid_t):
         vq0 = self.model.vq.indices_to_codes(self.code0).detach()
         zq_tokens = z_q.permute(0, 1, 3, 4, 5, 2)
         l_anom, den = ops.AnomalyL1.apply(zq_tokens if zq_tokens.is_contiguous() else zq_tokens.contiguous(),
-                                          mask_extreme_loss.float(), None, vq0)
+                                          mask_loss.float(), mask_valid_t.float() if mask_valid_t is not None else None, vq0)
         if parallel.world_size() > 1:      # global-batch normalisation (SURVEY.md §8(e))
             l_anom = l_anom * parallel.global_anomaly_scale(den)
+        return l_anom
+
+    def _finish(self, l_ext, l_anom, l_var, loss_z_q):
         total = l_ext + l_anom * self.config.lambda_anomaly + l_var + loss_z_q.reshape(())
         return total, dict(extreme=l_ext, anomaly=l_anom, var=l_var, z_q=loss_z_q.reshape(()))
 
-    def step(self, x_d, mask_extreme, mask_extreme_loss):
+    def _step(self, x_d, *masks):
         self.opt.zero_grad(set_to_none=True)
         outs = self.model(x_d)
-        total, parts = self.losses(outs, mask_extreme, mask_extreme_loss)
+        total, parts = self.losses(outs, *masks)
         total.backward()
         parallel.sync_gradients(self.opt)
         self.opt.step()
         return total.detach(), parts, outs
+
+
+class SyntheticTrainStep(_TrainStep):
+    def losses(self, outs, mask_extreme, mask_extreme_loss):
+        """outs of VQ_model.forward; mask_extreme (N,H,W) -> total loss and its parts."""
+        l_ext, l_var = self._bce_terms(outs, mask_extreme, None)
+        l_anom = self._anomaly_term(outs[3], mask_extreme_loss, None)
+        return self._finish(l_ext, l_anom, l_var, outs[4])
+
+    def step(self, x_d, mask_extreme, mask_extreme_loss):
+        return self._step(x_d, mask_extreme, mask_extreme_loss)
+
+
+class ERA5TrainStep(_TrainStep):
+    """train_ERA5_Land.py:168-198.  Batch as the ERA5-Land dataset yields it (dataset/ERA5_Land_dataset.py:521-625):
+    x_d (N,V,2,T,H,W); mask_drought (N,H,W); mask_drought_loss (N,H,W); mask_cold_surface (N,H,W);
+    mask_cold_surface_loss (N,T,H,W).  mask_valid = max(1 - mask_cold_surface, 0) (:176-177)."""
+
+    threshold = 0.35          # sigmoid threshold of the real-data drivers (train_ERA5_Land.py:205-208)
+
+    def losses(self, outs, mask_drought, mask_drought_loss, mask_cold_surface, mask_cold_surface_loss):
+        mask_valid = (1.0 - mask_cold_surface.float()).clamp_min_(0.0)
+        l_ext, l_var = self._bce_terms(outs, mask_drought, mask_valid)
+        l_anom = self._anomaly_term(outs[3], mask_drought_loss, mask_cold_surface_loss)
+        return self._finish(l_ext, l_anom, l_var, outs[4])
+
+    def step(self, x_d, mask_drought, mask_drought_loss, mask_cold_surface, mask_cold_surface_loss):
+        return self._step(x_d, mask_drought, mask_drought_loss, mask_cold_surface, mask_cold_surface_loss)

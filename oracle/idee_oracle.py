@@ -392,6 +392,21 @@ def train_losses_synthetic(outs, mask_extreme, mask_extreme_loss, sd, cfg):
     return total, dict(extreme=l_ext, anomaly=l_anom, var=l_var, z_q=loss_z_q.reshape(()))
 
 
+def train_losses_era5(outs, mask_drought, mask_drought_loss, mask_cold_surface, mask_cold_surface_loss, sd, cfg):
+    """The loss assembly of train_ERA5_Land.py:176-198: mask_valid = max(1 - mask_cold_surface, 0) (:176-177);
+    BCE_loss on pred[:, 0] and every pred_y[k][:, 0] (:181, :196); Anomaly_L1_loss with the per-time-step cold-surface
+    mask (:184-192).  Masks: (N,H,W) except mask_cold_surface_loss (N,T,H,W)."""
+    pred, pred_y, _anom, z_q, loss_z_q = outs
+    mask_valid = (1 - mask_cold_surface.float()).clamp(min=0)
+    tgt = mask_drought.float()
+    l_ext = bce_loss(pred[:, 0], tgt, mask_valid)
+    vq0 = lfq_indices_to_codes(torch.tensor([0]), sd, cfg).detach()
+    l_anom = anomaly_l1(z_q, mask_drought_loss.float(), mask_cold_surface_loss.float(), vq0)
+    l_var = sum(bce_loss(p[:, 0], tgt, mask_valid) for p in pred_y)
+    total = l_ext + l_anom * cfg.lambda_anomaly + l_var + loss_z_q
+    return total, dict(extreme=l_ext, anomaly=l_anom, var=l_var, z_q=loss_z_q.reshape(()))
+
+
 # ----------------------------------------------------------------------------
 # Adam  (torch.optim.Adam as constructed at train_synthetic.py:127-129)
 # ----------------------------------------------------------------------------

@@ -1,0 +1,82 @@
+"""Child rank of tests/test_parallel_gpu.py: runs the PRODUCT data-parallel path (idee_amd.train.SyntheticTrainStep /
+ERA5TrainStep with world > 1: global class counts, global-denominator rescaling, flat gradient all-reduce, Adam with
+1/world) on its shard of a seeded global batch and writes what rank 0 ends up with.
+
+    RANK=r WORLD_SIZE=w MASTER_ADDR=127.0.0.1 MASTER_PORT=p IDEE_DIST_BACKEND=gloo IDEE_FORCE_DEVICE=0 \
+        python tests/dp_worker.py <kind> <out.pt>
+
+With WORLD_SIZE unset it runs the whole global batch in one process (the reference result)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def global_batch(kind, cfg, N, T, H, W):
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((N, cfg.in_channels_dynamic, cfg.in_channels, T, H, W), generator=g).clamp_(-10, 10)
+    me = (torch.rand((N, H, W), generator=g) < 0.3).float()
+    ml = (torch.rand((N, H, W), generator=g) < 0.4).float()
+    if kind == "era5":
+        # uneven valid-pixel counts between the shards: the per-rank denominators differ
+        cold = (torch.rand((N, H, W), generator=g) < torch.tensor([0.05, 0.1, 0.3, 0.5]).view(N, 1, 1)).float()
+        cold_t = (torch.rand((N, T, H, W), generator=g) < 0.15).float()
+        return x, (me, ml, cold, cold_t)
+    return x, (me, ml)
+
+
+def main():
+    kind, out = sys.argv[1], sys.argv[2]
+    from idee_amd import parallel
+    from idee_amd.config import default_config
+    from idee_amd.train import SyntheticTrainStep, ERA5TrainStep
+    rank, world, local = parallel.init_from_env()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    # diversity_gamma = 0: LFQ's batch-entropy term is the one part of the step that is per-shard BY DEFINITION
+    # (SURVEY.md §8(e)(3)); every other term must reproduce the global-batch step exactly
+    cfg = default_config(encoder="Swin_3D", in_channels=2 if kind == "era5" else 1, in_channels_dynamic=2, diversity_gamma=0.0)
+    torch.manual_seed(100 + rank)                         # different initial replicas: the broadcast must fix that
+    ts = (ERA5TrainStep if kind == "era5" else SyntheticTrainStep)(cfg, device=dev)
+    if world == 1:                                        # the single-rank reference starts from rank 0's replica
+        torch.manual_seed(100)
+        ts = (ERA5TrainStep if kind == "era5" else SyntheticTrainStep)(cfg, device=dev)
+    N, T, H, W = 4, 8, 12, 20
+    x, masks = global_batch(kind, cfg, N, T, H, W)
+    lo, hi = parallel.shard_batch(N, rank, world)
+    x = x[lo:hi].to(dev)
+    masks = tuple(m[lo:hi].to(dev) for m in masks)
+    p0 = ts.opt.flat_p.clone()
+    # step 1 by hand (to look at the averaged gradient), step 2 through .step()
+    ts.opt.zero_grad(set_to_none=True)
+    outs = ts.model(x)
+    total, parts = ts.losses(outs, *masks)
+    total.backward()
+    parallel.sync_gradients(ts.opt)
+    grad = (ts.opt.flat_g * ts.opt.grad_scale).clone()
+    ts.opt.step()
+    p1 = ts.opt.flat_p.clone()
+    total2, _, _ = ts.step(x, *masks)
+    res = dict(world=world, p0=p0.cpu(), grad=grad.cpu(), p1=p1.cpu(), p2=ts.opt.flat_p.cpu(),
+               parts={k: float(v) for k, v in parts.items()}, total2=float(total2))
+    if world > 1:
+        # every rank must hold identical parameters after the steps
+        mine = ts.opt.flat_p.clone()
+        ref = mine.clone()
+        torch.distributed.broadcast(ref, src=0)
+        res["replicas_equal"] = bool(torch.equal(mine, ref))
+        flags = [None] * world
+        torch.distributed.all_gather_object(flags, res["replicas_equal"])
+        res["replicas_equal"] = all(flags)
+    if rank == 0:
+        torch.save(res, out)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,8 @@ def _install_timm_stub():
 
 
 _install_timm_stub()
+sys.path.insert(0, os.path.dirname(HERE))
+from conftest import relu_record  # noqa: E402  (ReLU-tie listing: tests/conftest.py)
 sys.path.insert(0, "/root/reference")
 import config as ref_config  # noqa: E402
 from models.build import VQ_model  # noqa: E402
@@ -141,7 +143,9 @@ def fx_conv_block(tag, cin, cout, seed):
     cb = ref_cnn.conv_block(cin, cout, (3, 3, 3), 0.0, 0.0)
     rerandomise(cb, seed)
     x = rand((2, cin, 8, 6, 10), seed + 1).requires_grad_()
-    y = cb(x)
+    with relu_record() as rec:
+        y = cb(x)
+    assert rec.ties() == 0, f"conv_block_{tag}: seed {seed} has a ReLU tie; pick another seed"
     r = rand(y.shape, seed + 2)
     (y * r).sum().backward()
     out = dict(x=x.detach(), y=y.detach(), r=r, dx=x.grad)
@@ -271,7 +275,9 @@ def fx_e2e(tag, cfg, N, T, H, W, seed, n_steps=3, with_grads=True):
     losses = []
     for step in range(n_steps if with_grads else 0):
         opt.zero_grad(set_to_none=True)
-        pred, pred_y, anomaly, z_q, loss_z_q = model(x_d)
+        with relu_record() as rec:
+            pred, pred_y, anomaly, z_q, loss_z_q = model(x_d)
+        assert step > 0 or rec.ties() == 0, f"e2e_{tag}: seed {seed} has a ReLU tie in the compared step; pick another seed"
         tgt = mask_extreme.unsqueeze(1)
         l_ext = crit(pred, tgt)
         l_an = crit_an(z_q, mask_loss, model.vq.indices_to_codes(torch.Tensor([0]).long()).clone().detach())
@@ -294,6 +300,59 @@ def fx_e2e(tag, cfg, N, T, H, W, seed, n_steps=3, with_grads=True):
     save("e2e_" + tag, **out)
 
 
+def fx_e2e_era5(tag, cfg, N, T, H, W, seed, n_steps=3):
+    """The train_ERA5_Land.py:168-198 call sequence on random tensors shaped like the ERA5-Land dataset's items
+    (dataset/ERA5_Land_dataset.py:521-625: C = 2 channels mean/std; drought, cold-surface masks)."""
+    torch.manual_seed(seed)
+    model = VQ_model(cfg)
+    rerandomise(model, seed)
+    model.train()
+    V, C = cfg.in_channels_dynamic, cfg.in_channels
+    g = torch.Generator().manual_seed(seed + 1)
+    x_d = torch.randn((N, V, C, T, H, W), generator=g).clamp_(-10, 10)
+    drought = (torch.rand((N, H, W), generator=g) < 0.3).float()
+    drought_loss = (torch.rand((N, H, W), generator=g) < 0.4).float()
+    cold = (torch.rand((N, H, W), generator=g) < 0.15).float()
+    cold_loss = (torch.rand((N, T, H, W), generator=g) < 0.15).float()
+    out = dict(x_d=x_d, mask_drought=drought, mask_drought_loss=drought_loss, mask_cold_surface=cold,
+               mask_cold_surface_loss=cold_loss, cfg_V=np.array(V), cfg_C=np.array(C), encoder=np.array(cfg.encoder))
+    out.update(sd_arrays(model))
+    crit = ref_losses.BCE_loss()
+    crit_an = ref_losses.Anomaly_L1_loss(n_dynamic=V, delta_t=cfg.delta_t, dim=cfg.en_embed_dim[-1])
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay, betas=(cfg.beta1, cfg.beta2))
+    losses = []
+    for step in range(n_steps):
+        opt.zero_grad(set_to_none=True)
+        mask_valid = 1 - cold                                   # train_ERA5_Land.py:176-177
+        mask_valid[mask_valid < 0] = 0
+        with relu_record() as rec:
+            pred, pred_y, anomaly, z_q, loss_z_q = model(x_d)
+        assert step > 0 or rec.ties() == 0, f"e2e_{tag}: seed {seed} has a ReLU tie in the compared step; pick another seed"
+        loss = crit(pred[:, 0, ...], drought, mask_valid)
+        l_ext = loss.detach().clone()
+        l_an = crit_an(z_q, drought_loss.float(), cold_loss, model.vq.indices_to_codes(torch.Tensor([0]).long()).detach())
+        l_var = 0
+        for k in range(V):
+            l_var = l_var + crit(pred_y[k][:, 0, ...], drought.float(), mask_valid)
+        loss = loss + l_an * cfg.lambda_anomaly + l_var + loss_z_q
+        loss.backward()
+        if step == 0:
+            out.update({"train/z": pred.detach(), "train/y": torch.stack([t.detach() for t in pred_y]),
+                        "train/anomaly": anomaly, "train/z_q": z_q.detach(), "train/loss_z_q": loss_z_q.detach(),
+                        "train/l_ext": l_ext, "train/l_anom": l_an.detach(), "train/l_var": l_var.detach(),
+                        "train/loss": loss.detach()})
+            out.update({"grad/" + k: p.grad.clone() for k, p in model.named_parameters()})
+        opt.step()
+        losses.append(float(loss.detach()))
+    out["train/loss_per_step"] = np.array(losses)
+    out.update(sd_arrays(model, prefix=f"sd_after{n_steps}/"))
+    save("e2e_" + tag, **out)
+
+
+if __name__ == "__main__" and "--era5-only" in sys.argv:
+    fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
+
+
 def main():
     fx_swin_block("w244_noshift", (2, 4, 4), (0, 0, 0), 8, 8, 12, seed=10)
     fx_swin_block("w244_shift", (2, 4, 4), (1, 2, 2), 8, 8, 12, seed=20)
@@ -305,7 +364,7 @@ def main():
     fx_patch_embed("swin_c1", ref_swin.PatchEmbed3D, 1, 100)
     fx_patch_embed("swin_c2", ref_swin.PatchEmbed3D, 2, 110)
     fx_patch_embed("cnn_c1", ref_cnn.PatchEmbed3D, 1, 120)
-    fx_conv_block("1_16", 1, 16, 130)
+    fx_conv_block("1_16", 1, 16, 131)    # 130 has a ReLU tie
     fx_conv_block("16_16", 16, 16, 140)
     fx_proj_var(150)
     fx_lfq("k2_train", 2, True, 200)
@@ -314,7 +373,7 @@ def main():
     fx_classifier(300, V=2)
     fx_losses(400)
     fx_e2e("swin_v2_14x18", ref_cfg(in_channels_dynamic=2), N=2, T=8, H=14, W=18, seed=500)
-    fx_e2e("cnn_v2_12x16", ref_cfg(in_channels_dynamic=2, encoder="CNN_3D"), N=2, T=8, H=12, W=16, seed=600)
+    fx_e2e("cnn_v2_12x16", ref_cfg(in_channels_dynamic=2, encoder="CNN_3D"), N=2, T=8, H=12, W=16, seed=601)  # 600: tie
     fx_e2e("swin_v6_8x8_c2", ref_cfg(in_channels=2), N=1, T=8, H=8, W=8, seed=700, with_grads=False)
     fx_config_defaults()
 
@@ -496,8 +555,10 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
     fx_dataset_items()
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
+                                                                "--era5-only")):
     main()
+    fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
     fx_patch_mergings()
     fx_dataset_items()
     fx_vq("k2_train", 2, True, 800)

@@ -4,6 +4,7 @@ declares (no compute calls), the flag surface and the state-dict keys equal the 
 import json
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -101,3 +102,74 @@ def test_cosine_lr_schedule_known_answers():
     s.step_update(2); assert abs(o.param_groups[0]["lr"] - (1e-5 + 0.5 * (1e-3 - 1e-5) * (1 + math.cos(math.pi * 2 / 100)))) < 1e-15
     s.step_update(50); assert abs(o.param_groups[0]["lr"] - (1e-5 + 0.5 * (1e-3 - 1e-5))) < 1e-12
     s.step_update(100); assert o.param_groups[0]["lr"] == 1e-5   # past the single cycle
+
+
+def test_step_lr_schedule_known_answers():
+    """timm StepLRScheduler semantics at the reference's settings (utils_train.py:146-154; t_in_epochs=True): `step(epoch)`
+    applies warm-up then base * rate ** (t // decay_t); `step_update` is ignored, which is what the reference's drivers
+    call (so their learning rate stays at warmup_lr_init)."""
+    from idee_amd.harness import StepLRScheduler, get_learning_scheduler
+    from idee_amd.config import default_config
+
+    class Opt:
+        param_groups = [dict(lr=1e-3)]
+    o = Opt()
+    s = StepLRScheduler(o, decay_t=20, decay_rate=0.9, warmup_t=2, warmup_lr_init=1e-6)
+    assert o.param_groups[0]["lr"] == 1e-6
+    s.step_update(50); assert o.param_groups[0]["lr"] == 1e-6          # ignored (t_in_epochs)
+    s.step(1); assert abs(o.param_groups[0]["lr"] - (1e-6 + (1e-3 - 1e-6) / 2)) < 1e-15
+    s.step(2); assert o.param_groups[0]["lr"] == 1e-3
+    s.step(19); assert o.param_groups[0]["lr"] == 1e-3
+    s.step(20); assert abs(o.param_groups[0]["lr"] - 0.9e-3) < 1e-15
+    s.step(45); assert abs(o.param_groups[0]["lr"] - 1e-3 * 0.9 ** 2) < 1e-15
+    o2 = Opt(); o2.param_groups = [dict(lr=1e-3)]
+    cfg = default_config(lr_scheduler="step")
+    assert isinstance(get_learning_scheduler(o2, cfg), StepLRScheduler)
+    cfg.lr_scheduler = "linear"
+    with pytest.raises(ValueError):
+        get_learning_scheduler(o2, cfg)
+
+
+def test_adam_state_dict_interchanges_with_torch_adam():
+    """idee_amd.optim.Adam speaks torch.optim.Adam's state-dict layout both ways (checkpoint interchange with the
+    reference's `optimizer_state_dict`, utils_train.py:562-584) and refuses a parameter without a gradient."""
+    from idee_amd import optim
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    ref = torch.optim.Adam(lin.parameters(), lr=2e-3, weight_decay=0.003, betas=(0.8, 0.99))
+    lin(torch.randn(4, 5)).sum().backward()
+    ref.step()
+    ours = optim.Adam(lin.parameters(), lr=1e-3)
+    ours.load_state_dict(ref.state_dict())
+    assert ours.step_count == 1 and ours.param_groups[0]["lr"] == 2e-3 and tuple(ours.param_groups[0]["betas"]) == (0.8, 0.99)
+    off = 0
+    for i, p in enumerate(ours.params):
+        st = ref.state_dict()["state"][i]
+        assert torch.equal(ours.exp_avg[off:off + p.numel()].view(p.shape), st["exp_avg"])
+        assert torch.equal(ours.exp_avg_sq[off:off + p.numel()].view(p.shape), st["exp_avg_sq"])
+        off += p.numel()
+    sd = ours.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == [0, 1, 2, 3]
+    lin2 = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    back = torch.optim.Adam(lin2.parameters())
+    back.load_state_dict(sd)                                           # torch accepts it
+    assert back.state_dict()["state"][2]["exp_avg"].shape == (2, 3) and float(back.state_dict()["state"][0]["step"]) == 1.0
+    # a parameter without a gradient: torch would skip it; the flat step refuses instead of decaying it silently
+    ours.zero_grad(set_to_none=True)
+    lin[0](torch.randn(4, 5)).sum().backward()
+    with pytest.raises(RuntimeError, match="no gradient"):
+        ours.gather_grads()
+
+
+def test_bench_refuses_rank_count_mismatch():
+    """`bench.py --gpus N` never reports a line for another rank count: a torchrun-style environment with a different
+    WORLD_SIZE is refused before any GPU work, and the self-launch path refuses when fewer GPUs are visible."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "IDEE_FORCE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"metric"' not in r.stdout

@@ -165,7 +165,14 @@ def test_e2e_forward(tag):
     close(lz, a["eval/loss_z_q"])
 
 
-@pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16"])
+def _losses(a, outs, sd, cfg):
+    if "mask_drought" in a:      # train_ERA5_Land.py sequence
+        return O.train_losses_era5(outs, a["mask_drought"], a["mask_drought_loss"], a["mask_cold_surface"],
+                                   a["mask_cold_surface_loss"], sd, cfg)
+    return O.train_losses_synthetic(outs, a["mask_extreme"], a["mask_extreme_loss"], sd, cfg)
+
+
+@pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16", "era5_swin_v3_c2_10x12"])
 def test_e2e_train_steps(tag):
     a, sd, grads = load_golden("e2e_" + tag)
     cfg = _cfg_from(a)
@@ -175,7 +182,7 @@ def test_e2e_train_steps(tag):
     losses = []
     for step in range(1, 4):
         outs = O.vq_model_forward(a["x_d"], sd, cfg, training=True)
-        total, parts = O.train_losses_synthetic(outs, a["mask_extreme"], a["mask_extreme_loss"], sd, cfg)
+        total, parts = _losses(a, outs, sd, cfg)
         for k in names:
             sd[k].grad = None
         total.backward()

