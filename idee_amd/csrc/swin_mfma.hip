@@ -218,6 +218,134 @@ __device__ __forceinline__ void mm_lds(f32x4 (&Y)[OT][M], const float* wl, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 GEMMs ("bf16x4"): an f32 operand x is cut into two bf16 pieces x = hi + lo + O(2^-18 |x|)
+// (hi = RNE_bf16(x), lo = RNE_bf16(x - hi)) and the product (a_hi + a_lo)(b_hi + b_lo) is formed EXACTLY (bf16 x bf16
+// products are exact in f32) by TWO v_mfma_f32_16x16x32_bf16 with the pieces concatenated along K: a 16-deep f32 GEMM
+// step (4 x v_mfma_f32_16x16x4_f32, 128 cycles) becomes 2 x 16 cycles on the bf16 matrix pipe, which — unlike the
+// f32-input MFMA (tools/micro/coexec.hip) — overlaps with VALU work (tools/micro/coexec_bf16.hip).
+// K-slot map of the 16x16x32 operands (lane = 16 g + i; slot jj = 0..7 of lane group g):
+//     B (column i):  jj < 4 -> hi piece of k = 4 g + jj      jj >= 4 -> lo piece of k = 4 g + jj - 4
+//     A (row i):     jj < 4 -> piece P of k = 4 g + jj       jj >= 4 -> the same piece P again      (P = hi, then lo)
+// so MFMA(A_hi, B) + MFMA(A_lo, B) = sum_k (a_hi + a_lo)[k] (b_hi + b_lo)[k] with the (g, jj & 3) <-> k map of the f32
+// 16x16x4 chain — every fragment layout of this file ("token layout", weight fragments, D tiles) carries over unchanged.
+// Operand rounding 2^-18 relative (vs 2^-24 for f32): ~2e-6 relative error per GEMM, 100x inside the 2e-4 activation
+// tolerance the parity tests state; IDEE_SWIN_MATH=f32 selects the exact-f32 kernels.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// Two piece formats, chosen per kernel (template flag F16):
+//   bf16 pieces (F16 = false): 8 + 8 mantissa bits, f32's exponent range — operand rounding 2^-18; used by the BACKWARD
+//       kernels, whose gradient operands have no a-priori scale;
+//   f16 pieces  (F16 = true): 11 + 11 mantissa bits — operand rounding 2^-22 (f32 level) for |x| in [6e-5, 65504], an
+//       absolute floor of 2^-25 below; used by the FORWARD kernel, whose operands (LayerNorm outputs, weights, softmax,
+//       GELU) are O(1) by construction.
+// An operand fragment is 4 registers = 8 pieces; fragments travel as u32x4 and are bit-cast at the MFMA.
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_s(u32x4 a, u32x4 b, f32x4 c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: low half = a, high half = b
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {    // v_cvt_pk_f16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, h16x2));
+}
+struct Split { unsigned h01, h23, l01, l23; };
+template <bool F16>
+__device__ __forceinline__ Split split2(f32x4 x) {
+  Split p;
+  if (F16) {
+    p.h01 = cvt_pk_f16(x[0], x[1]);
+    p.h23 = cvt_pk_f16(x[2], x[3]);
+    // residual x - float(hi), exact, one v_fma_mix_f32 per element (the f16 half is read in place: no conversion back)
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p.h01), "v"(x[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p.h01), "v"(x[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(p.h23), "v"(x[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(p.h23), "v"(x[3]));
+    p.l01 = cvt_pk_f16(r0, r1);
+    p.l23 = cvt_pk_f16(r2, r3);
+  } else {
+    p.h01 = cvt_pk_bf16(x[0], x[1]);
+    p.h23 = cvt_pk_bf16(x[2], x[3]);
+    // residual x - float(hi), exact; as v_pk_add_f32 with a negated source (LLVM scalarises a v2f32 fsub, hence the asm)
+    const f32x2 hf01 = {__uint_as_float(p.h01 << 16), __uint_as_float(p.h01 & 0xffff0000u)};
+    const f32x2 hf23 = {__uint_as_float(p.h23 << 16), __uint_as_float(p.h23 & 0xffff0000u)};
+    const f32x2 x01 = {x[0], x[1]}, x23 = {x[2], x[3]};
+    f32x2 r01, r23;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r01) : "v"(x01), "v"(hf01));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r23) : "v"(x23), "v"(hf23));
+    p.l01 = cvt_pk_bf16(r01[0], r01[1]);
+    p.l23 = cvt_pk_bf16(r23[0], r23[1]);
+  }
+  return p;
+}
+__device__ __forceinline__ u32x4 frag_b(const Split& p) { return u32x4{p.h01, p.h23, p.l01, p.l23}; }
+
+// weight tile -> the two A fragments (hi | hi), (lo | lo), stored at ((tile * 2 + piece) * 64 + lane) * 4 words
+template <bool F16>
+__device__ __forceinline__ void put_wfrag_b(unsigned* wl, int tile, f32x4 w, int lane) {
+  const Split p = split2<F16>(w);
+  *reinterpret_cast<u32x4*>(wl + ((tile * 2 + 0) * 64 + lane) * 4) = u32x4{p.h01, p.h23, p.h01, p.h23};
+  *reinterpret_cast<u32x4*>(wl + ((tile * 2 + 1) * 64 + lane) * 4) = u32x4{p.l01, p.l23, p.l01, p.l23};
+}
+__device__ __forceinline__ u32x4 get_wfrag_b(const unsigned* wl, int tile, int piece, int lane) {
+  return *reinterpret_cast<const u32x4*>(wl + ((tile * 2 + piece) * 64 + lane) * 4);
+}
+// Y[OT][M] += W X with the weight fragments of tiles tile0 + o * KT + k in LDS and X already split (B fragments)
+template <bool F16, int OT, int KT, int M>
+__device__ __forceinline__ void mm_b(f32x4 (&Y)[OT][M], const unsigned* wl, int tile0, const u32x4 (&XB)[KT][M], int lane) {
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const u32x4 ah = get_wfrag_b(wl, tile0 + o * KT + k, 0, lane), al = get_wfrag_b(wl, tile0 + o * KT + k, 1, lane);
+#pragma unroll
+      for (int m = 0; m < M; ++m) Y[o][m] = mfma_s<F16>(ah, XB[k][m], Y[o][m]);
+#pragma unroll
+      for (int m = 0; m < M; ++m) Y[o][m] = mfma_s<F16>(al, XB[k][m], Y[o][m]);
+    }
+}
+
+// bf16 piece images for the token-reduction GEMMs: one row per token, kImgRow words = [16 positions hi | 16 positions lo |
+// pad] (96 bytes: the 8 token rows a 32-lane half of ds_read_b64_tr_b16 touches fall on distinct banks).  A lane of the
+// token layout owns positions 4kq..4kq+3 of its token: one 8-byte store per piece.  Read back TRANSPOSED by
+// ds_read_b64_tr_b16: lane (row i, group g) receives position i of tokens 4g..4g+3 — the K = tokens operand layout.
+constexpr int kImgRow = 24;   // 32-bit words per token row
+__device__ __forceinline__ void put_img_b(unsigned* img, int row, int kq, const Split& p) {
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<u32x2v*>(img + row * kImgRow + 2 * kq) = u32x2v{p.h01, p.h23};
+  *reinterpret_cast<u32x2v*>(img + row * kImgRow + 8 + 2 * kq) = u32x2v{p.l01, p.l23};
+}
+// the 4 tokens 16 m + 4 g + {0..3} of position (lane & 15), piece `lo`
+__device__ __forceinline__ unsigned long long tr_read(const unsigned* img, int m, int lo, int lane) {
+  const int row = 16 * m + 4 * (lane >> 4) + ((lane & 15) >> 2);
+  const unsigned* p = img + row * kImgRow + lo * 8 + 2 * (lane & 3);
+  const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+  return __builtin_bit_cast(unsigned long long, t);
+}
+// acc[a][b] += sum over the wave's 16 M tokens of A[a][tok] B[b][tok]   (positions a of imgA on rows, b of imgB on columns)
+template <int M>
+__device__ __forceinline__ void gemm_tok_b(f32x4& acc, const unsigned* imgA, const unsigned* imgB, int lane) {
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const unsigned long long ah = tr_read(imgA, m, 0, lane), al = tr_read(imgA, m, 1, lane);
+    const unsigned long long bh = tr_read(imgB, m, 0, lane), bl = tr_read(imgB, m, 1, lane);
+    const u32x4 B = {(unsigned)bh, (unsigned)(bh >> 32), (unsigned)bl, (unsigned)(bl >> 32)};
+    acc = mfma_s<false>(u32x4{(unsigned)ah, (unsigned)(ah >> 32), (unsigned)ah, (unsigned)(ah >> 32)}, B, acc);
+    acc = mfma_s<false>(u32x4{(unsigned)al, (unsigned)(al >> 32), (unsigned)al, (unsigned)(al >> 32)}, B, acc);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -329,22 +457,30 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
       for (int h = 0; h < NH; ++h) {
         const int c = h / HPC, s0 = (h % HPC) * SP;
         f32x4 S[TPW][TPW];
+        // the k-steps outermost: the TPW^2 tiles are independent accumulators, so no MFMA waits on its predecessor
 #pragma unroll
         for (int kt = 0; kt < TPW; ++kt)
 #pragma unroll
-          for (int qt = 0; qt < TPW; ++qt) {
-            f32x4 acc = rb[h][kt][qt];
+          for (int qt = 0; qt < TPW; ++qt) S[kt][qt] = rb[h][kt][qt];
 #pragma unroll
-            for (int s = 0; s < SP; ++s)
-              acc = MFMA(QKV[CT + c][grp * TPW + kt][s0 + s], QKV[c][grp * TPW + qt][s0 + s], acc);
-            if (g.shifted) {
-              const int4 rk = *reinterpret_cast<const int4*>(rid_l + 16 * (grp * TPW + kt) + 4 * kq);
+        for (int s = 0; s < SP; ++s)
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt)
+              S[kt][qt] = MFMA(QKV[CT + c][grp * TPW + kt][s0 + s], QKV[c][grp * TPW + qt][s0 + s], S[kt][qt]);
+        if (g.shifted) {
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const int4 rk = *reinterpret_cast<const int4*>(rid_l + 16 * (grp * TPW + kt) + 4 * kq);
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt) {
               const int rq = t[grp * TPW + qt].rid;
-              acc[0] += rk.x != rq ? -100.f : 0.f; acc[1] += rk.y != rq ? -100.f : 0.f;
-              acc[2] += rk.z != rq ? -100.f : 0.f; acc[3] += rk.w != rq ? -100.f : 0.f;
+              S[kt][qt][0] += rk.x != rq ? -100.f : 0.f; S[kt][qt][1] += rk.y != rq ? -100.f : 0.f;
+              S[kt][qt][2] += rk.z != rq ? -100.f : 0.f; S[kt][qt][3] += rk.w != rq ? -100.f : 0.f;
             }
-            S[kt][qt] = acc;
           }
+        }
         // softmax over keys (rows) for each query column
 #pragma unroll
         for (int qt = 0; qt < TPW; ++qt) {
@@ -366,17 +502,22 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
           for (int kt = 0; kt < TPW; ++kt) S[kt][qt] *= inv;
         }
         // O[chan][query] = sum_keys V^T[chan][key] P[key][query]; keep this head's rows
+        {
+          f32x4 acc[TPW];   // the query blocks interleaved: independent accumulators between dependent MFMAs
 #pragma unroll
-        for (int qt = 0; qt < TPW; ++qt) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int qt = 0; qt < TPW; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) {
             const f32x4 vf = ld4(vt + (16 * c + sig<HPC>(lane & 15)) * VS + 16 * (grp * TPW + kt) + 4 * kq);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = MFMA(vf[s], S[kt][qt][s], acc);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int qt = 0; qt < TPW; ++qt) acc[qt] = MFMA(vf[s], S[kt][qt][s], acc[qt]);
           }
 #pragma unroll
-          for (int r = 0; r < SP; ++r) O[c][grp * TPW + qt][s0 + r] = acc[s0 + r];
+          for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+            for (int r = 0; r < SP; ++r) O[c][grp * TPW + qt][s0 + r] = acc[qt][s0 + r];
         }
       }
     }
@@ -422,6 +563,267 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
         for (int c = 0; c < CT; ++c) st4(y + t[m].off + 16 * c + 4 * kq, Y[c][m]);
   }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// forward with the four linear layers (qkv, proj, fc1, fc2: 75 % of the block's FLOPs) on the split-bf16 MFMA path;
+// the attention core (K Q^T, softmax, V^T P) stays on the f32 MFMA.  Same arguments and layout as swin_fwd_mfma_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int C, int NH, int NW, bool SAVE_H>
+__global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
+    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ hsave, const float* __restrict__ qkv_w,
+    const float* __restrict__ qkv_b, const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+    const float* __restrict__ fc1_w, const float* __restrict__ fc1_b, const float* __restrict__ fc2_w,
+    const float* __restrict__ fc2_b, const float* __restrict__ rel_bias, Geom g) {
+  constexpr int CT = C / 16, HID = 4 * C, HT = HID / 16, HD = C / NH;
+  static_assert(C % 16 == 0 && HD <= 16 && 16 % HD == 0, "head_dim must divide 16");
+  constexpr int HPC = 16 / HD;             // heads per 16-channel chunk
+  constexpr int SP = 4 / HPC;              // k-steps per head inside a chunk
+  constexpr int TPW = NW >= 16 ? NW / 16 : 1;   // column blocks per window group
+  constexpr int NG = MT / TPW;             // window groups per wave
+    __shared__ __attribute__((aligned(16))) float s_vt[4][C * VS];
+  __shared__ __attribute__((aligned(16))) int s_rid[4][64];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, v = b % g.V;
+  qkv_w += (long)v * 3 * C * C;  qkv_b += v * 3 * C;
+  proj_w += (long)v * C * C;     proj_b += v * C;
+  fc1_w += (long)v * HID * C;    fc1_b += v * HID;
+  fc2_w += (long)v * C * HID;    fc2_b += v * C;
+  rel_bias += (long)v * NH * NW * NW;
+
+  // ---- weight fragments: split-bf16 A fragments in LDS (shared by the 4 waves), biases as f32 fragments ----
+  constexpr int T_Q = 0, T_P = 3 * CT * CT, T_1 = T_P + CT * CT, T_2 = T_1 + HT * CT, NTILE = T_2 + CT * HT;
+  constexpr int B_Q = 0, B_P = 3 * CT, B_1 = B_P + CT, B_2 = B_1 + HT, NBIAS = B_2 + CT;
+  __shared__ __attribute__((aligned(16))) unsigned s_wf[NTILE * 2 * 256];
+  __shared__ __attribute__((aligned(16))) float s_bias[NBIAS * 256];
+  {
+    int i = 0;
+#pragma unroll
+    for (int o = 0; o < 3 * CT; ++o) {
+      const float mul = o < CT ? g.scale : 1.f;   // q pre-scaled (Swin_3D.py:155)
+      if ((i++) % 4 == wave) st4(s_bias + (B_Q + o) * 256 + lane * 4, vfrag<HPC>(qkv_b, 16 * o, lane, mul));
+#pragma unroll
+      for (int k = 0; k < CT; ++k)
+        if ((i++) % 4 == wave) put_wfrag_b<true>(s_wf, T_Q + o * CT + k, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul), lane);
+    }
+#pragma unroll
+    for (int o = 0; o < CT; ++o) {
+      if ((i++) % 4 == wave) st4(s_bias + (B_P + o) * 256 + lane * 4, vfrag<1>(proj_b, 16 * o, lane));
+      if ((i++) % 4 == wave) st4(s_bias + (B_2 + o) * 256 + lane * 4, vfrag<1>(fc2_b, 16 * o, lane));
+#pragma unroll
+      for (int k = 0; k < CT; ++k)
+        if ((i++) % 4 == wave) put_wfrag_b<true>(s_wf, T_P + o * CT + k, wfrag<false, 1, HPC>(proj_w, C, 16 * o, 16 * k, lane), lane);
+#pragma unroll
+      for (int k = 0; k < HT; ++k)
+        if ((i++) % 4 == wave) put_wfrag_b<true>(s_wf, T_2 + o * HT + k, wfrag<false, 1, 1>(fc2_w, HID, 16 * o, 16 * k, lane), lane);
+    }
+#pragma unroll
+    for (int o = 0; o < HT; ++o) {
+      if ((i++) % 4 == wave) st4(s_bias + (B_1 + o) * 256 + lane * 4, vfrag<1>(fc1_b, 16 * o, lane));
+#pragma unroll
+      for (int k = 0; k < CT; ++k)
+        if ((i++) % 4 == wave) put_wfrag_b<true>(s_wf, T_1 + o * CT + k, wfrag<false, 1, 1>(fc1_w, C, 16 * o, 16 * k, lane), lane);
+    }
+    __syncthreads();
+  }
+  auto BIAS = [&](int i) { return ld4(s_bias + i * 256 + lane * 4); };
+  // relative-position bias per (head, key block, query block): rows = keys 4kq+r, col = query j;
+  // for NW < 16 the cross-window entries of a column block are masked here once and for all
+  f32x4 rb[NH][TPW][TPW];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
+          const bool same = (key / NW) == (qry / NW);
+          rb[h][kt][qt][r] = same ? rel_bias[(h * NW + qry % NW) * NW + key % NW] : -1e30f;
+        }
+
+  float* vt = s_vt[wave];
+  int* rid_l = s_rid[wave];
+
+  for (int it0 = blockIdx.x * 4; it0 < g.items; it0 += gridDim.x * 4) {
+    Tok t[MT];
+    bool keep[MT];
+    f32x4 X[CT][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      t[m] = locate<NW>(g, b, it0 + wave, 16 * m + j, C);
+      keep[m] = t[m].valid;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) X[c][m] = t[m].valid ? ld4(x + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 XN[CT][MT];
+    float rstd[MT];
+    layer_norm_tl(X, XN, rstd, keep);   // zero padding is applied AFTER norm1 (Swin_3D.py:229-238)
+
+    f32x4 QKV[3 * CT][MT];
+    {
+      u32x4 bXN[CT][MT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bXN[c][m] = frag_b(split2<true>(XN[c][m]));
+#pragma unroll
+      for (int o = 0; o < 3 * CT; ++o) {
+        const f32x4 bqo = BIAS(B_Q + o);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) QKV[o][m] = bqo;
+      }
+      mm_b<true, 3 * CT, CT, MT>(QKV, s_wf, T_Q, bXN, lane);
+    }
+
+    wave_sync();   // previous iteration's readers of vt / rid are done
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vt[(16 * c + sig<HPC>(4 * kq + r)) * VS + 16 * m + j] = QKV[2 * CT + c][m][r];
+    if (kq == 0)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) rid_l[16 * m + j] = t[m].rid;
+    wave_sync();
+
+    f32x4 O[CT][MT];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int c = h / HPC, s0 = (h % HPC) * SP;
+        f32x4 S[TPW][TPW];
+        // the k-steps outermost: the TPW^2 tiles are independent accumulators, so no MFMA waits on its predecessor
+#pragma unroll
+        for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) S[kt][qt] = rb[h][kt][qt];
+#pragma unroll
+        for (int s = 0; s < SP; ++s)
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt)
+              S[kt][qt] = MFMA(QKV[CT + c][grp * TPW + kt][s0 + s], QKV[c][grp * TPW + qt][s0 + s], S[kt][qt]);
+        if (g.shifted) {
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const int4 rk = *reinterpret_cast<const int4*>(rid_l + 16 * (grp * TPW + kt) + 4 * kq);
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt) {
+              const int rq = t[grp * TPW + qt].rid;
+              S[kt][qt][0] += rk.x != rq ? -100.f : 0.f; S[kt][qt][1] += rk.y != rq ? -100.f : 0.f;
+              S[kt][qt][2] += rk.z != rq ? -100.f : 0.f; S[kt][qt][3] += rk.w != rq ? -100.f : 0.f;
+            }
+          }
+        }
+        // softmax over keys (rows) for each query column
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt) {
+          float mx = -3.0e38f;
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(S[kt][qt][0], S[kt][qt][1]), fmaxf(S[kt][qt][2], S[kt][qt][3])));
+          mx = chan_max(mx);
+          const float mxl = -mx * kLog2e;
+          f32x4 l4 = splat(0.f);
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const f32x4 ea = fma4(S[kt][qt], splat(kLog2e), splat(mxl));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[kt][qt][r] = __builtin_amdgcn_exp2f(ea[r]);
+            l4 += S[kt][qt];
+          }
+          const float inv = __builtin_amdgcn_rcpf(chan_sum(hsum(l4)));   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) S[kt][qt] *= inv;
+        }
+        // O[chan][query] = sum_keys V^T[chan][key] P[key][query]; keep this head's rows
+        {
+          f32x4 acc[TPW];   // the query blocks interleaved: independent accumulators between dependent MFMAs
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const f32x4 vf = ld4(vt + (16 * c + sig<HPC>(lane & 15)) * VS + 16 * (grp * TPW + kt) + 4 * kq);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int qt = 0; qt < TPW; ++qt) acc[qt] = MFMA(vf[s], S[kt][qt][s], acc[qt]);
+          }
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+            for (int r = 0; r < SP; ++r) O[c][grp * TPW + qt][s0 + r] = acc[qt][s0 + r];
+        }
+      }
+    }
+
+    // proj + shortcut
+    f32x4 Hs[CT][MT];
+    {
+      u32x4 bO[CT][MT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const f32x4 bpc = BIAS(B_P + c);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { Hs[c][m] = X[c][m] + bpc; bO[c][m] = frag_b(split2<true>(O[c][m])); }
+      }
+      mm_b<true, CT, CT, MT>(Hs, s_wf, T_P, bO, lane);
+    }
+    if (SAVE_H) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (t[m].valid)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) st4(hsave + t[m].off + 16 * c + 4 * kq, Hs[c][m]);
+    }
+    f32x4 HN[CT][MT];
+    float rstd2[MT];
+    bool all[MT] = {true, true, true, true};
+    layer_norm_tl(Hs, HN, rstd2, all);
+    f32x4 Y[CT][MT];
+    {
+      u32x4 bHN[CT][MT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const f32x4 b2c = BIAS(B_2 + c);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { Y[c][m] = Hs[c][m] + b2c; bHN[c][m] = frag_b(split2<true>(HN[c][m])); }
+      }
+      // one hidden 16-block at a time: fc1 -> GELU -> split -> fc2 (the hidden activation never exists as a whole)
+#pragma unroll
+      for (int ho = 0; ho < HT; ++ho) {
+        f32x4 A1[1][MT];
+        const f32x4 b1o = BIAS(B_1 + ho);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) A1[0][m] = b1o;
+        mm_b<true, 1, CT, MT>(A1, s_wf, T_1 + ho * CT, bHN, lane);
+        u32x4 bG[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bG[m] = frag_b(split2<true>(gelu4(A1[0][m])));
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const u32x4 ah = get_wfrag_b(s_wf, T_2 + c * HT + ho, 0, lane), al = get_wfrag_b(s_wf, T_2 + c * HT + ho, 1, lane);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Y[c][m] = mfma_s<true>(ah, bG[m], Y[c][m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Y[c][m] = mfma_s<true>(al, bG[m], Y[c][m]);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (t[m].valid)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) st4(y + t[m].off + 16 * c + 4 * kq, Y[c][m]);
+  }
+}
+
 
 
 // ---------------------------------------------------------------------------------------------
@@ -622,6 +1024,164 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
           gemm_tok<M, VSM>(aW1[ho][c], imgA, imgHN + c * 16 * VSM, lane);
           gemm_tok<M, VSM>(aW2[c][ho], imgDY + c * 16 * VSM, imgB, lane);
         }
+      }
+    }
+    f32x4 dH[CT][M];
+    layer_norm_bwd_tl(dHN, HN, rstd2, DY, dH);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      if (valid[m])
+#pragma unroll
+        for (int c = 0; c < CT; ++c) st4(dh + (base + 16 * m + j) * C + 16 * c + 4 * kq, dH[c][m]);
+  }
+#pragma unroll
+  for (int o = 0; o < HT; ++o) {
+    flush_vec<1>(g_fc1_b + 16 * o, pb1[o], lane);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      flush_acc(g_fc1_w + (long)(16 * o) * C + 16 * c, C, aW1[o][c], lane);
+      flush_acc(g_fc2_w + (long)(16 * c) * HID + 16 * o, HID, aW2[c][o], lane);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) flush_vec<1>(g_fc2_b + 16 * c, pb2[c], lane);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 1 on the split-bf16 MFMA path (see "Split-bf16 GEMMs" above): same algorithm, same arguments and the
+// same results to ~2e-6 relative as swin_mlp_bwd_kernel.  Per 32 tokens: 80 bf16 MFMAs (16 cycles each, overlapping the
+// VALU work) instead of 160 f32 MFMAs (32 cycles each, serialised with it) + 20 operand splits.
+// ---------------------------------------------------------------------------------------------
+template <int C, int M>
+__global__ __launch_bounds__(256, 2) void swin_mlp_bwd_b_kernel(
+    const float* __restrict__ hs, const float* __restrict__ dy, float* __restrict__ dh, const float* __restrict__ fc1_w,
+    const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float* __restrict__ g_fc1_w,
+    float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L) {
+  constexpr int CT = C / 16, HID = 4 * C, HT = HID / 16;
+  constexpr int TOK = 16 * M;
+  constexpr int IMGW = TOK * kImgRow;   // words per image (one 16-position chunk, TOK token rows)
+  __shared__ __attribute__((aligned(16))) unsigned s_img[4][(2 * CT + 2) * IMGW];
+  constexpr int F_W1 = 0, F_W2T = HT * CT, F_W1T = 2 * HT * CT, NT = 3 * HT * CT;
+  __shared__ __attribute__((aligned(16))) unsigned s_wf[NT * 2 * 256];
+  __shared__ __attribute__((aligned(16))) float s_b1[HT * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, v = b % V;
+  fc1_w += (long)v * HID * C;  fc1_b += v * HID;  fc2_w += (long)v * C * HID;
+  g_fc1_w += (long)v * HID * C;  g_fc1_b += v * HID;  g_fc2_w += (long)v * C * HID;  g_fc2_b += v * C;
+  hs += (long)b * L * C;  dy += (long)b * L * C;  dh += (long)b * L * C;
+
+  f32x4 aW1[HT][CT], aW2[CT][HT], pb1[HT], pb2[CT];
+#pragma unroll
+  for (int o = 0; o < HT; ++o) {
+    pb1[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CT; ++k) { aW1[o][k] = f32x4{0.f, 0.f, 0.f, 0.f}; aW2[k][o] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+#pragma unroll
+  for (int k = 0; k < CT; ++k) pb2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    int i = 0;
+#pragma unroll
+    for (int ho = 0; ho < HT; ++ho) {
+      if ((i++) % 4 == wave) st4(s_b1 + ho * 256 + lane * 4, vfrag<1>(fc1_b, 16 * ho, lane));
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if ((i++) % 4 == wave) put_wfrag_b<false>(s_wf, F_W1 + ho * CT + c, wfrag<false, 1, 1>(fc1_w, C, 16 * ho, 16 * c, lane), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<false>(s_wf, F_W2T + ho * CT + c, wfrag<true, 1, 1>(fc2_w, HID, 16 * ho, 16 * c, lane), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<false>(s_wf, F_W1T + c * HT + ho, wfrag<true, 1, 1>(fc1_w, C, 16 * c, 16 * ho, lane), lane);
+      }
+    }
+    __syncthreads();
+  }
+  unsigned* img = s_img[wave];
+  unsigned* imgHN = img;
+  unsigned* imgDY = img + CT * IMGW;
+  unsigned* imgA = img + 2 * CT * IMGW;      // dA1 tile
+  unsigned* imgB = imgA + IMGW;              // gelu tile
+  const long items = (L + TOK - 1) / TOK;
+
+  for (long it0 = (long)blockIdx.x * 4; it0 < items; it0 += (long)gridDim.x * 4) {
+    const long base = (it0 + wave) * TOK;
+    bool valid[M];
+    f32x4 HN[CT][M], DY[CT][M];
+    float rstd2[M];
+    {
+      f32x4 Hs[CT][M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const long tok = base + 16 * m + j;
+        valid[m] = tok < L;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          Hs[c][m] = valid[m] ? ld4(hs + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+          DY[c][m] = valid[m] ? ld4(dy + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      bool all[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) all[m] = true;
+      layer_norm_tl(Hs, HN, rstd2, all);
+    }
+    u32x4 bHN[CT][M], bDY[CT][M];
+    wave_sync();   // previous iteration's image readers are done
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const Split sh = split2<false>(HN[c][m]), sd = split2<false>(DY[c][m]);
+        bHN[c][m] = frag_b(sh);
+        bDY[c][m] = frag_b(sd);
+        put_img_b(imgHN + c * IMGW, 16 * m + j, kq, sh);
+        put_img_b(imgDY + c * IMGW, 16 * m + j, kq, sd);
+        pb2[c] += DY[c][m];
+      }
+    f32x4 dHN[CT][M];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < M; ++m) dHN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ho = 0; ho < HT; ++ho) {
+      f32x4 A1[1][M], dG[1][M];
+      const f32x4 b1 = ld4(s_b1 + ho * 256 + lane * 4);
+#pragma unroll
+      for (int m = 0; m < M; ++m) { A1[0][m] = b1; dG[0][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      mm_b<false, 1, CT, M>(A1, s_wf, F_W1 + ho * CT, bHN, lane);
+      mm_b<false, 1, CT, M>(dG, s_wf, F_W2T + ho * CT, bDY, lane);
+      Split sdg[M], sgl[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        f32x4 gl, dgl;
+        gelu_both4(A1[0][m], gl, dgl);
+        dG[0][m] *= dgl;                    // dA1
+        pb1[ho] += dG[0][m];
+        sdg[m] = split2<false>(dG[0][m]);
+        sgl[m] = split2<false>(gl);
+      }
+      // dHN += W1^T dA1 (K = this hidden block)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const u32x4 ah = get_wfrag_b(s_wf, F_W1T + c * HT + ho, 0, lane), al = get_wfrag_b(s_wf, F_W1T + c * HT + ho, 1, lane);
+#pragma unroll
+        for (int m = 0; m < M; ++m) dHN[c][m] = mfma_s<false>(ah, frag_b(sdg[m]), dHN[c][m]);
+#pragma unroll
+        for (int m = 0; m < M; ++m) dHN[c][m] = mfma_s<false>(al, frag_b(sdg[m]), dHN[c][m]);
+      }
+      // weight gradients: dW1[hid][c] += dA1 . HN^T ; dW2[c][hid] += DY . G^T  (K = tokens)
+      if (ho) wave_sync();
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        put_img_b(imgA, 16 * m + j, kq, sdg[m]);
+        put_img_b(imgB, 16 * m + j, kq, sgl[m]);
+      }
+      wave_sync();
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        gemm_tok_b<M>(aW1[ho][c], imgA, imgHN + c * IMGW, lane);
+        gemm_tok_b<M>(aW2[c][ho], imgDY + c * IMGW, imgB, lane);
       }
     }
     f32x4 dH[CT][M];
@@ -1042,6 +1602,12 @@ int make_geom(const idee_swin_geom* s, Geom& g, int& NW) {
   return IDEE_OK;
 }
 
+// IDEE_SWIN_MATH=f32 selects the exact-f32 MFMA kernels; default: the split-bf16 GEMM kernels where they exist (C = 16)
+bool split_math() {
+  const char* e = getenv("IDEE_SWIN_MATH");
+  return !(e && strcmp(e, "f32") == 0);
+}
+
 // One round of resident workgroups: gx * B <= CUs * (workgroups per CU), so that no CU is left with a
 // lone straggler round (work items are uniform; every workgroup loops over its share).
 dim3 swin_grid(int items_per_wg_loop, int B, int wg_per_cu) {
@@ -1067,9 +1633,17 @@ extern "C" int idee_swin_block_fwd(const float* x, float* y, float* h_save, cons
   Geom g; int NW;
   if (int rc = make_geom(s, g, NW)) return rc;
   const int C = s->C, NH = s->heads, B = s->N * s->V;
-  const dim3 grid = swin_grid(cdiv(g.items, 4), B, C == 16 ? 2 : 1);
+  const bool split = split_math();
+  const dim3 grid = swin_grid(cdiv(g.items, 4), B, C == 16 ? (split ? 3 : 2) : 1);
 #define CALL(C_, NH_, NW_)                                                                                   \
-  if (h_save)                                                                                                \
+  if (C_ == 16 && split) {                                                                                   \
+    if (h_save)                                                                                              \
+      hipLaunchKernelGGL((swin_fwd_b_kernel<C_ == 16 ? C_ : 16, NH_, NW_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
+                         p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
+    else                                                                                                     \
+      hipLaunchKernelGGL((swin_fwd_b_kernel<C_ == 16 ? C_ : 16, NH_, NW_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
+                         p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
+  } else if (h_save)                                                                                         \
     hipLaunchKernelGGL((swin_fwd_mfma_kernel<C_, NH_, NW_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
                        p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
   else                                                                                                       \
@@ -1091,7 +1665,11 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
   const long L = (long)s->D * s->H * s->W;
   hipStream_t st = (hipStream_t)stream;
   {   // part 1: MLP + norm2 (token order)
-    if (C == 16) {   // 32 tokens per wave: half the live registers -> two waves per SIMD overlap GELU with the MFMA chains
+    if (C == 16 && split_math()) {
+      const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 2);
+      hipLaunchKernelGGL((swin_mlp_bwd_b_kernel<16, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
+                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
+    } else if (C == 16) {   // 32 tokens per wave: half the live registers -> two waves per SIMD overlap GELU with the MFMA chains
       const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 2);
       hipLaunchKernelGGL((swin_mlp_bwd_kernel<16, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
                          p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
