@@ -1558,6 +1558,398 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 2 on the split-bf16 MFMA path: same algorithm, arguments and results (to ~1e-5 relative, gradients are
+// compared at 1e-3) as swin_attn_bwd_kernel.  Only the K = 8 score products S = K Q^T and dP = V dO^T stay on the f32 MFMA
+// (operands already in registers); the linear layers, O / dQ / dK / dV and the five token-reduction GEMMs run as piece
+// products.  Q, K, V, dO (and later dH, O, XN, dQ, dK, dV) live in LDS as token-major bf16 piece images; the
+// [channel][token] and the transposed P^T / dS^T operands come out of them with ds_read_b64_tr_b16.
+// ---------------------------------------------------------------------------------------------
+// D tile (rows 4kq+r, col j) -> dst[(row0 + HR(4kq + r)) * ld + col0 + HC(j)]: the piece images keep TL positions, so the head
+// permutation of q/k/v/O channels is undone here
+template <int HR, int HC>
+__device__ __forceinline__ void flush_acc_perm(float* dst, int ld, const f32x4& acc, int lane, float mul = 1.f) {
+  const int j = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) atomicAdd(dst + (long)sig<HR>(r0 + r) * ld + sig<HC>(j), mul * acc[r]);
+}
+__device__ __forceinline__ u32x4 dup2(unsigned long long a) { return u32x4{(unsigned)a, (unsigned)(a >> 32), (unsigned)a, (unsigned)(a >> 32)}; }
+
+template <int C, int NH, int NW, int WPB, int MTK>
+__global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
+    const float* __restrict__ x, const float* __restrict__ dh, float* __restrict__ dx, const float* __restrict__ qkv_w,
+    const float* __restrict__ qkv_b, const float* __restrict__ proj_w, const float* __restrict__ rel_bias,
+    float* __restrict__ g_qkv_w, float* __restrict__ g_qkv_b, float* __restrict__ g_proj_w, float* __restrict__ g_proj_b,
+    float* __restrict__ g_rel_bias, Geom g) {
+  constexpr int CT = C / 16, HD = C / NH;
+  static_assert(C % 16 == 0 && HD <= 16 && 16 % HD == 0, "head_dim must divide 16");
+  constexpr int HPC = 16 / HD, SP = 4 / HPC;
+  constexpr int TPW = NW >= 16 ? NW / 16 : 1, NG = MTK / TPW;
+  static_assert(MTK % TPW == 0 && NG >= 1, "a work item holds whole windows");
+  constexpr int IMGW = 16 * MTK * kImgRow;      // words per piece image of one 16-position chunk
+  constexpr int TILEW = 16 * kImgRow;           // words per 16 x 16 scratch tile
+  // per wave: [0,CT) K  [CT,2CT) Q  [2CT,3CT) V  [3CT,4CT) dO, then two scratch tiles
+  __shared__ __attribute__((aligned(16))) unsigned s_img[WPB][4 * CT * IMGW + 2 * TILEW];
+  __shared__ __attribute__((aligned(16))) int s_rid[WPB][16 * MTK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, v = b % g.V;
+  qkv_w += (long)v * 3 * C * C;  qkv_b += v * 3 * C;  proj_w += (long)v * C * C;
+  rel_bias += (long)v * NH * NW * NW;
+  g_qkv_w += (long)v * 3 * C * C;  g_qkv_b += v * 3 * C;  g_proj_w += (long)v * C * C;  g_proj_b += v * C;
+  g_rel_bias += (long)v * NH * NW * NW;
+
+  constexpr int NRB = NH * TPW * TPW;
+  constexpr int W_Q = 0, W_QT = 3 * CT * CT, W_PT = 6 * CT * CT, NWT = 7 * CT * CT;
+  __shared__ __attribute__((aligned(16))) float s_rb[NRB * 256];
+  __shared__ __attribute__((aligned(16))) unsigned s_wf[NWT * 2 * 256];
+  __shared__ __attribute__((aligned(16))) float s_bq[3 * CT * 256];
+  {
+    int i = 0;
+#pragma unroll
+    for (int o = 0; o < 3 * CT; ++o) {
+      const float mul = o < CT ? g.scale : 1.f;
+      if ((i++) % WPB == wave) st4(s_bq + o * 256 + lane * 4, vfrag<HPC>(qkv_b, 16 * o, lane, mul));
+#pragma unroll
+      for (int k = 0; k < CT; ++k) {
+        if ((i++) % WPB == wave) put_wfrag_b<false>(s_wf, W_Q + o * CT + k, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul), lane);
+        // [c][o] = qkv_w[o][c] (q rows carry the scale)
+        if ((i++) % WPB == wave) put_wfrag_b<false>(s_wf, W_QT + k * 3 * CT + o, wfrag<true, 1, HPC>(qkv_w, C, 16 * k, 16 * o, lane, mul), lane);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < CT; ++o)
+#pragma unroll
+      for (int k = 0; k < CT; ++k)   // [c'][c] = proj_w[c][c']
+        if ((i++) % WPB == wave) put_wfrag_b<false>(s_wf, W_PT + o * CT + k, wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane), lane);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt) {
+          if ((i++) % WPB != wave) continue;
+          f32x4 f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
+            f[r] = (key / NW) == (qry / NW) ? rel_bias[(h * NW + qry % NW) * NW + key % NW] : -1e30f;
+          }
+          st4(s_rb + ((h * TPW + kt) * TPW + qt) * 256 + lane * 4, f);
+        }
+    __syncthreads();
+  }
+  auto RB = [&](int h, int kt, int qt) { return ld4(s_rb + ((h * TPW + kt) * TPW + qt) * 256 + lane * 4); };
+  f32x4 dB[NH][TPW][TPW];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < TPW; ++qt) dB[h][kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 aWq[3 * CT][CT], aWp[CT][CT], pbq[3 * CT], pbp[CT];
+#pragma unroll
+  for (int o = 0; o < 3 * CT; ++o) {
+    pbq[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CT; ++k) aWq[o][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int o = 0; o < CT; ++o) {
+    pbp[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CT; ++k) aWp[o][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  unsigned* img = s_img[wave];
+  unsigned* imgK = img;
+  unsigned* imgQ = img + CT * IMGW;
+  unsigned* imgV = img + 2 * CT * IMGW;
+  unsigned* imgDO = img + 3 * CT * IMGW;
+  unsigned* tileP = img + 4 * CT * IMGW;
+  unsigned* tileS = tileP + TILEW;
+  int* rid_l = s_rid[wave];
+
+  for (int it0 = blockIdx.x * WPB; it0 < g.items; it0 += gridDim.x * WPB) {
+    Tok t[MTK];
+    bool keep[MTK];
+    f32x4 X[CT][MTK], DH[CT][MTK];
+#pragma unroll
+    for (int m = 0; m < MTK; ++m) {
+      t[m] = locate<NW, 16 * MTK>(g, b, it0 + wave, 16 * m + j, C);
+      keep[m] = t[m].valid;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        X[c][m] = t[m].valid ? ld4(x + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        DH[c][m] = t[m].valid ? ld4(dh + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    f32x4 XN[CT][MTK];
+    float rstd[MTK];
+    layer_norm_tl(X, XN, rstd, keep);
+    Split sXN[CT][MTK], sDH[CT][MTK];
+    f32x4 QKV[3 * CT][MTK], DO[CT][MTK];
+    {
+      u32x4 bXN[CT][MTK], bDH[CT][MTK];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int m = 0; m < MTK; ++m) {
+          sXN[c][m] = split2<false>(XN[c][m]);
+          sDH[c][m] = split2<false>(DH[c][m]);
+          bXN[c][m] = frag_b(sXN[c][m]);
+          bDH[c][m] = frag_b(sDH[c][m]);
+          DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          pbp[c] += DH[c][m];
+        }
+#pragma unroll
+      for (int o = 0; o < 3 * CT; ++o) {
+        const f32x4 bqo = ld4(s_bq + o * 256 + lane * 4);
+#pragma unroll
+        for (int m = 0; m < MTK; ++m) QKV[o][m] = bqo;
+      }
+      mm_b<false, 3 * CT, CT, MTK>(QKV, s_wf, W_Q, bXN, lane);
+      mm_b<false, CT, CT, MTK>(DO, s_wf, W_PT, bDH, lane);       // dO = proj_w^T dH
+    }
+    wave_sync();   // previous iteration's image readers are done
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MTK; ++m) {
+        put_img_b(imgQ + c * IMGW, 16 * m + j, kq, split2<false>(QKV[c][m]));
+        put_img_b(imgK + c * IMGW, 16 * m + j, kq, split2<false>(QKV[CT + c][m]));
+        put_img_b(imgV + c * IMGW, 16 * m + j, kq, split2<false>(QKV[2 * CT + c][m]));
+        put_img_b(imgDO + c * IMGW, 16 * m + j, kq, split2<false>(DO[c][m]));
+      }
+    if (kq == 0)
+#pragma unroll
+      for (int m = 0; m < MTK; ++m) rid_l[16 * m + j] = t[m].rid;
+    wave_sync();
+
+    f32x4 O[CT][MTK], DQ[CT][MTK], DK[CT][MTK], DV[CT][MTK];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int c = h / HPC, s0 = (h % HPC) * SP;
+        // ---- row pass: S, P, dP with keys on rows, query on the column (f32 MFMA, K = head_dim) ----
+        f32x4 P[TPW][TPW], dP[TPW][TPW];
+#pragma unroll
+        for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) { P[kt][qt] = RB(h, kt, qt); dP[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < SP; ++s)
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt) {
+              P[kt][qt] = MFMA(QKV[CT + c][grp * TPW + kt][s0 + s], QKV[c][grp * TPW + qt][s0 + s], P[kt][qt]);
+              dP[kt][qt] = MFMA(QKV[2 * CT + c][grp * TPW + kt][s0 + s], DO[c][grp * TPW + qt][s0 + s], dP[kt][qt]);
+            }
+        if (g.shifted) {
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const int4 rk = *reinterpret_cast<const int4*>(rid_l + 16 * (grp * TPW + kt) + 4 * kq);
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt) {
+              const int rq = t[grp * TPW + qt].rid;
+              P[kt][qt][0] += rk.x != rq ? -100.f : 0.f; P[kt][qt][1] += rk.y != rq ? -100.f : 0.f;
+              P[kt][qt][2] += rk.z != rq ? -100.f : 0.f; P[kt][qt][3] += rk.w != rq ? -100.f : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int qt = 0; qt < TPW; ++qt) {
+          float mx = -3.0e38f;
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(P[kt][qt][0], P[kt][qt][1]), fmaxf(P[kt][qt][2], P[kt][qt][3])));
+          mx = chan_max(mx);
+          const float mxl = -mx * kLog2e;
+          f32x4 l4 = splat(0.f);
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const f32x4 ea = fma4(P[kt][qt], splat(kLog2e), splat(mxl));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[kt][qt][r] = __builtin_amdgcn_exp2f(ea[r]);
+            l4 += P[kt][qt];
+          }
+          const float inv = __builtin_amdgcn_rcpf(chan_sum(hsum(l4)));
+          f32x4 D4 = splat(0.f);
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            P[kt][qt] *= inv;
+            D4 = fma4(P[kt][qt], dP[kt][qt], D4);
+          }
+          const float D = chan_sum(hsum(D4));
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            dP[kt][qt] = P[kt][qt] * (dP[kt][qt] - splat(D));   // dS
+            dB[h][kt][qt] += dP[kt][qt];
+          }
+        }
+        Split sP[TPW][TPW], sS[TPW][TPW];
+#pragma unroll
+        for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) { sP[kt][qt] = split2<false>(P[kt][qt]); sS[kt][qt] = split2<false>(dP[kt][qt]); }
+        // O[chan][query] = sum_keys V^T P ; dQ[chan][query] = sum_keys K^T dS : A from the V / K piece images (transposed read)
+        {
+          f32x4 acco[TPW], accq[TPW];
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) { acco[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; accq[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) {
+            const int mk = grp * TPW + kt;
+            const u32x4 vh = dup2(tr_read(imgV + c * IMGW, mk, 0, lane)), vl = dup2(tr_read(imgV + c * IMGW, mk, 1, lane));
+            const u32x4 kh = dup2(tr_read(imgK + c * IMGW, mk, 0, lane)), kl = dup2(tr_read(imgK + c * IMGW, mk, 1, lane));
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt) {
+              acco[qt] = mfma_s<false>(vh, frag_b(sP[kt][qt]), acco[qt]);
+              accq[qt] = mfma_s<false>(kh, frag_b(sS[kt][qt]), accq[qt]);
+            }
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt) {
+              acco[qt] = mfma_s<false>(vl, frag_b(sP[kt][qt]), acco[qt]);
+              accq[qt] = mfma_s<false>(kl, frag_b(sS[kt][qt]), accq[qt]);
+            }
+          }
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+            for (int r = 0; r < SP; ++r) { O[c][grp * TPW + qt][s0 + r] = acco[qt][s0 + r]; DQ[c][grp * TPW + qt][s0 + r] = accq[qt][s0 + r]; }
+        }
+        // ---- column pass: dK[chan][key] = sum_queries Q^T dS^T ; dV[chan][key] = sum_queries dO^T P^T.  The transposed B
+        // operands are the row-pass tiles' pieces written query-major to a scratch tile and read back with the transposing
+        // LDS read: two 8-byte writes and two reads per tile and tensor
+        {
+          f32x4 acck[TPW], accv[TPW];
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt) { acck[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int qt = 0; qt < TPW; ++qt) {
+            const int mq = grp * TPW + qt;
+            const u32x4 qh = dup2(tr_read(imgQ + c * IMGW, mq, 0, lane)), ql = dup2(tr_read(imgQ + c * IMGW, mq, 1, lane));
+            const u32x4 dh_ = dup2(tr_read(imgDO + c * IMGW, mq, 0, lane)), dl_ = dup2(tr_read(imgDO + c * IMGW, mq, 1, lane));
+#pragma unroll
+            for (int kt = 0; kt < TPW; ++kt) {
+              wave_sync();   // the previous tile's readers are done
+              put_img_b(tileP, j, kq, sP[kt][qt]);      // rows = queries, positions = keys
+              put_img_b(tileS, j, kq, sS[kt][qt]);
+              wave_sync();
+              const unsigned long long ph = tr_read(tileP, 0, 0, lane), pl = tr_read(tileP, 0, 1, lane);
+              const unsigned long long sh = tr_read(tileS, 0, 0, lane), sl = tr_read(tileS, 0, 1, lane);
+              const u32x4 PT = {(unsigned)ph, (unsigned)(ph >> 32), (unsigned)pl, (unsigned)(pl >> 32)};
+              const u32x4 ST = {(unsigned)sh, (unsigned)(sh >> 32), (unsigned)sl, (unsigned)(sl >> 32)};
+              acck[kt] = mfma_s<false>(qh, ST, acck[kt]);
+              accv[kt] = mfma_s<false>(dh_, PT, accv[kt]);
+              acck[kt] = mfma_s<false>(ql, ST, acck[kt]);
+              accv[kt] = mfma_s<false>(dl_, PT, accv[kt]);
+            }
+          }
+#pragma unroll
+          for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+            for (int r = 0; r < SP; ++r) { DK[c][grp * TPW + kt][s0 + r] = acck[kt][s0 + r]; DV[c][grp * TPW + kt][s0 + r] = accv[kt][s0 + r]; }
+        }
+      }
+    }
+    // ---- dxn = Wqkv^T dQKV, norm1 backward ----
+    Split sDQ[CT][MTK], sDK[CT][MTK], sDV[CT][MTK], sO[CT][MTK];
+    f32x4 dXN[CT][MTK];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MTK; ++m) {
+        dXN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the q gradient refers to the pre-scaled q: the scale is folded into wqt (above) and into dWq / dbq at the flush
+        pbq[c] += DQ[c][m]; pbq[CT + c] += DK[c][m]; pbq[2 * CT + c] += DV[c][m];
+        sDQ[c][m] = split2<false>(DQ[c][m]); sDK[c][m] = split2<false>(DK[c][m]); sDV[c][m] = split2<false>(DV[c][m]);
+        sO[c][m] = split2<false>(O[c][m]);
+      }
+#pragma unroll
+    for (int oc = 0; oc < CT; ++oc)
+#pragma unroll
+      for (int k = 0; k < CT; ++k)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          const u32x4 wa = get_wfrag_b(s_wf, W_QT + oc * 3 * CT + k, pc, lane), wb = get_wfrag_b(s_wf, W_QT + oc * 3 * CT + CT + k, pc, lane),
+                      wc = get_wfrag_b(s_wf, W_QT + oc * 3 * CT + 2 * CT + k, pc, lane);
+#pragma unroll
+          for (int m = 0; m < MTK; ++m) dXN[oc][m] = mfma_s<false>(wa, frag_b(sDQ[k][m]), dXN[oc][m]);
+#pragma unroll
+          for (int m = 0; m < MTK; ++m) dXN[oc][m] = mfma_s<false>(wb, frag_b(sDK[k][m]), dXN[oc][m]);
+#pragma unroll
+          for (int m = 0; m < MTK; ++m) dXN[oc][m] = mfma_s<false>(wc, frag_b(sDV[k][m]), dXN[oc][m]);
+        }
+    f32x4 DX[CT][MTK];
+    layer_norm_bwd_tl(dXN, XN, rstd, DH, DX);
+#pragma unroll
+    for (int m = 0; m < MTK; ++m)
+      if (t[m].valid)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) st4(dx + t[m].off + 16 * c + 4 * kq, DX[c][m]);
+
+    // ---- token-reduction GEMMs (weight gradients) from piece images that reuse the Q / K / V / dO slots ----
+    // dproj_w[c][c'] += dH[c] O[c'] ; dqkv_w[o][c] += dQKV[o] XN[c] ; K = tokens
+    unsigned* imgDH = imgQ;   // CT chunks each
+    unsigned* imgO = imgK;
+    unsigned* imgXN = imgV;
+    unsigned* imgG = imgDO;   // one dQKV chunk at a time
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MTK; ++m) {
+        put_img_b(imgDH + c * IMGW, 16 * m + j, kq, sDH[c][m]);
+        put_img_b(imgO + c * IMGW, 16 * m + j, kq, sO[c][m]);
+        put_img_b(imgXN + c * IMGW, 16 * m + j, kq, sXN[c][m]);
+      }
+    wave_sync();
+#pragma unroll
+    for (int ca = 0; ca < CT; ++ca)
+#pragma unroll
+      for (int cb = 0; cb < CT; ++cb) gemm_tok_b<MTK>(aWp[ca][cb], imgDH + ca * IMGW, imgO + cb * IMGW, lane);
+#pragma unroll
+    for (int o = 0; o < 3 * CT; ++o) {
+      if (o) wave_sync();
+#pragma unroll
+      for (int m = 0; m < MTK; ++m)
+        put_img_b(imgG, 16 * m + j, kq, o < CT ? sDQ[o][m] : o < 2 * CT ? sDK[o - CT][m] : sDV[o - 2 * CT][m]);
+      wave_sync();
+#pragma unroll
+      for (int cb = 0; cb < CT; ++cb) gemm_tok_b<MTK>(aWq[o][cb], imgG, imgXN + cb * IMGW, lane);
+    }
+  }
+
+  // ---- flush (image positions -> channels: the q/k/v/O chunks carry the head permutation) ----
+#pragma unroll
+  for (int o = 0; o < 3 * CT; ++o) {
+    const float mul = o < CT ? g.scale : 1.f;
+    flush_vec<HPC>(g_qkv_b + 16 * o, pbq[o] * mul, lane);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) flush_acc_perm<HPC, 1>(g_qkv_w + (long)(16 * o) * C + 16 * k, C, aWq[o][k], lane, mul);
+  }
+#pragma unroll
+  for (int o = 0; o < CT; ++o) {
+    flush_vec<1>(g_proj_b + 16 * o, pbp[o], lane);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) flush_acc_perm<1, HPC>(g_proj_w + (long)(16 * o) * C + 16 * k, C, aWp[o][k], lane);
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * kq + r, qry = 16 * qt + j;
+          if ((key / NW) == (qry / NW)) atomicAdd(g_rel_bias + (h * NW + qry % NW) * NW + key % NW, dB[h][kt][qt][r]);
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // relative-position bias: table (V, L, NH) gathered through index (NW, NW) -> dense (V, NH, NW, NW)
 // (Swin_3D.py:158-162) and its scatter-add backward.
@@ -1684,10 +2076,16 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
   // per lane, so two waves share a SIMD and one's LDS / global latency hides under the other's MFMA chain.
   // C = 32: 64 tokens per wave, 2 waves (48 KB of images each).
   const int WPB = C == 16 ? 8 : 2, MTK = C == 16 ? 2 : 4;
+  const bool split = split_math();
   Geom ga = g;
   ga.items = cdiv(g.nWin, (16 * MTK) / NW);
   const dim3 grid = swin_grid(cdiv(ga.items, WPB), B, 1);
 #define CALL(C_, NH_, NW_)                                                                                           \
+  if (C_ == 16 && split)                                                                                             \
+    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<16, NH_, NW_, 8, 2>), grid, dim3(512), 0, st, x,                      \
+                       dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,  \
+                       d->proj_b, d->rel_bias, ga);                                                                  \
+  else                                                                                                               \
   hipLaunchKernelGGL((swin_attn_bwd_kernel<C_, NH_, NW_, (C_ == 16 ? 8 : 2), (C_ == 16 ? 2 : 4)>), grid,             \
                      dim3(64 * (C_ == 16 ? 8 : 2)), 0, st, x,                                                        \
                      dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,    \
