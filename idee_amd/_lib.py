@@ -45,6 +45,8 @@ _SIGS = {
     "idee_check_device": (_I, [_I]),
     "idee_patch_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
     "idee_patch_embed_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "idee_stage_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "idee_stage_embed_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
     "idee_swin_block_fwd": (_I, [_P, _P, _P, C.POINTER(SwinParams), C.POINTER(SwinGeom), _P]),
     "idee_swin_block_bwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(SwinParams), C.POINTER(SwinGrads), C.POINTER(SwinGeom), _P]),
     "idee_relpos_bias_gather": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
@@ -71,6 +73,10 @@ _SIGS = {
     "idee_vq_workspace_floats": (_L, [_L]),
     "idee_vq_nn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     "idee_vq_nn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
+    "idee_vq_cluster_stats": (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    "idee_vq_ema_update": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P]),
+    "idee_vq_kmeans_update": (_I, [_P, _P, _P, _I, _I, _P]),
+    "idee_vq_expire_codes": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P]),
     "idee_bce_class_counts": (_I, [_P, _P, _L, _P, _P]),
     "idee_bce_workspace_floats": (_L, [_I, _L]),
     "idee_bce_weighted_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P]),

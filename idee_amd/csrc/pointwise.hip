@@ -172,6 +172,130 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Stage embedding of a hierarchical Swin encoder: PatchEmbed3D with patch (1,1,1) between two stages of different width
+// (BasicLayer builds it when in_dim != dim, Swin_3D.py:414-419; forward :473-491): y = LN_noaffine(W x + b) per token,
+// input ALREADY channels-last tokens (B, L, CIN), CIN a multiple of 16.  Backward also returns dx.
+// E/4 adjacent lanes per token, 4 output channels each; the token's CIN inputs are read by all of them (broadcast loads).
+// -------------------------------------------------------------------------------------------
+template <int E, int CIN>
+__global__ __launch_bounds__(256) void stage_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int V, long L) {
+  constexpr int QE = E / 4;
+  const int b = blockIdx.y, v = b % V;
+  const float* wv = w + (long)v * E * CIN;
+  const float* xb = x + (long)b * L * CIN;
+  float* yb = y + (long)b * L * E;
+  const int q = threadIdx.x % QE;
+  f32x4 wl[4][CIN / 4];
+  float bl[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bl[k] = bias ? bias[v * E + 4 * q + k] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN / 4; ++c) wl[k][c] = ld4(wv + (4 * q + k) * CIN + 4 * c);
+  }
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    float e[4] = {bl[0], bl[1], bl[2], bl[3]};
+#pragma unroll
+    for (int c = 0; c < CIN / 4; ++c) {
+      const f32x4 xi = ld4(xb + tok * CIN + 4 * c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] += (wl[k][c][0] * xi[0] + wl[k][c][1] * xi[1]) + (wl[k][c][2] * xi[2] + wl[k][c][3] * xi[3]);
+    }
+    const float mean = tok_sum<QE>(e[0] + e[1] + e[2] + e[3]) * (1.f / E);
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+    st4(yb + tok * E + 4 * q, f32x4{(e[0] - mean) * rstd, (e[1] - mean) * rstd, (e[2] - mean) * rstd, (e[3] - mean) * rstd});
+  }
+}
+
+template <int E, int CIN>
+__global__ __launch_bounds__(256) void stage_embed_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, float* __restrict__ dw,
+                                                              float* __restrict__ db, int V, long L) {
+  constexpr int QE = E / 4, CQ = CIN / 4;
+  static_assert(CQ % QE == 0 || QE % CQ == 0, "lane <-> input-channel-quad map");
+  const int b = blockIdx.y, v = b % V;
+  const float* wv = w + (long)v * E * CIN;
+  const float* xb = x + (long)b * L * CIN;
+  const float* dyb = dy + (long)b * L * E;
+  float* dxb = dx + (long)b * L * CIN;
+  const int q = threadIdx.x % QE;
+  f32x4 wl[4][CQ], gw[4][CQ];
+  float bl[4], gb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bl[k] = bias ? bias[v * E + 4 * q + k] : 0.f;
+    gb[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) { wl[k][c] = ld4(wv + (4 * q + k) * CIN + 4 * c); gw[k][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  const long total = L * QE;
+  // every lane of a token group runs the same trip count (the group reductions below need all QE lanes)
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const f32x4 g = ld4(dyb + tok * E + 4 * q);
+    f32x4 xi[CQ];
+    float e[4] = {bl[0], bl[1], bl[2], bl[3]};
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      xi[c] = ld4(xb + tok * CIN + 4 * c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] += (wl[k][c][0] * xi[c][0] + wl[k][c][1] * xi[c][1]) + (wl[k][c][2] * xi[c][2] + wl[k][c][3] * xi[c][3]);
+    }
+    const float mean = tok_sum<QE>(e[0] + e[1] + e[2] + e[3]) * (1.f / E);
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { e[k] = (e[k] - mean) * rstd; s1 += g[k]; s2 = fmaf(g[k], e[k], s2); }
+    s1 = tok_sum<QE>(s1) * (1.f / E); s2 = tok_sum<QE>(s2) * (1.f / E);
+    float de[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      de[k] = rstd * (g[k] - s1 - e[k] * s2);
+      gb[k] += de[k];
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) gw[k][c] += xi[c] * de[k];
+    }
+    // dx[c] = sum_e W[e][c] de[e]: this lane's 4 rows first, then across the QE lanes of the token; lane q keeps quads
+    // c with c % QE == q (CQ >= QE) or lane q < CQ keeps quad q (CQ < QE)
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      f32x4 pc = wl[0][c] * de[0] + wl[1][c] * de[1] + wl[2][c] * de[2] + wl[3][c] * de[3];
+      pc[0] = tok_sum<QE>(pc[0]); pc[1] = tok_sum<QE>(pc[1]); pc[2] = tok_sum<QE>(pc[2]); pc[3] = tok_sum<QE>(pc[3]);
+      if (c % QE == q) st4(dxb + tok * CIN + 4 * c, pc);
+    }
+  }
+  auto same_q_sum = [](float val) {
+#pragma unroll
+    for (int o = QE; o < 64; o <<= 1) val += __shfl_xor(val, o, 64);
+    return val;
+  };
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float sb = same_q_sum(gb[k]);
+    if (lane < QE && db) atomicAdd(db + v * E + 4 * q + k, sb);
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sw = same_q_sum(gw[k][c][r]);
+        if (lane < QE) atomicAdd(dw + ((long)v * E + 4 * q + k) * CIN + 4 * c + r, sw);
+      }
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 // LFQ (models/codebook/LFQ.py:183-307), projections on, D = log2(codebook_size) code bits.
 // tokens: z (M, E) -> z_q (M, E), indices int64 (M).  Training adds the aux-loss sums.
@@ -746,6 +870,95 @@ __global__ __launch_bounds__(256) void vq_nn_bwd_kernel(const float* __restrict_
   for (int i = threadIdx.x; i < K * E; i += 256) atomicAdd(dembed + i, s_g[i]);
 }
 
+
+// -------------------------------------------------------------------------------------------
+// EuclideanCodebook's EMA path (models/codebook/VQ.py:519-545), k-means initialisation (:213-253, :354-377) and dead-code
+// expiry (:449-475).  The per-token reductions (cluster sizes, per-code sums of the tokens) are the only heavy part:
+// block-level accumulation in LDS, one atomic flush per block; everything else works on (K, E) and runs in one workgroup.
+// -------------------------------------------------------------------------------------------
+// counts[k] += #{tok : idx = k} ; sums[k][:] += sum_{idx = k} x[tok][:]        (embed_onehot.sum / einsum 'h n d, h n c -> h c d')
+template <int E>
+__global__ __launch_bounds__(256) void vq_cluster_stats_kernel(const float* __restrict__ x, const long long* __restrict__ indices,
+                                                               float* __restrict__ counts, float* __restrict__ sums, long M, int K) {
+  constexpr int QE = E / 4;
+  __shared__ float s_s[kVqMaxFloats];
+  __shared__ float s_c[kVqMaxFloats / E];
+  for (int i = threadIdx.x; i < K * E; i += 256) s_s[i] = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) s_c[i] = 0.f;
+  __syncthreads();
+  const int qq = threadIdx.x % QE;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const int k = (int)indices[tok];
+    const f32x4 xv = ld4(x + tok * E + 4 * qq);
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) atomicAdd(&s_s[k * E + 4 * qq + uu], xv[uu]);
+    if (qq == 0) atomicAdd(&s_c[k], 1.f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * E; i += 256) if (s_s[i] != 0.f) atomicAdd(sums + i, s_s[i]);
+  for (int i = threadIdx.x; i < K; i += 256) if (s_c[i] != 0.f) atomicAdd(counts + i, s_c[i]);
+}
+
+// ema_inplace on cluster_size and embed_avg (lerp with 1 - decay, :56-62), Laplace smoothing (:126-128), embed = embed_avg /
+// smoothed size (:539-543).  One workgroup.
+__global__ __launch_bounds__(256) void vq_ema_update_kernel(float* __restrict__ cluster_size, float* __restrict__ embed_avg,
+                                                            float* __restrict__ embed, const float* __restrict__ new_size,
+                                                            const float* __restrict__ new_sum, int K, int E, float decay, float eps) {
+  __shared__ float s_red[256];
+  const float w = 1.f - decay;
+  float part = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float c = cluster_size[k], cs = c + w * (new_size[k] - c);        // torch.lerp: start + weight * (end - start), weight < 0.5
+    cluster_size[k] = cs;
+    part += cs;
+  }
+  s_red[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o]; __syncthreads(); }
+  const float total = s_red[0];
+  for (int i = threadIdx.x; i < K * E; i += 256) {
+    const int k = i / E;
+    const float a = embed_avg[i], av = a + w * (new_sum[i] - a);
+    embed_avg[i] = av;
+    const float smoothed = (cluster_size[k] + eps) / (total + K * eps) * total;
+    embed[i] = av / smoothed;
+  }
+}
+
+// one k-means step (:231-251): means = bins == 0 ? means : sums / bins
+__global__ void vq_kmeans_update_kernel(float* __restrict__ means, const float* __restrict__ bins, const float* __restrict__ sums,
+                                        int K, int E) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K * E; i += gridDim.x * blockDim.x) {
+    const float n = bins[i / E];
+    if (n != 0.f) means[i] = sums[i] / n;
+  }
+}
+
+// expire_codes_ / replace (:449-475): the r-th code whose EMA cluster size is below the threshold takes the r-th candidate
+// sample; its cluster size is reset and embed_avg = sample * reset.  One workgroup (the rank is a prefix count over K).
+__global__ __launch_bounds__(256) void vq_expire_kernel(float* __restrict__ embed, float* __restrict__ cluster_size,
+                                                        float* __restrict__ embed_avg, const float* __restrict__ x,
+                                                        const long long* __restrict__ cand, int K, int E, float threshold,
+                                                        float reset, int* __restrict__ n_expired) {
+  __shared__ int s_rank[kVqMaxFloats / 16];
+  if (threadIdx.x == 0) {
+    int r = 0;
+    for (int k = 0; k < K; ++k) { const bool dead = cluster_size[k] < threshold; s_rank[k] = dead ? r : -1; r += dead; }
+    if (n_expired) *n_expired = r;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * E; i += 256) {
+    const int k = i / E, r = s_rank[k];
+    if (r < 0) continue;
+    const float v = x[cand[r] * E + (i - k * E)];
+    embed[i] = v;
+    embed_avg[i] = v * reset;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256) if (s_rank[k] >= 0) cluster_size[k] = reset;
+}
+
 // -------------------------------------------------------------------------------------------
 // Device-side bookkeeping of the training drivers (utils/utils_train.py): confusion counts of the thresholded
 // prediction (evaluator :175-267, evaluator_synthetic :269-348) and the majority-vote anomaly collector (:529-554),
@@ -1101,6 +1314,35 @@ extern "C" int idee_patch_embed_ln_bwd(const float* x, const float* w, const flo
   return IDEE_OK;
 }
 
+
+#define SE_DISPATCH(CALL)                                                                      \
+  if (E == 32 && Cin == 16) { CALL(32, 16); } else if (E == 16 && Cin == 32) { CALL(16, 32); } \
+  else if (E == 16 && Cin == 16) { CALL(16, 16); } else if (E == 32 && Cin == 32) { CALL(32, 32); } \
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "stage_embed_ln: (E=%d, Cin=%d) not built (widths 16 and 32)", E, Cin);
+
+extern "C" int idee_stage_embed_ln_fwd(const float* x, const float* w, const float* b, float* y, int B, int V, int Cin, long L,
+                                       int E, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && w && y && B > 0 && V > 0 && L > 0 && B % V == 0, "stage_embed_ln_fwd: bad argument");
+  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, (long)B)), B);
+#define SE(E_, C_) hipLaunchKernelGGL((stage_embed_fwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, V, L)
+  SE_DISPATCH(SE)
+#undef SE
+  IDEE_LAUNCH_CHECK("stage_embed_ln_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_stage_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dx, float* dw,
+                                       float* db, int B, int V, int Cin, long L, int E, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && w && dy && dx && dw && B > 0 && V > 0 && L > 0 && B % V == 0, "stage_embed_ln_bwd: bad argument");
+  // whole token groups per trip: the grid stride (gridDim.x * 256 lanes) is a multiple of E/4
+  const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 4, (long)B)), B);
+#define SE(E_, C_) hipLaunchKernelGGL((stage_embed_bwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, dy, dx, dw, db, V, L)
+  SE_DISPATCH(SE)
+#undef SE
+  IDEE_LAUNCH_CHECK("stage_embed_ln_bwd");
+  return IDEE_OK;
+}
+
 extern "C" long idee_lfq_workspace_floats(long M, int codebook_size) {
   return (long)stream_grid(M * 4) * (2 + codebook_size);
 }
@@ -1275,6 +1517,46 @@ extern "C" int idee_vq_nn_bwd(const float* x, const float* embed, const int64_t*
   else if (E == 32) hipLaunchKernelGGL((vq_nn_bwd_kernel<32>), dim3(nb), dim3(256), 0, st, x, embed, (const long long*)indices, dq, gloss, dx, dembed, M, K, w_commit);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "vq_nn: dim %d not built", E);
   IDEE_LAUNCH_CHECK("vq_nn_bwd");
+  return IDEE_OK;
+}
+
+
+extern "C" int idee_vq_cluster_stats(const float* x, const int64_t* indices, float* counts, float* sums, long M, int E, int K,
+                                     idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && indices && counts && sums && M > 0 && K > 0, "vq_cluster_stats: bad argument");
+  if ((long)K * E > kVqMaxFloats) return idee::fail(IDEE_ERR_UNSUPPORTED, "vq: codebook %d x %d exceeds %d floats", K, E, kVqMaxFloats);
+  const int nb = imin(cdiv(M * (E / 4), 256), kCUs * 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 16) hipLaunchKernelGGL((vq_cluster_stats_kernel<16>), dim3(nb), dim3(256), 0, st, x, (const long long*)indices, counts, sums, M, K);
+  else if (E == 32) hipLaunchKernelGGL((vq_cluster_stats_kernel<32>), dim3(nb), dim3(256), 0, st, x, (const long long*)indices, counts, sums, M, K);
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "vq: dim %d not built", E);
+  IDEE_LAUNCH_CHECK("vq_cluster_stats");
+  return IDEE_OK;
+}
+
+extern "C" int idee_vq_ema_update(float* cluster_size, float* embed_avg, float* embed, const float* new_size, const float* new_sum,
+                                  int K, int E, float decay, float eps, idee_stream_t stream) {
+  IDEE_CHECK_ARG(cluster_size && embed_avg && embed && new_size && new_sum && K > 0 && E > 0, "vq_ema_update: bad argument");
+  hipLaunchKernelGGL(vq_ema_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cluster_size, embed_avg, embed, new_size,
+                     new_sum, K, E, decay, eps);
+  IDEE_LAUNCH_CHECK("vq_ema_update");
+  return IDEE_OK;
+}
+
+extern "C" int idee_vq_kmeans_update(float* means, const float* bins, const float* sums, int K, int E, idee_stream_t stream) {
+  IDEE_CHECK_ARG(means && bins && sums && K > 0 && E > 0, "vq_kmeans_update: bad argument");
+  hipLaunchKernelGGL(vq_kmeans_update_kernel, dim3(cdiv((long)K * E, 256)), dim3(256), 0, (hipStream_t)stream, means, bins, sums, K, E);
+  IDEE_LAUNCH_CHECK("vq_kmeans_update");
+  return IDEE_OK;
+}
+
+extern "C" int idee_vq_expire_codes(float* embed, float* cluster_size, float* embed_avg, const float* x, const int64_t* candidates,
+                                    int K, int E, float threshold, float reset, int32_t* n_expired, idee_stream_t stream) {
+  IDEE_CHECK_ARG(embed && cluster_size && embed_avg && x && candidates && K > 0 && E > 0, "vq_expire_codes: bad argument");
+  if (K > kVqMaxFloats / 16) return idee::fail(IDEE_ERR_UNSUPPORTED, "vq_expire_codes: %d codes exceed %d", K, kVqMaxFloats / 16);
+  hipLaunchKernelGGL(vq_expire_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, embed, cluster_size, embed_avg, x,
+                     (const long long*)candidates, K, E, threshold, reset, (int*)n_expired);
+  IDEE_LAUNCH_CHECK("vq_expire_codes");
   return IDEE_OK;
 }
 

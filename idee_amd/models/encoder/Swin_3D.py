@@ -160,9 +160,8 @@ class Swin_3D(_stacked.StackedModule):
             if has_ds:
                 if s == 0:
                     t = ops.PatchEmbedLN.apply(x, getattr(self, f"s{s}_ds_w"), getattr(self, f"s{s}_ds_b"))
-                else:
-                    raise NotImplementedError("idee_amd Swin_3D: a width change between stages is not built "
-                                              "(reference default embed_dim is [16, 16])")
+                else:   # hierarchical configuration: the reference re-embeds with PatchEmbed3D(in_dim -> dim) + LN (:414-419)
+                    t = ops.StageEmbedLN.apply(t, getattr(self, f"s{s}_ds_w"), getattr(self, f"s{s}_ds_b"))
             elif s == 0:
                 raise NotImplementedError("idee_amd Swin_3D: in_chans == embed_dim[0] (no patch embedding) is not built")
             wsz = self.window_size[s]

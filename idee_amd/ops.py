@@ -63,6 +63,34 @@ class PatchEmbedLN(torch.autograd.Function):
         return None, dw, db
 
 
+class StageEmbedLN(torch.autograd.Function):
+    """PatchEmbed3D (1,1,1) + non-affine LN between two Swin stages of different width, on channels-last tokens:
+    x (N,V,T,H,W,Cin), w (V,E,Cin), b (V,E) -> (N,V,T,H,W,E).  Reference: BasicLayer.forward's downsample,
+    models/encoder/Swin_3D.py:414-419, :422-428, PatchEmbed3D.forward :473-491."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        N, V, T, H, W, Cin = x.shape
+        E = w.shape[1]
+        y = torch.empty((N, V, T, H, W, E), device=x.device, dtype=torch.float32)
+        L.call("idee_stage_embed_ln_fwd", ptr(x), ptr(w), ptr(b), ptr(y), N * V, V, Cin, T * H * W, E, L.stream())
+        ctx.save_for_backward(x, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        N, V, T, H, W, Cin = x.shape
+        E = w.shape[1]
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        dw, db = _zeros_like_many(w, b)
+        L.call("idee_stage_embed_ln_bwd", ptr(x), ptr(w), ptr(b), ptr(dy), ptr(dx), ptr(dw), ptr(db), N * V, V, Cin, T * H * W, E,
+               L.stream())
+        return dx, dw, db
+
+
 # ----------------------------------------------------------------------------------------
 # fused Swin block
 # ----------------------------------------------------------------------------------------
@@ -625,4 +653,5 @@ class VQNearest(torch.autograd.Function):
         dembed = torch.zeros_like(embed)
         L.call("idee_vq_nn_bwd", ptr(x), ptr(embed), ptr(idx), ptr(dq), ptr(gl), ptr(dx), ptr(dembed), M, E, K, w_commit,
                L.stream())
-        return dx, dembed, None, None
+        # a codebook that is not learnable (EMA update) enters detached: commit_quantize = quantize.detach(), VQ.py:983-985
+        return dx, (dembed if ctx.needs_input_grad[1] else None), None, None

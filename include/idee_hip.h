@@ -52,6 +52,15 @@ int idee_patch_embed_ln_fwd(const float* x, const float* w, const float* b, floa
 int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dw, float* db, int N,
                             int V, int Cin, long L, int E, idee_stream_t stream);
 
+/* The same PatchEmbed3D (patch (1,1,1), bias, non-affine LayerNorm) BETWEEN two Swin stages of different width — BasicLayer
+ * builds it when in_dim != dim (models/encoder/Swin_3D.py:414-419, forward :473-491).  Input is already channels-last tokens.
+ *   x (B, L, Cin), w (V, E, Cin), b (V, E) | NULL, y (B, L, E); item b uses weight set b % V; Cin, E in {16, 32}
+ * bwd: dx (B, L, Cin) overwritten; dw (V, E, Cin), db (V, E) | NULL accumulate. */
+int idee_stage_embed_ln_fwd(const float* x, const float* w, const float* b, float* y, int B, int V, int Cin, long L, int E,
+                            idee_stream_t stream);
+int idee_stage_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dx, float* dw, float* db,
+                            int B, int V, int Cin, long L, int E, idee_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * One fused SwinTransformerBlock3D (norm1, pad, cyclic shift, window partition, WindowAttention3D
  * with relative-position bias and shift mask, window reverse, un-shift, crop, residual, norm2,
@@ -225,6 +234,23 @@ int idee_vq_nn_fwd(const float* x, const float* embed, float* q, int64_t* indice
                    int E, int K, int training, float w_commit, idee_stream_t stream);
 int idee_vq_nn_bwd(const float* x, const float* embed, const int64_t* indices, const float* dq, const float* gloss, float* dx,
                    float* dembed, long M, int E, int K, float w_commit, idee_stream_t stream);
+
+/* EuclideanCodebook's codebook maintenance (models/codebook/VQ.py): EMA update :519-545, k-means init :213-253 + :354-377,
+ * dead-code expiry :449-475.  All buffers f32; x (M, E) tokens, indices int64 (M) from idee_vq_nn_fwd.
+ *   cluster_stats : counts (K), sums (K, E) ACCUMULATE #{idx = k} and sum_{idx = k} x  (the caller zeroes them, and
+ *                   all-reduces them across data-parallel ranks where the reference calls all_reduce_fn)
+ *   ema_update    : cluster_size <- lerp(cluster_size, new_size, 1 - decay); embed_avg likewise; embed <- embed_avg /
+ *                   (laplace_smoothing(cluster_size, K, eps) * sum(cluster_size))
+ *   kmeans_update : means[k] <- sums[k] / bins[k] where bins[k] != 0
+ *   expire_codes  : the r-th code with cluster_size < threshold <- x[candidates[r]]; cluster_size <- reset, embed_avg <- sample *
+ *                   reset; n_expired (device int32 | NULL) receives the count.  candidates: int64 (>= K entries) sample rows. */
+int idee_vq_cluster_stats(const float* x, const int64_t* indices, float* counts, float* sums, long M, int E, int K,
+                          idee_stream_t stream);
+int idee_vq_ema_update(float* cluster_size, float* embed_avg, float* embed, const float* new_size, const float* new_sum, int K,
+                       int E, float decay, float eps, idee_stream_t stream);
+int idee_vq_kmeans_update(float* means, const float* bins, const float* sums, int K, int E, idee_stream_t stream);
+int idee_vq_expire_codes(float* embed, float* cluster_size, float* embed_avg, const float* x, const int64_t* candidates, int K,
+                         int E, float threshold, float reset, int32_t* n_expired, idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses (models/losses.py).

@@ -446,6 +446,42 @@ def vq_nearest(x, embed, training, commitment_weight=1.0):
     return q, idx, loss
 
 
+def vq_kmeans(samples, means, num_iters):
+    """kmeans, VQ.py:213-253, Euclidean, one codebook, from given initial means (the reference samples them).
+    samples (M,d), means (K,d) -> (means, bins)."""
+    K = means.shape[0]
+    bins = None
+    for _ in range(num_iters):
+        dist = -torch.cdist(samples[None], means[None])[0] if False else -(
+            (samples * samples).sum(-1, keepdim=True) + (means * means).sum(-1)[None] - 2 * samples @ means.t()).clamp(min=0).sqrt()
+        buckets = dist.argmax(-1)
+        bins = torch.bincount(buckets, minlength=K).to(samples.dtype)
+        sums = torch.zeros_like(means).index_add_(0, buckets, samples)
+        new_means = sums / bins.clamp(min=1).unsqueeze(1)
+        means = torch.where((bins == 0).unsqueeze(1), means, new_means)
+    return means, bins
+
+
+def vq_ema_update(x, idx, embed, cluster_size, embed_avg, decay=0.8, eps=1e-5, threshold_dead=0, candidates=None):
+    """The codebook update of EuclideanCodebook.forward, VQ.py:519-545 (+ expire_codes_ / replace :449-475 with the
+    replacement samples x[candidates[r]] for the r-th dead code).  x (M,d), idx (M) -> new (embed, cluster_size, embed_avg)."""
+    K = embed.shape[0]
+    onehot = F.one_hot(idx, K).to(x.dtype)
+    cluster_size = torch.lerp(cluster_size, onehot.sum(0), 1 - decay)
+    embed_avg = torch.lerp(embed_avg, onehot.t() @ x, 1 - decay)
+    smoothed = (cluster_size + eps) / (cluster_size.sum() + K * eps) * cluster_size.sum()
+    embed = embed_avg / smoothed.unsqueeze(1)
+    if threshold_dead > 0:
+        dead = cluster_size < threshold_dead
+        if bool(dead.any()):
+            sampled = x[candidates[: int(dead.sum())]]
+            embed, cluster_size, embed_avg = embed.clone(), cluster_size.clone(), embed_avg.clone()
+            embed[dead] = sampled
+            cluster_size[dead] = float(threshold_dead)
+            embed_avg[dead] = sampled * float(threshold_dead)
+    return embed, cluster_size, embed_avg
+
+
 # ----------------------------------------------------------------------------
 # training-driver bookkeeping (utils/utils_train.py) — SURVEY.md §8(f) rows 1-2
 # ----------------------------------------------------------------------------

@@ -126,6 +126,28 @@ def fx_swin_block(tag, window, shift, D, H, W, C=16, heads=2, B=2, seed=0):
     save("swin_block_" + tag, **out)
 
 
+def fx_swin_hier(tag, embed_dim, seed):
+    """A hierarchical Swin_3D (embed_dim changes between stages: BasicLayer re-embeds with PatchEmbed3D(in_dim -> dim) + LN,
+    Swin_3D.py:414-419): whole encoder, forward + every gradient."""
+    enc = ref_swin.Swin_3D(in_vars=2, in_chans=1, embed_dim=list(embed_dim), depths=[2, 1], num_heads=[2, 2])
+    rerandomise(enc, seed)
+    x = rand((1, 2, 1, 8, 8, 12), seed + 1)
+    with relu_record() as rec:
+        y = enc(x)
+    assert rec.ties() == 0, f"swin_hier_{tag}: seed {seed} has a ReLU tie; pick another seed"
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x, y=y.detach(), r=r, embed_dim=np.array(embed_dim))
+    out.update(sd_arrays(enc))
+    out.update({"grad/" + k: p.grad for k, p in enc.named_parameters()})
+    save("swin_hier_" + tag, **out)
+
+
+if __name__ == "__main__" and "--hier-only" in sys.argv:
+    fx_swin_hier("16_32", (16, 32), 1200)
+    fx_swin_hier("32_16", (32, 16), 1210)
+
+
 def fx_patch_embed(tag, cls, cin, seed):
     pe = cls(patch_size=(1, 1, 1), in_chans=cin, embed_dim=16, norm_layer=nn.LayerNorm)
     rerandomise(pe, seed)
@@ -412,6 +434,38 @@ def fx_vq(tag, K, training, seed):
     save("vq_" + tag, **out)
 
 
+def fx_vq_ema(seed=830):
+    """The reference VQ with the EMA codebook update (ema_update=True, learnable_codebook=False), k-means initialisation and
+    dead-code expiry, its sample choices made deterministic by substituting `sample_fn` (the first `num` batch samples) —
+    models/codebook/VQ.py:213-253, :354-377, :449-475, :519-545."""
+    from models.codebook.VQ import VQ as RefVQ
+    first = lambda samples, num: samples[:, :num]
+    out = {}
+    for tag, kw in (("plain", dict()), ("kmeans", dict(kmeans_init=True, kmeans_iters=4)), ("expire", dict(threshold_ema_dead_code=2))):
+        torch.manual_seed(seed)
+        q = RefVQ(dim=16, codebook_size=8, codebook_dim=16, ema_update=True, learnable_codebook=False, decay=0.8, **kw)
+        q._codebook.sample_fn = first
+        if not kw.get("kmeans_init"):
+            with torch.no_grad():
+                q._codebook.embed.copy_(torch.randn(q._codebook.embed.shape, generator=torch.Generator().manual_seed(seed)) * 0.7)
+                q._codebook.embed_avg.copy_(q._codebook.embed)
+        out.update({f"{tag}/sd0/" + k: v.clone() for k, v in q.state_dict().items()})
+        q.train()
+        for step in range(3):
+            x = rand((2, 150, 16), seed + 10 * step + 1).requires_grad_()
+            zq, idx, loss = q(x)
+            r = rand(zq.shape, seed + 10 * step + 2)
+            ((zq * r).sum() + 1.7 * loss.sum()).backward()
+            out.update({f"{tag}/s{step}/x": x.detach(), f"{tag}/s{step}/r": r, f"{tag}/s{step}/z_q": zq.detach(), f"{tag}/s{step}/indices": idx,
+                        f"{tag}/s{step}/loss": loss.detach(), f"{tag}/s{step}/dx": x.grad})
+            out.update({f"{tag}/s{step}/sd/" + k: v.clone() for k, v in q.state_dict().items()})
+    save("vq_ema", **out)
+
+
+if __name__ == "__main__" and "--vqema-only" in sys.argv:
+    fx_vq_ema()
+
+
 if __name__ == "__main__" and "--vq-only" in sys.argv:
     fx_vq("k2_train", 2, True, 800)
     fx_vq("k2_eval", 2, False, 810)
@@ -556,12 +610,15 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
 
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
-                                                                "--era5-only")):
+                                                                "--era5-only", "--hier-only", "--vqema-only")):
     main()
+    fx_swin_hier("16_32", (16, 32), 1200)
+    fx_swin_hier("32_16", (32, 16), 1210)
     fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
     fx_patch_mergings()
     fx_dataset_items()
     fx_vq("k2_train", 2, True, 800)
     fx_vq("k2_eval", 2, False, 810)
     fx_vq("k8_train", 8, True, 820)
+    fx_vq_ema()
     fx_evaluators()

@@ -743,3 +743,55 @@ def test_harness_evaluators_collector_checkpoint(tmp_path):
     assert path.endswith("model_checkpoints/best_loss_model.pth")
     m2 = VQ_model(cfg)
     m2.load_state_dict({k.replace("module.", ""): v for k, v in ck["model_state_dict"].items()}, strict=True)
+
+
+@pytest.mark.parametrize("tag", ["16_32", "32_16"])
+def test_swin_hierarchical_encoder_golden(tag):
+    """Swin_3D with a width change between its stages (the reference re-embeds with PatchEmbed3D(in_dim -> dim) + LN,
+    Swin_3D.py:414-419): outputs and every gradient against the reference's own."""
+    from idee_amd.models.encoder.Swin_3D import Swin_3D
+    a, sd, grads = load_golden("swin_hier_" + tag)
+    enc = Swin_3D(in_vars=2, in_chans=1, embed_dim=[int(v) for v in a["embed_dim"]], depths=[2, 1], num_heads=[2, 2])
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(DEV).train()
+    y = enc(dev(a["x"]))
+    close("y", y, a["y"])
+    (y * dev(a["r"])).sum().backward()
+    ps = dict(enc.named_parameters())
+    checked = 0
+    for key, name, idx in enc._key_map():
+        if name.endswith("_index"):
+            continue
+        base = name[:-1] if name.endswith("_ds_w5") else name
+        g = ps[base].grad
+        g = g.view(*g.shape, 1, 1, 1) if name.endswith("_ds_w5") else g
+        gclose("d" + key, g if idx is None else g[idx], grads[key], rtol=2e-3, floor=2e-4)
+        checked += 1
+    assert checked == len(grads)
+
+
+@pytest.mark.parametrize("tag", ["plain", "kmeans", "expire"])
+def test_vq_ema_kmeans_expire_golden(tag):
+    """VQ with the EMA codebook update, k-means initialisation and dead-code expiry against three training steps of the
+    reference's VQ (its sample choice made deterministic: the first `num` batch samples) — outputs, dx and the codebook
+    buffers after every step."""
+    from idee_amd.models.codebook.VQ import VQ
+    a, _, _ = load_golden("vq_ema")
+    kw = dict(plain={}, kmeans=dict(kmeans_init=True, kmeans_iters=4), expire=dict(threshold_ema_dead_code=2))[tag]
+    q = VQ(dim=16, codebook_size=8, codebook_dim=16, ema_update=True, learnable_codebook=False, decay=0.8, **kw)
+    q.load_state_dict({k[len(tag) + 5:]: v for k, v in a.items() if k.startswith(f"{tag}/sd0/")}, strict=True)
+    q.sample_indices = lambda n, num, device: torch.arange(num, device=device)
+    q = q.to(DEV).train()
+    for step in range(3):
+        g = lambda k: a[f"{tag}/s{step}/{k}"]
+        x = dev(g("x")).requires_grad_()
+        zq, idx, loss = q(x)
+        assert torch.equal(idx.cpu(), g("indices").long())
+        close("z_q", zq, g("z_q"))
+        close("loss", loss, g("loss"), atol=1e-6, rtol=1e-4)
+        ((zq * dev(g("r"))).sum() + 1.7 * loss.sum()).backward()
+        gclose("dx", x.grad, g("dx"))
+        sd = q.state_dict()
+        for k in ("_codebook.embed", "_codebook.cluster_size", "_codebook.embed_avg"):
+            close(f"step {step} {k}", sd[k], g("sd/" + k), atol=2e-5, rtol=1e-4)
+        assert bool(sd["_codebook.initted"])

@@ -238,3 +238,42 @@ def test_evaluators_and_collector():
     out, cnt = O.anomaly_majority_vote(batches, a["col/timesteps"].numpy(), 8, tuple(a["col/result"].shape))
     assert np.array_equal(cnt, a["col/counter"].numpy())
     assert np.array_equal(np.nan_to_num(out, nan=-1), np.nan_to_num(a["col/result"].numpy(), nan=-1))
+
+
+@pytest.mark.parametrize("tag", ["16_32", "32_16"])
+def test_swin_hierarchical_encoder(tag):
+    """Width change between Swin stages (PatchEmbed3D(in_dim -> dim) + LN, Swin_3D.py:414-419) in the oracle."""
+    a, sd, grads = load_golden("swin_hier_" + tag)
+    cfg = O.default_cfg(in_channels_dynamic=2, en_embed_dim=[int(v) for v in a["embed_dim"]])
+    sdl = leaf({"encoder." + k: v for k, v in sd.items()})
+    y = O.swin_encoder(a["x"], sdl, cfg)
+    close(y, a["y"])
+    (y * a["r"]).sum().backward()
+    check_grads(sdl, {"encoder." + k: v for k, v in grads.items()}, atol=2e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["plain", "kmeans", "expire"])
+def test_vq_ema_kmeans_expire(tag):
+    """EuclideanCodebook's EMA update, k-means initialisation and dead-code expiry (VQ.py:213-253, :354-377, :449-475,
+    :519-545) restated in the oracle, three training steps against the reference's buffers."""
+    a, _, _ = load_golden("vq_ema")
+    g = lambda k: a[f"{tag}/{k}"]
+    embed, cs, avg = g("sd0/_codebook.embed")[0], g("sd0/_codebook.cluster_size")[0], g("sd0/_codebook.embed_avg")[0]
+    initted = bool(g("sd0/_codebook.initted"))
+    for step in range(3):
+        x = g(f"s{step}/x").clone().requires_grad_()
+        x2 = x.detach().reshape(-1, 16)
+        if not initted:
+            embed, bins = O.vq_kmeans(x2, x2[:8].clone(), 4)
+            avg, cs, initted = embed * bins.unsqueeze(1), bins, True
+        zq, idx, loss = O.vq_nearest(x, embed, True)
+        close(zq, g(f"s{step}/z_q"))
+        assert torch.equal(idx, g(f"s{step}/indices").long())
+        close(loss, g(f"s{step}/loss"))
+        ((zq * g(f"s{step}/r")).sum() + 1.7 * loss.sum()).backward()
+        close(x.grad, g(f"s{step}/dx"), 1e-6, 1e-3)
+        embed, cs, avg = O.vq_ema_update(x2, idx.reshape(-1), embed, cs, avg, 0.8, 1e-5, 2 if tag == "expire" else 0,
+                                         torch.arange(8))
+        close(embed, g(f"s{step}/sd/_codebook.embed")[0], 1e-6, 1e-5)
+        close(cs, g(f"s{step}/sd/_codebook.cluster_size")[0], 1e-6, 1e-5)
+        close(avg, g(f"s{step}/sd/_codebook.embed_avg")[0], 1e-5, 1e-5)
