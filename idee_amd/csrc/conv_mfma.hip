@@ -573,11 +573,14 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
   const long nunits = (long)nb * a.To * nhrun * nstrip;
 
   for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+    // t runs fastest: the 4 waves of a workgroup take 4 consecutive output frames of the SAME strip and rows at the same
+    // time, so the source rows they share (frame t feeds outputs t-1, t, t+1) are fetched from HBM once and re-read from
+    // this CU's L1 / the XCD's L2 (with t slowest the three users ran far apart: 3.1x the input bytes from HBM)
     long r = un;
+    const int t = (int)(r % a.To); r /= a.To;
     const int sp = (int)(r % nstrip); r /= nstrip;
-    const int hr = (int)(r % nhrun); r /= nhrun;
-    const int t = (int)(r % a.To);
-    const int b = (int)(r / a.To) * a.wsets + wset;
+    const int hr = (int)(r % nhrun);
+    const int b = (int)(r / nhrun) * a.wsets + wset;
     const int my_sub = min(MT, nsub - sp * MT);                        // column blocks of this strip (1 or 2)
     const int p0 = sp * MT * 16;                                       // first frame column of the strip
     const int rowlen = my_sub * 16 + 2;
@@ -746,11 +749,11 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
   const long nunits = (long)nb * a.To * nhrun * nstrip;
 
   for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
-    long r = un;
+    long r = un;      // t fastest: see conv16_lds_kernel
+    const int t = (int)(r % a.To); r /= a.To;
     const int sp = (int)(r % nstrip); r /= nstrip;
-    const int hr = (int)(r % nhrun); r /= nhrun;
-    const int t = (int)(r % a.To);
-    const int b = (int)(r / a.To) * a.wsets + wset;
+    const int hr = (int)(r % nhrun);
+    const int b = (int)(r / nhrun) * a.wsets + wset;
     const int my_sub = min(2, nsub - sp * 2);
     const int p0 = sp * 32;
     const int rowlen = my_sub * 16 + 2;

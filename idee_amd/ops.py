@@ -15,10 +15,67 @@ from . import _lib as L
 from ._lib import ptr
 
 
+class ZeroArena:
+    """One zero-filled f32 buffer per training step for every accumulate-into gradient / statistics buffer of the path
+    (~30 of them per step: each used to be its own fill kernel).  The first step under an arena records the sequence of
+    requested sizes; every later step takes ONE torch.zeros of the total and hands out 16-byte-aligned slices in the same
+    order (256-byte aligned: float atomics of different buffers must not share a memory line).  A request that does not match the recorded sequence falls back to its own torch.zeros (and the arena re-records
+    on the next step), so a change of shapes or of control flow is safe.  Used as `with arena:` around forward + backward
+    (idee_amd/train.py); without an active arena `_zeros` is plain torch.zeros."""
+    active = None
+
+    def __init__(self):
+        self.plan, self.recording, self.buf, self.pos, self.off, self.ok = None, [], None, 0, 0, True
+
+    def __enter__(self):
+        self.recording, self.pos, self.off, self.ok = [], 0, 0, True
+        self.buf = None
+        if self.plan is not None:
+            self.buf = torch.zeros(self.plan[1], device=self.plan[2], dtype=torch.float32)
+        ZeroArena.active = self
+        return self
+
+    def __exit__(self, *exc):
+        ZeroArena.active = None
+        if self.buf is None or not self.ok or self.pos != len(self.plan[0]):
+            total = sum(n for n, _ in self.recording)
+            dev = self.recording[0][1] if self.recording else None
+            self.plan = ([n for n, _ in self.recording], total, dev) if self.recording else None
+        self.buf = None
+        return False
+
+    def take(self, numel, device):
+        n = (numel + 63) // 64 * 64        # 256-byte slots: small accumulate-into buffers on separate lines
+        self.recording.append((n, device))
+        if self.buf is not None and self.ok and self.pos < len(self.plan[0]) and self.plan[0][self.pos] == n and device == self.plan[2]:
+            out = self.buf[self.off:self.off + numel]
+            self.pos += 1
+            self.off += n
+            return out
+        self.ok = False
+        return torch.zeros(numel, device=device, dtype=torch.float32)
+
+
+def _zeros(shape, device):
+    """Zero-filled f32 tensor: a slice of the step's ZeroArena when one is active, else torch.zeros."""
+    shape = tuple(shape) if not isinstance(shape, int) else (shape,)
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    a = ZeroArena.active
+    if a is None or numel == 0:
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+    return a.take(numel, torch.device(device)).view(shape)
+
+
+def _zeros_like(t):
+    return _zeros(t.shape, t.device)
+
+
 def _zeros_like_many(*ts):
     """Zero-filled f32 tensors shaped like `ts`, carved (16-byte aligned) out of ONE buffer: one fill kernel instead of len(ts)."""
-    sizes = [(t.numel() + 3) // 4 * 4 for t in ts]
-    flat = torch.zeros(sum(sizes), device=ts[0].device, dtype=torch.float32)
+    sizes = [(t.numel() + 63) // 64 * 64 for t in ts]      # 256-byte slots (float atomics of different buffers on separate lines)
+    flat = _zeros(sum(sizes), ts[0].device)
     out, o = [], 0
     for t, n in zip(ts, sizes):
         out.append(flat[o:o + t.numel()].view(t.shape))
@@ -56,8 +113,8 @@ class PatchEmbedLN(torch.autograd.Function):
         N, V, Cin, T, H, W = x.shape
         E = w.shape[1]
         dy = _f32c(dy)
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(b) if b is not None else None
+        dw = _zeros_like(w)
+        db = _zeros_like(b) if b is not None else None
         L.call("idee_patch_embed_ln_bwd", ptr(x), ptr(w), ptr(b), ptr(dy), ptr(dw), ptr(db), N, V, Cin, T * H * W, E,
                L.stream())
         return None, dw, db
@@ -216,7 +273,7 @@ class ConvLayer:
         dev = x.device
         cpad = ((self.Cout + 15) // 16) * 16
         nw = (self.wgrad_floats + 3) // 4 * 4
-        flat = torch.zeros(nw + (self.wsets * cpad if want_bias else 0), device=dev, dtype=torch.float32)   # one fill
+        flat = _zeros(nw + (self.wsets * cpad if want_bias else 0), dev)   # one fill (a slice of the step's arena)
         dwp = flat[:self.wgrad_floats]
         dbp = flat[nw:].view(self.wsets, cpad) if want_bias else None
         L.call("idee_conv_wgrad", C.byref(self.desc), ptr(x), ptr(dy), ptr(dwp), ptr(dbp), L.stream())
@@ -444,7 +501,7 @@ class ClassifierHeadsSigns(torch.autograd.Function):
         dhwe, dhb1 = h1.wgrad(sx, dha1, hwe)
         # unfold the weight gradients through [w_out | b_out]
         djw1, dhw1 = torch.empty_like(jw1), torch.empty_like(hw1)
-        dw_out, db_out = torch.zeros_like(w_out), torch.zeros_like(b_out)
+        dw_out, db_out = _zeros_like_many(w_out, b_out)
         L.call("idee_lfq_fold_weights_bwd", ptr(djwe), ptr(jw1), ptr(w_out), ptr(b_out), ptr(djw1), ptr(dw_out), ptr(db_out),
                Dj, V, Cc, D, CS, 0, st)
         L.call("idee_lfq_fold_weights_bwd", ptr(dhwe), ptr(hw1), ptr(w_out), ptr(b_out), ptr(dhw1), ptr(dw_out), ptr(db_out),
@@ -476,7 +533,7 @@ class LFQQuantize(torch.autograd.Function):
         dev = z.device
         zq = torch.empty_like(z)
         idx = torch.empty(z.shape[:-1], device=dev, dtype=torch.int64)
-        stats = torch.zeros(4 + codebook_size, device=dev, dtype=torch.float32)
+        stats = _zeros(4 + codebook_size, dev)
         ws = torch.empty(L.load().idee_lfq_workspace_floats(M, codebook_size), device=dev, dtype=torch.float32)
         D = max(1, codebook_size.bit_length() - 1)
         signs = torch.empty(z.shape[:-1] + (D,), device=dev, dtype=torch.float32) if want_signs else None
@@ -494,8 +551,8 @@ class LFQQuantize(torch.autograd.Function):
         dzq = _f32c(dzq) if dzq is not None else torch.zeros_like(z)
         gl = _f32c(dloss).reshape(1) if dloss is not None else torch.zeros(1, device=z.device)
         dz = torch.empty_like(z)
-        dw_in, db_in, dw_out = torch.zeros_like(w_in), torch.zeros_like(b_in), torch.zeros_like(w_out)
-        db_out = torch.zeros(E, device=z.device, dtype=torch.float32)
+        dw_in, db_in, dw_out = _zeros_like_many(w_in, b_in, w_out)
+        db_out = _zeros(E, z.device)
         dsigns = _f32c(dsigns) if dsigns is not None else None
         L.call("idee_lfq_bwd", ptr(z), ptr(dzq), ptr(w_in), ptr(b_in), ptr(w_out), ptr(stats), ptr(gl), ptr(dsigns), ptr(dz),
                ptr(dw_in), ptr(db_in), ptr(dw_out), ptr(db_out), M, E, K, w_entropy, gamma, w_commit, L.stream())
@@ -607,7 +664,7 @@ class ConvLNUnit(torch.autograd.Function):
         N, V, T, H, W, Cc = x.shape
         dy = _f32c(dy)
         dc = torch.empty_like(c)
-        dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(beta)
+        dgamma, dbeta = _zeros_like_many(gamma, beta)
         L.call("idee_ln_relu_res_bwd", ptr(c), ptr(gamma), ptr(beta), ptr(dy), ptr(dc), ptr(dgamma), ptr(dbeta), N * V, V,
                T * H * W, Cc, L.stream())
         dw, _ = conv.wgrad(x, dc, w, want_bias=False)

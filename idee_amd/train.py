@@ -29,6 +29,7 @@ class _TrainStep:
                               betas=(config.beta1, config.beta2))
         parallel.broadcast_parameters(self.opt.flat_p)
         self.code0 = torch.zeros(1, dtype=torch.long, device=device)
+        self.arena = ops.ZeroArena()
 
     @staticmethod
     def _stack_logits(pred, pred_y):
@@ -68,9 +69,10 @@ class _TrainStep:
 
     def _step(self, x_d, *masks):
         self.opt.zero_grad(set_to_none=True)
-        outs = self.model(x_d)
-        total, parts = self.losses(outs, *masks)
-        total.backward()
+        with self.arena:        # one fill for all accumulate-into buffers of forward + backward
+            outs = self.model(x_d)
+            total, parts = self.losses(outs, *masks)
+            total.backward()
         parallel.sync_gradients(self.opt)
         self.opt.step()
         return total.detach(), parts, outs

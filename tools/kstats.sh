@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: kstats.sh <tag> : rocprofv3 kernel stats of a short bench run, top kernels printed
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d gpurun_out/ks_$1 -o r --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/ks_$1.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d gpurun_out/ks_$1 -o r --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/ks_$1.log 2>&1
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("gpurun_out/ks_$1/r_kernel_stats.csv")))
