@@ -716,6 +716,212 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// conv16_lds_kernel on split-precision MFMAs (opt-in: IDEE_CONV_MATH=split; reported as its own bench line).
+// Every f32 operand is cut into two 16-bit pieces x = hi + lo (common.h split2): f16 pieces in the FORWARD modes (11 + 11
+// mantissa bits: f32-level, operands are O(1); the weights are pre-scaled by a power of two into f16's normal range and the
+// accumulator un-scaled in the epilogue), bf16 pieces in the DATA-GRADIENT modes (8 + 8 bits, f32's exponent range).
+// A product is formed from THREE piece products hi*hi + hi*lo + lo*hi (the dropped lo*lo is 2^-22 resp. 2^-16 of the
+// product) on v_mfma_f32_16x16x32_{f16,bf16}: K = 32 = TWO TAPS x 16 input channels, so a pair of taps costs 3 MFMAs of 16
+// cycles instead of 8 f32 MFMAs of 32 cycles.  Same work decomposition, LDS ring and epilogue as conv16_lds_kernel; the
+// staged rows are kept as two piece images [quad pair][pixel][quad & 1][4 channels x 16 bit] so that a lane's 4 channels
+// of one piece are one 8-byte, conflict-free ds_read_b64 (32 lanes x 8 B = one 256-byte LDS row).
+// ---------------------------------------------------------------------------------------------
+constexpr int kSplitRowW = 2 * kC16Row * 4;     // 32-bit words of one staged row of ONE piece: [2 quad pairs][34 px][4 words]
+
+template <int MODE, bool F16>
+__global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
+  constexpr int MT = 2;
+  constexpr bool REP = MODE == FWD_REP || MODE == DGRAD_REP;
+  constexpr int TSN = REP ? 3 : (MODE == FWD_S2 ? 2 : 1);
+  constexpr int NTAP = TSN * 9, NPAIR = (NTAP + 1) / 2;
+  __shared__ __attribute__((aligned(16))) unsigned s_xw[4][2 * 9 * kSplitRowW];   // [piece][T-slot * 3 + ring slot][row]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  unsigned* s_x = s_xw[wave];
+  u32x4 wh[NPAIR], wl[NPAIR];       // A fragments of a tap pair: [piece of tap a | piece of tap b]
+  int wkey = -1;
+  const float* wp = a.wp + (long)wset * a.ntaps * 256;
+  // power-of-two weight scale (f16 pieces only): max |w| of this weight set lands in [2^13, 2^14)
+  float wscale = 1.f, winv = 1.f;
+  if (F16) {
+    float mx = 0.f;
+    for (int tp = 0; tp < a.ntaps; ++tp) {
+      const f32x4 f = ld4(wp + tp * 256 + lane * 4);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(f[0]), fabsf(f[1]))), fmaxf(fabsf(f[2]), fabsf(f[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    int e = 0;
+    frexpf(fmaxf(mx, 1e-30f), &e);            // mx = m * 2^e, m in [0.5, 1)
+    wscale = ldexpf(1.f, 14 - e);
+    winv = ldexpf(1.f, e - 14);
+  }
+  const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
+  const int nsub = (Wframe + 15) / 16;
+  const int nb = a.B / a.wsets;
+  const long nunits = (long)nb * a.To * nhrun * nstrip;
+  // word offset of this lane's 8-byte fragment piece inside a staged row, for pixel index 0: [kq >> 1][pixel][kq & 1][2 words]
+  const int lane_off = (kq >> 1) * (kC16Row * 4) + (kq & 1) * 2;
+
+  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+    long r = un;      // t fastest: see conv16_lds_kernel
+    const int t = (int)(r % a.To); r /= a.To;
+    const int sp = (int)(r % nstrip); r /= nstrip;
+    const int hr = (int)(r % nhrun);
+    const int b = (int)(r / nhrun) * a.wsets + wset;
+    const int my_sub = min(MT, nsub - sp * MT);
+    const int p0 = sp * MT * 16;
+    const int rowlen = my_sub * 16 + 2;
+    const int h0 = hr * hrun, h1 = min(a.Ho, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;
+    const float* in_b = a.in + (long)b * a.i_sB;
+    Slot st[3];
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti, a.kt);
+    const int blk1 = my_sub > 1 ? 16 : 0;
+
+    for (int h = h0; h < h1; ++h) {
+      wave_fence();
+      Slot sh[3];
+      int slot_of[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        sh[oh] = slot_h<MODE>(oh, h, a.Hi);
+        const int hs = sh[oh].src;
+        const bool inside = sh[oh].ok;
+        const int slot = (hs + 3) % 3;
+        slot_of[oh] = slot;
+        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+        if (cur == hs + 1) continue;
+        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
+        f32x4 stg[TSN][3];
+#pragma unroll
+        for (int ot = 0; ot < TSN; ++ot) {
+          const float* src = in_b + (long)st[ot].src * a.i_sT + (long)hs * a.i_sH;
+          const bool live = inside && st[ot].ok;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            const int px = u >> 2, q4 = u & 3;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < rowlen * 4 && live) {
+              if (MODE == FWD_REP) {
+                const int w = min(max(p0 + px - 1, 0), a.Wi - 1);
+                v = ld4(src + (long)w * a.i_sW + 4 * q4);
+              } else {
+                const int w = p0 + px - (MODE == DGRAD_REP ? 2 : 1);
+                if (w >= 0 && w < a.Wi) v = ld4(src + (long)w * a.i_sW + 4 * q4);
+              }
+            }
+            stg[ot][k] = v;
+          }
+        }
+#pragma unroll
+        for (int ot = 0; ot < TSN; ++ot) {
+          unsigned* dst = s_x + (ot * 3 + slot) * kSplitRowW;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            if (u < rowlen * 4) {
+              const Split p = split2<F16>(stg[ot][k]);
+              const int o = ((u & 3) >> 1) * (kC16Row * 4) + (u >> 2) * 4 + (u & 1) * 2;
+              typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+              *reinterpret_cast<u32x2v*>(dst + o) = u32x2v{p.h01, p.h23};
+              *reinterpret_cast<u32x2v*>(dst + 9 * kSplitRowW + o) = u32x2v{p.l01, p.l23};
+            }
+          }
+        }
+      }
+      wave_fence();
+      {
+        const int key = ((((st[0].tap * 3 + st[1].tap) * 3 + st[2].tap) * 3 + sh[0].tap) * 3 + sh[1].tap) * 3 + sh[2].tap;
+        if (key != wkey) {
+          wkey = key;
+#pragma unroll
+          for (int pr = 0; pr < NPAIR; ++pr) {
+            Split sa, sb = {0u, 0u, 0u, 0u};
+            {
+              const int tp = 2 * pr, ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
+              sa = split2<F16>(ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * 256 + lane * 4) * wscale);
+            }
+            if (2 * pr + 1 < NTAP) {
+              const int tp = 2 * pr + 1, ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
+              sb = split2<F16>(ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * 256 + lane * 4) * wscale);
+            }
+            wh[pr] = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
+            wl[pr] = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
+          }
+        }
+      }
+      f32x4 acc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // word address of (T-slot ot, tap row oh, pixel shift ow) for this lane, piece 0, tile 0
+      auto addr = [&](int tp) __attribute__((always_inline)) {
+        const int ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
+        const int sh_px = (MODE == FWD_REP || MODE == FWD_S2) ? ow : 2 - ow;
+        return (ot * 3 + slot_of[oh]) * kSplitRowW + lane_off + (j + sh_px) * 4;
+      };
+      typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+      auto rd = [&](int pr, u32x4 (&bh)[MT], u32x4 (&bl)[MT]) __attribute__((always_inline)) {
+        const int aa = addr(2 * pr), ab = addr(2 * pr + 1 < NTAP ? 2 * pr + 1 : 2 * pr);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int mo = m ? blk1 * 4 : 0;
+          const u32x2v ha = *reinterpret_cast<const u32x2v*>(s_x + aa + mo), hb = *reinterpret_cast<const u32x2v*>(s_x + ab + mo);
+          const u32x2v la = *reinterpret_cast<const u32x2v*>(s_x + 9 * kSplitRowW + aa + mo),
+                       lb = *reinterpret_cast<const u32x2v*>(s_x + 9 * kSplitRowW + ab + mo);
+          bh[m] = u32x4{ha[0], ha[1], hb[0], hb[1]};
+          bl[m] = u32x4{la[0], la[1], lb[0], lb[1]};
+        }
+      };
+      u32x4 bh[2][MT], bl[2][MT];
+      rd(0, bh[0], bl[0]);
+#pragma unroll
+      for (int pr = 0; pr < NPAIR; ++pr) {
+        if (pr + 1 < NPAIR) rd(pr + 1, bh[(pr + 1) & 1], bl[(pr + 1) & 1]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = mfma_s<F16>(wh[pr], bh[pr & 1][m], acc[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = mfma_s<F16>(wh[pr], bl[pr & 1][m], acc[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = mfma_s<F16>(wl[pr], bh[pr & 1][m], acc[m]);
+      }
+      // epilogue (as conv16_lds_kernel; the f16 weight scale is taken out first)
+      float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+      const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (m >= my_sub) continue;
+        const int p = p0 + m * 16 + j;
+        if (p >= Wframe) continue;
+        int wdst = p;
+        bool atomic = false;
+        if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
+        f32x4 v = F16 ? acc[m] * winv : acc[m];
+        if (a.bias) v += ld4(a.bias + (long)wset * 16 + 4 * kq);
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const long o = (long)wdst * a.o_sW + 4 * kq;
+        if (ref_r) {
+          const f32x4 rr = ld4(ref_r + o);
+          v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+          v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+        }
+        if (atomic) {
+          atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
+          atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
+        } else {
+          if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
+          st4(out_r + o, v);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradient of the 16 -> 16 3x3x3 replicate convolution, every WAVE on its own (the structure of
 // conv16_lds_kernel): a wave owns a strip of 2 column blocks (32 pixels) and walks a run of rows of one (batch item, t),
@@ -857,6 +1063,145 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
       v += __shfl_xor(v, 32, 64);
       if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + (gb0 + n) * 16 + lane, v);
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// wgrad16_strip_kernel on split-precision MFMAs (opt-in, IDEE_CONV_MATH=split): bf16 pieces (gradients have no a-priori
+// scale), three piece products per tap, K = the strip's 32 pixels in ONE v_mfma_f32_16x16x32_bf16: 81 MFMAs of 16 cycles
+// per output row instead of 216 f32 MFMAs of 32 cycles.  The x rows are staged as token-major piece images
+// [pixel][16 channels hi | 16 channels lo] (64 B per pixel) and read back TRANSPOSED (ds_read_b64_tr_b16: lane (channel i,
+// group g) gets pixels 8g..8g+7 of channel i, shifted by the tap); dy comes from global memory as before and is split in
+// registers.  16 -> 16 channels only (NB = 1).
+// ---------------------------------------------------------------------------------------------
+template <int MODE /*FWD_REP | FWD_S2*/, int TSL>
+__global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
+  constexpr int NTAPS = TSL * 9;
+  constexpr int ROWW = kC16Row * 16;              // 32-bit words per staged row: 34 pixels x (8 words hi + 8 words lo)
+  __shared__ __attribute__((aligned(16))) unsigned s_xw[4][TSL * 3 * ROWW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  unsigned* s_x = s_xw[wave];
+  f32x4 acc[NTAPS];
+  float bsum = 0.f;
+#pragma unroll
+  for (int tp = 0; tp < NTAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsub = (a.W + 15) / 16;
+  const int nb = a.B / a.wsets;
+  const long nunits = (long)nb * a.To * nhrun * nstrip;
+  // transposed-read address of this lane inside a staged row, for pixel shift 0: lane 4q + p of group g supplies row
+  // (pixel) 8g + q [+ 4 for the second read], columns (channels) 4p .. 4p + 3
+  const int tr_off = (8 * kq + (r16 >> 2)) * 16 + 2 * (r16 & 3);
+  typedef short s16x4t __attribute__((ext_vector_type(4)));
+  auto tr = [&](const unsigned* p) __attribute__((always_inline)) {
+    const s16x4t t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4t __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(unsigned long long, t);
+  };
+
+  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+    long r = un;      // t fastest: see conv16_lds_kernel
+    const int t = (int)(r % a.To); r /= a.To;
+    const int sp = (int)(r % nstrip); r /= nstrip;
+    const int hr = (int)(r % nhrun);
+    const int b = (int)(r / nhrun) * a.wsets + wset;
+    const int my_sub = min(2, nsub - sp * 2);
+    const int p0 = sp * 32;
+    const int rowlen = my_sub * 16 + 2;
+    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;
+    const float* x_b = a.x + (long)b * a.x_sB;
+    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
+    int tsrc[TSL];
+#pragma unroll
+    for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : a.kt * t + ot;
+
+    for (int h = h0; h < h1; ++h) {
+      wave_fence();
+      // dy of this row: lane (cout = r16, pixels p0 + 8 kq + {0..7}); pixels past the row end contribute zero
+      f32x4 d0, d1;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int p = p0 + 8 * kq + jj;
+        const bool on = 8 * kq + jj < 16 * my_sub && p < a.W;
+        const float v = on ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW + goff(0, a.y_gpu, a.y_sU, a.y_sG) + r16] : 0.f;
+        if (jj < 4) d0[jj] = v; else d1[jj - 4] = v;
+        bsum += v;
+      }
+      const Split s0 = split2<false>(d0), s1 = split2<false>(d1);
+      const u32x4 Bh = {s0.h01, s0.h23, s1.h01, s1.h23}, Bl = {s0.l01, s0.l23, s1.l01, s1.l23};
+      int slot_of[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const int hs = MODE == FWD_REP ? min(max(h + oh - 1, 0), a.H - 1) : h + oh - 1;
+        const bool inside = hs >= 0 && hs < a.H;
+        const int slot = (hs + 3) % 3;
+        slot_of[oh] = slot;
+        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+        if (cur == hs + 1) continue;
+        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
+        f32x4 stg[TSL][3];
+#pragma unroll
+        for (int ot = 0; ot < TSL; ++ot) {
+          const float* src = x_b + (long)tsrc[ot] * a.x_sT + (long)hs * a.x_sH;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < rowlen * 4 && inside) {
+              const int w = p0 + (u >> 2) - 1;
+              if (MODE == FWD_REP) v = ld4(src + (long)min(max(w, 0), a.W - 1) * a.x_sW + 4 * (u & 3));
+              else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * (u & 3));
+            }
+            stg[ot][k] = v;
+          }
+        }
+#pragma unroll
+        for (int ot = 0; ot < TSL; ++ot) {
+          unsigned* dst = s_x + (ot * 3 + slot) * ROWW;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            if (u < kC16Row * 4) {          // pixels past a one-block strip are written as zeros
+              const Split p = split2<false>(stg[ot][k]);
+              typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+              *reinterpret_cast<u32x2v*>(dst + (u >> 2) * 16 + (u & 3) * 2) = u32x2v{p.h01, p.h23};
+              *reinterpret_cast<u32x2v*>(dst + (u >> 2) * 16 + 8 + (u & 3) * 2) = u32x2v{p.l01, p.l23};
+            }
+          }
+        }
+      }
+      wave_fence();
+      // acc[tap][cin][cout] += sum over the strip's 32 pixels of x[pixel + tap offset][cin] dy[pixel][cout]
+#pragma unroll
+      for (int ot = 0; ot < TSL; ++ot)
+#pragma unroll
+        for (int oh = 0; oh < 3; ++oh)
+#pragma unroll
+          for (int ow = 0; ow < 3; ++ow) {
+            const unsigned* ap = s_x + (ot * 3 + slot_of[oh]) * ROWW + ow * 16 + tr_off;
+            const unsigned long long h0_ = tr(ap), h1_ = tr(ap + 4 * 16), l0_ = tr(ap + 8), l1_ = tr(ap + 4 * 16 + 8);
+            const u32x4 Ah = {(unsigned)h0_, (unsigned)(h0_ >> 32), (unsigned)h1_, (unsigned)(h1_ >> 32)};
+            const u32x4 Al = {(unsigned)l0_, (unsigned)(l0_ >> 32), (unsigned)l1_, (unsigned)(l1_ >> 32)};
+            const int tp = (ot * 3 + oh) * 3 + ow;
+            acc[tp] = mfma_s<false>(Ah, Bh, acc[tp]);
+            acc[tp] = mfma_s<false>(Ah, Bl, acc[tp]);
+            acc[tp] = mfma_s<false>(Al, Bh, acc[tp]);
+          }
+    }
+  }
+  float* dw = a.dwp + (long)wset * NTAPS * 16 * a.CoutPad;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + col, acc[tp][r]);
+  if (a.dbias) {
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + lane, v);
   }
 }
 
@@ -1338,6 +1683,12 @@ void split_tiles(ConvArgs& a, int Wframe) {
   a.tiles = a.To * a.hgroups * a.wtiles;
 }
 
+// IDEE_CONV_MATH=split selects the split-precision 16 -> 16 kernels (default: exact f32 MFMA)
+bool conv_split_math() {
+  const char* e = getenv("IDEE_CONV_MATH");
+  return e && strcmp(e, "split") == 0;
+}
+
 template <int MODE>
 int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   const int NT = pick_nt(a.GnTot);
@@ -1353,6 +1704,12 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       while (hrun > 8 && bt * cdiv(a.Ho, hrun) * nstrip * a.wsets < 5L * kCUs * 8) hrun = (hrun + 1) / 2;
       const int nhrun = cdiv(a.Ho, hrun);
       const long nunits = bt * nhrun * nstrip;
+      if (conv_split_math()) {      // opt-in split-precision path: f16 pieces forward, bf16 pieces in the data gradient
+        auto kern = conv16_split_kernel<MODE, (MODE == FWD_REP || MODE == FWD_S2)>;
+        const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
+        hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
+        return IDEE_OK;
+      }
       auto kern = conv16_lds_kernel<MODE>;
       const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
       hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
@@ -1553,7 +1910,10 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), (long)d->wsets * gz, wg_per_cu(kern, 256)), d->wsets, gz), \
                        dim3(256), 0, st, a, nstrip, hr2, nhr2);                                               \
   } while (0)
-    if (rep) LSTRIP((wgrad16_strip_kernel<FWD_REP, 3, 1>));
+    const bool split = conv_split_math() && Gb == 1;
+    if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
+    else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSTRIP((wgrad16_split_kernel<FWD_S2, 2>));
+    else if (rep) LSTRIP((wgrad16_strip_kernel<FWD_REP, 3, 1>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO) LSTRIP((wgrad16_strip_kernel<FWD_S2, 2, 1>));
     else if (Gb == 1) LSTRIP((wgrad16_strip_kernel<FWD_S2, 1, 1>));
     else LSTRIP((wgrad16_strip_kernel<FWD_S2, 1, 3>));

@@ -41,8 +41,6 @@ constexpr float kLog2e = 1.4426950408889634f;
 // gfx950 does not co-issue VALU work with the f32 MFMA (measured: tools/micro/coexec.hip), so every VALU instruction of
 // these kernels costs MFMA time.  The element-wise math below is therefore written on f32x4 values so that the compiler
 // emits PACKED f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of work per issue slot).
-__device__ __forceinline__ f32x4 splat(float v) { return f32x4{v, v, v, v}; }
-__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float hsum(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // GELU(erf) with erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. at f32 rounding level):
@@ -233,62 +231,6 @@ __device__ __forceinline__ void mm_lds(f32x4 (&Y)[OT][M], const float* wl, const
 // Operand rounding 2^-18 relative (vs 2^-24 for f32): ~2e-6 relative error per GEMM, 100x inside the 2e-4 activation
 // tolerance the parity tests state; IDEE_SWIN_MATH=f32 selects the exact-f32 kernels.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-// Two piece formats, chosen per kernel (template flag F16):
-//   bf16 pieces (F16 = false): 8 + 8 mantissa bits, f32's exponent range — operand rounding 2^-18; used by the BACKWARD
-//       kernels, whose gradient operands have no a-priori scale;
-//   f16 pieces  (F16 = true): 11 + 11 mantissa bits — operand rounding 2^-22 (f32 level) for |x| in [6e-5, 65504], an
-//       absolute floor of 2^-25 below; used by the FORWARD kernel, whose operands (LayerNorm outputs, weights, softmax,
-//       GELU) are O(1) by construction.
-// An operand fragment is 4 registers = 8 pieces; fragments travel as u32x4 and are bit-cast at the MFMA.
-template <bool F16>
-__device__ __forceinline__ f32x4 mfma_s(u32x4 a, u32x4 b, f32x4 c) {
-  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: low half = a, high half = b
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {    // v_cvt_pk_f16_f32 (RNE)
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, h16x2));
-}
-struct Split { unsigned h01, h23, l01, l23; };
-template <bool F16>
-__device__ __forceinline__ Split split2(f32x4 x) {
-  Split p;
-  if (F16) {
-    p.h01 = cvt_pk_f16(x[0], x[1]);
-    p.h23 = cvt_pk_f16(x[2], x[3]);
-    // residual x - float(hi), exact, one v_fma_mix_f32 per element (the f16 half is read in place: no conversion back)
-    float r0, r1, r2, r3;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p.h01), "v"(x[0]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p.h01), "v"(x[1]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(p.h23), "v"(x[2]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(p.h23), "v"(x[3]));
-    p.l01 = cvt_pk_f16(r0, r1);
-    p.l23 = cvt_pk_f16(r2, r3);
-  } else {
-    p.h01 = cvt_pk_bf16(x[0], x[1]);
-    p.h23 = cvt_pk_bf16(x[2], x[3]);
-    // residual x - float(hi), exact; as v_pk_add_f32 with a negated source (LLVM scalarises a v2f32 fsub, hence the asm)
-    const f32x2 hf01 = {__uint_as_float(p.h01 << 16), __uint_as_float(p.h01 & 0xffff0000u)};
-    const f32x2 hf23 = {__uint_as_float(p.h23 << 16), __uint_as_float(p.h23 & 0xffff0000u)};
-    const f32x2 x01 = {x[0], x[1]}, x23 = {x[2], x[3]};
-    f32x2 r01, r23;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r01) : "v"(x01), "v"(hf01));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r23) : "v"(x23), "v"(hf23));
-    p.l01 = cvt_pk_bf16(r01[0], r01[1]);
-    p.l23 = cvt_pk_bf16(r23[0], r23[1]);
-  }
-  return p;
-}
 __device__ __forceinline__ u32x4 frag_b(const Split& p) { return u32x4{p.h01, p.h23, p.l01, p.l23}; }
 
 // weight tile -> the two A fragments (hi | hi), (lo | lo), stored at ((tile * 2 + piece) * 64 + lane) * 4 words

@@ -158,8 +158,15 @@ def test_fullsize_conv_linearity_and_wgrad_identity():
     conv.dgrad(r, pd, None, dx)
     dw, _ = conv.wgrad(x1, r, w, want_bias=False)
     lhs = float((y1.double() * r.double()).sum())
-    assert abs(lhs - float((x1.double() * dx.double()).sum())) <= 1e-5 * abs(lhs) + 1e-2
-    assert abs(lhs - float((w.double() * dw.double()).sum())) <= 1e-4 * abs(lhs) + 1e-2
+    # the three inner products are sums of ~6e7 signed terms: the exact-f32 kernels agree to 1e-5 of the result; the opt-in
+    # split-precision kernels (IDEE_CONV_MATH=split: bf16 pieces in dgrad / wgrad, 2^-17 per product, unbiased) are allowed
+    # that per-term error accumulated as a random walk
+    import os
+    noise = 0.0
+    if os.environ.get("IDEE_CONV_MATH") == "split":
+        noise = 4 * 2.0 ** -17 * float((y1.double() * r.double()).square().sum().sqrt())
+    assert abs(lhs - float((x1.double() * dx.double()).sum())) <= 1e-5 * abs(lhs) + 1e-2 + noise
+    assert abs(lhs - float((w.double() * dw.double()).sum())) <= 1e-4 * abs(lhs) + 1e-2 + noise
 
 
 def test_fullsize_swin_block_roll_equivariance():
