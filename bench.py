@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
     ap.add_argument("--hw", type=int, default=None, help="override grid height = width")
     ap.add_argument("--encoder", default=None, help="override the config's encoder")
+    ap.add_argument("--math", default="f32", choices=["f32", "split"],
+                    help="f32 (default): convolutions on the exact-f32 MFMA.  split: the opt-in split-precision 16->16 "
+                         "convolution kernels (IDEE_CONV_MATH=split) — a separately labelled line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-entry-point / per-shape time table (stderr)")
     return ap.parse_args()
@@ -229,6 +232,8 @@ def cpu_baseline(cfg, kind, model, T, H, W):
 
 def main():
     a = parse()
+    if a.math == "split":
+        os.environ["IDEE_CONV_MATH"] = "split"          # read by the library at every convolution launch; inherited by ranks
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
     import torch
@@ -345,7 +350,14 @@ def main():
     out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * batch * a.steps / dt, 3),
                unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
                ms_per_step_median=round(statistics.median(step_ms), 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f32", data="synthetic",
+               dtype="f32" if a.math == "f32" else "f32 storage/accumulate, 16->16 convolutions on f16x3 (fwd) / bf16x3 (bwd) split MFMAs",
+               math=dict(conv="exact f32 MFMA (v_mfma_f32_16x16x4_f32)" if a.math == "f32" else
+                              "16->16 convs: two 16-bit pieces per operand, 3 piece products (f16 fwd, bf16 bwd); other convs exact f32 MFMA",
+                         swin_gemm=("exact f32 MFMA" if os.environ.get("IDEE_SWIN_MATH") == "f32" or cfg.en_embed_dim[0] != 16 else
+                                    "two 16-bit pieces per operand, all 4 piece products, f32 accumulate (f16 pieces fwd: 2^-22 operand "
+                                    "rounding; bf16 pieces bwd: 2^-18); attention scores on the f32 MFMA"),
+                         everything_else="f32"),
+               data="synthetic",
                config=dict(workload=f"#{a.config}: {label}, V={cfg.in_channels_dynamic}, batch {batch}/GPU" +
                                     (f", grid overridden to {H}x{W}" if a.hw else ""), global_batch=world * batch,
                            parallelism=f"dp{world}"),

@@ -22,12 +22,15 @@ class SwinGeom(C.Structure):
         ("scale", _F)]
 
 
+_SWIN_PTRS = ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "rel_bias")
+
+
 class SwinParams(C.Structure):
-    _fields_ = [(n, _P) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "rel_bias")]
+    _fields_ = [(n, _P) for n in _SWIN_PTRS + ("path_scale",)]
 
 
 class SwinGrads(C.Structure):
-    _fields_ = SwinParams._fields_
+    _fields_ = [(n, _P) for n in _SWIN_PTRS]
 
 
 class ConvDesc(C.Structure):

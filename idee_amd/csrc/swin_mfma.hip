@@ -28,6 +28,7 @@ struct Geom {
   int shifted;
   float scale;
   float inv_nWhW, inv_nWw, inv_whww, inv_ww;   // reciprocals for the coordinate decode (exact for operands < 2^22)
+  const float* path_scale;   // (batch items, 2) DropPath factors mask / keep_prob of the attention and MLP branch, or null
 };
 
 constexpr float kLnEps = 1e-5f;
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y, v = b % g.V;
+  const float ps1 = g.path_scale ? g.path_scale[2 * b] : 1.f, ps2 = g.path_scale ? g.path_scale[2 * b + 1] : 1.f;
   qkv_w += (long)v * 3 * C * C;  qkv_b += v * 3 * C;
   proj_w += (long)v * C * C;     proj_b += v * C;
   fc1_w += (long)v * HID * C;    fc1_b += v * HID;
@@ -469,8 +471,12 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) Hs[c][m] = X[c][m] + bp[c];
+      for (int m = 0; m < MT; ++m) Hs[c][m] = bp[c];
     mm(Hs, wp, O);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) Hs[c][m] = fma4(Hs[c][m], splat(ps1), X[c][m]);     // shortcut + drop_path(attention branch)
     if (SAVE_H) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -496,8 +502,12 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) Y[c][m] = Hs[c][m] + b2[c];
+      for (int m = 0; m < MT; ++m) Y[c][m] = b2[c];
     mm(Y, w2, A1);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) Y[c][m] = fma4(Y[c][m], splat(ps2), Hs[c][m]);       // x + drop_path(mlp branch)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
       if (t[m].valid)
@@ -529,6 +539,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y, v = b % g.V;
+  const float ps1 = g.path_scale ? g.path_scale[2 * b] : 1.f, ps2 = g.path_scale ? g.path_scale[2 * b + 1] : 1.f;
   qkv_w += (long)v * 3 * C * C;  qkv_b += v * 3 * C;
   proj_w += (long)v * C * C;     proj_b += v * C;
   fc1_w += (long)v * HID * C;    fc1_b += v * HID;
@@ -713,9 +724,13 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
       for (int c = 0; c < CT; ++c) {
         const f32x4 bpc = BIAS(B_P + c);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { Hs[c][m] = X[c][m] + bpc; bO[c][m] = frag_b(split2<true>(O[c][m])); }
+        for (int m = 0; m < MT; ++m) { Hs[c][m] = bpc; bO[c][m] = frag_b(split2<true>(O[c][m])); }
       }
       mm_b<true, CT, CT, MT>(Hs, s_wf, T_P, bO, lane);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) Hs[c][m] = fma4(Hs[c][m], splat(ps1), X[c][m]);   // shortcut + drop_path(attention branch)
     }
     if (SAVE_H) {
 #pragma unroll
@@ -735,7 +750,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
       for (int c = 0; c < CT; ++c) {
         const f32x4 b2c = BIAS(B_2 + c);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { Y[c][m] = Hs[c][m] + b2c; bHN[c][m] = frag_b(split2<true>(HN[c][m])); }
+        for (int m = 0; m < MT; ++m) { Y[c][m] = b2c; bHN[c][m] = frag_b(split2<true>(HN[c][m])); }
       }
       // one hidden 16-block at a time: fc1 -> GELU -> split -> fc2 (the hidden activation never exists as a whole)
 #pragma unroll
@@ -757,6 +772,10 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
           for (int m = 0; m < MT; ++m) Y[c][m] = mfma_s<true>(al, bG[m], Y[c][m]);
         }
       }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) Y[c][m] = fma4(Y[c][m], splat(ps2), Hs[c][m]);     // x + drop_path(mlp branch)
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -838,7 +857,8 @@ template <int C, int M>
 __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
     const float* __restrict__ hs, const float* __restrict__ dy, float* __restrict__ dh, const float* __restrict__ fc1_w,
     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float* __restrict__ g_fc1_w,
-    float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L) {
+    float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L,
+    const float* __restrict__ path_scale) {
   constexpr int CT = C / 16, HID = 4 * C, HT = HID / 16;
   constexpr int HP = 2;                 // hidden 16-blocks per pass (keeps the live set within 256 registers)
   constexpr int TOK = 16 * M;           // tokens per wave and iteration
@@ -855,6 +875,7 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
   fc1_w += (long)v * HID * C;  fc1_b += v * HID;  fc2_w += (long)v * C * HID;
   g_fc1_w += (long)v * HID * C;  g_fc1_b += v * HID;  g_fc2_w += (long)v * C * HID;  g_fc2_b += v * C;
   hs += (long)b * L * C;  dy += (long)b * L * C;  dh += (long)b * L * C;
+  const float ps2 = path_scale ? path_scale[2 * b + 1] : 1.f;
 
   f32x4 aW1[HT][CT], aW2[CT][HT], pb1[HT], pb2[CT];
 #pragma unroll
@@ -909,13 +930,18 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
       for (int m = 0; m < M; ++m) all[m] = true;
       layer_norm_tl(Hs, HN, rstd2, all);
     }
+    f32x4 DYs[CT][M];      // gradient entering the MLP branch: drop_path factor of this batch item times dy
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < M; ++m) DYs[c][m] = DY[c][m] * ps2;
     wave_sync();   // previous iteration's image readers are done
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       put_img<1, M, VSM>(imgHN + c * 16 * VSM, HN[c], lane);
-      put_img<1, M, VSM>(imgDY + c * 16 * VSM, DY[c], lane);
+      put_img<1, M, VSM>(imgDY + c * 16 * VSM, DYs[c], lane);
 #pragma unroll
-      for (int m = 0; m < M; ++m) pb2[c] += DY[c][m];
+      for (int m = 0; m < M; ++m) pb2[c] += DYs[c][m];
     }
     f32x4 dHN[CT][M];
 #pragma unroll
@@ -941,7 +967,7 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
         for (int m = 0; m < M; ++m) { A1[o][m] = b1; dG[o][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
       mm(A1, w1, HN);
-      mm(dG, w2t, DY);
+      mm(dG, w2t, DYs);
 #pragma unroll
       for (int o = 0; o < HP; ++o)
 #pragma unroll
@@ -999,7 +1025,8 @@ template <int C, int M>
 __global__ __launch_bounds__(256, 2) void swin_mlp_bwd_b_kernel(
     const float* __restrict__ hs, const float* __restrict__ dy, float* __restrict__ dh, const float* __restrict__ fc1_w,
     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float* __restrict__ g_fc1_w,
-    float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L) {
+    float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L,
+    const float* __restrict__ path_scale) {
   constexpr int CT = C / 16, HID = 4 * C, HT = HID / 16;
   constexpr int TOK = 16 * M;
   constexpr int IMGW = TOK * kImgRow;   // words per image (one 16-position chunk, TOK token rows)
@@ -1013,6 +1040,7 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_bwd_b_kernel(
   fc1_w += (long)v * HID * C;  fc1_b += v * HID;  fc2_w += (long)v * C * HID;
   g_fc1_w += (long)v * HID * C;  g_fc1_b += v * HID;  g_fc2_w += (long)v * C * HID;  g_fc2_b += v * C;
   hs += (long)b * L * C;  dy += (long)b * L * C;  dh += (long)b * L * C;
+  const float ps2 = path_scale ? path_scale[2 * b + 1] : 1.f;
 
   f32x4 aW1[HT][CT], aW2[CT][HT], pb1[HT], pb2[CT];
 #pragma unroll
@@ -1072,12 +1100,13 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_bwd_b_kernel(
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        const Split sh = split2<false>(HN[c][m]), sd = split2<false>(DY[c][m]);
+        const f32x4 dys = DY[c][m] * ps2;       // gradient entering the MLP branch (drop_path factor of this batch item)
+        const Split sh = split2<false>(HN[c][m]), sd = split2<false>(dys);
         bHN[c][m] = frag_b(sh);
         bDY[c][m] = frag_b(sd);
         put_img_b(imgHN + c * IMGW, 16 * m + j, kq, sh);
         put_img_b(imgDY + c * IMGW, 16 * m + j, kq, sd);
-        pb2[c] += DY[c][m];
+        pb2[c] += dys;
       }
     f32x4 dHN[CT][M];
 #pragma unroll
@@ -1175,6 +1204,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
   rel_bias += (long)v * NH * NW * NW;
   g_qkv_w += (long)v * 3 * C * C;  g_qkv_b += v * 3 * C;  g_proj_w += (long)v * C * C;  g_proj_b += v * C;
   g_rel_bias += (long)v * NH * NW * NW;
+  const float ps1 = g.path_scale ? g.path_scale[2 * b] : 1.f;
 
   // Weight fragments and the relative-position bias tiles live in LDS in lane-fragment order
   // (tile i, lane l -> 16 bytes at (i * 64 + l) * 4): the same for every wave of the workgroup, read with one
@@ -1279,11 +1309,12 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
     mm_lds(QKV, s_wf + W_Q * 256, XN, lane);
     // dO = proj_w^T dH  (TL with the head permutation, like V and O)
     f32x4 DO[CT][MTK];
+    f32x4 DHs[CT][MTK];    // gradient entering the attention branch: drop_path factor of this batch item times dh
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MTK; ++m) { DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; pbp[c] += DH[c][m]; }
-    mm_lds(DO, s_wf + W_PT * 256, DH, lane);
+      for (int m = 0; m < MTK; ++m) { DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f}; DHs[c][m] = DH[c][m] * ps1; pbp[c] += DHs[c][m]; }
+    mm_lds(DO, s_wf + W_PT * 256, DHs, lane);
 
     wave_sync();   // previous iteration's image readers are done
 #pragma unroll
@@ -1446,7 +1477,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_kernel(
 #pragma unroll
     for (int ca = 0; ca < CT; ++ca) {        // dproj_w rows (c) from dH, cols (c') from O
       wave_sync();
-      put_img<1, MTK, VSK>(imgA, DH[ca], lane);
+      put_img<1, MTK, VSK>(imgA, DHs[ca], lane);
       if (ca == 0)
 #pragma unroll
         for (int cb = 0; cb < CT; ++cb) put_img<HPC, MTK, VSK>(imgB + cb * IMG, O[cb], lane);
@@ -1541,6 +1572,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
   rel_bias += (long)v * NH * NW * NW;
   g_qkv_w += (long)v * 3 * C * C;  g_qkv_b += v * 3 * C;  g_proj_w += (long)v * C * C;  g_proj_b += v * C;
   g_rel_bias += (long)v * NH * NW * NW;
+  const float ps1 = g.path_scale ? g.path_scale[2 * b] : 1.f;
 
   constexpr int NRB = NH * TPW * TPW;
   constexpr int W_Q = 0, W_QT = 3 * CT * CT, W_PT = 6 * CT * CT, NWT = 7 * CT * CT;
@@ -1639,11 +1671,11 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 #pragma unroll
         for (int m = 0; m < MTK; ++m) {
           sXN[c][m] = split2<false>(XN[c][m]);
-          sDH[c][m] = split2<false>(DH[c][m]);
+          sDH[c][m] = split2<false>(DH[c][m] * ps1);     // gradient entering the attention branch (drop_path factor of this item)
           bXN[c][m] = frag_b(sXN[c][m]);
           bDH[c][m] = frag_b(sDH[c][m]);
           DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-          pbp[c] += DH[c][m];
+          pbp[c] += DH[c][m] * ps1;
         }
 #pragma unroll
       for (int o = 0; o < 3 * CT; ++o) {
@@ -1927,6 +1959,7 @@ int make_geom(const idee_swin_geom* s, Geom& g, int& NW) {
   g.nWin = (g.Dp / s->wd) * g.nWh * g.nWw;
   g.shifted = (s->sd | s->sh | s->sw) != 0;
   g.scale = s->scale;
+  g.path_scale = nullptr;
   if (NW != 8 && NW != 16 && NW != 32 && NW != 64)
     return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: window volume %d not in {8,16,32,64}", NW);
   g.items = cdiv(g.nWin, 64 / NW);
@@ -1966,6 +1999,7 @@ extern "C" int idee_swin_block_fwd(const float* x, float* y, float* h_save, cons
   IDEE_CHECK_ARG(x && y && p && s, "swin_block_fwd: null argument");
   Geom g; int NW;
   if (int rc = make_geom(s, g, NW)) return rc;
+  g.path_scale = p->path_scale;
   const int C = s->C, NH = s->heads, B = s->N * s->V;
   const bool split = split_math();
   const dim3 grid = swin_grid(cdiv(g.items, 4), B, C == 16 ? (split ? 3 : 2) : 1);
@@ -1995,6 +2029,7 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
   IDEE_CHECK_ARG(x && h_saved && dy && dx && dh_workspace && p && d && s, "swin_block_bwd: null argument");
   Geom g; int NW;
   if (int rc = make_geom(s, g, NW)) return rc;
+  g.path_scale = p->path_scale;
   const int C = s->C, NH = s->heads, B = s->N * s->V;
   const long L = (long)s->D * s->H * s->W;
   hipStream_t st = (hipStream_t)stream;
@@ -2002,15 +2037,15 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
     if (C == 16 && split_math()) {
       const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 2);
       hipLaunchKernelGGL((swin_mlp_bwd_b_kernel<16, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
-                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
+                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L, p->path_scale);
     } else if (C == 16) {   // 32 tokens per wave: half the live registers -> two waves per SIMD overlap GELU with the MFMA chains
       const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 2);
       hipLaunchKernelGGL((swin_mlp_bwd_kernel<16, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
-                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
+                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L, p->path_scale);
     } else if (C == 32) {
       const dim3 grid = swin_grid(cdiv(cdiv(L, 64), 4), B, 1);
       hipLaunchKernelGGL((swin_mlp_bwd_kernel<32, 4>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
-                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L);
+                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L, p->path_scale);
     }
     else return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: C=%d is not built", C);
   }

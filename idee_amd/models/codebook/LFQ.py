@@ -42,14 +42,14 @@ class LFQ(nn.Module):
         self.register_buffer("codebook", bits * 2 - 1, persistent=False)
 
     def indices_to_codes(self, indices, project_out=True):
-        """LFQ.indices_to_codes (LFQ.py:152-181) for index tensors of up to 2 dims, e.g. the
-        `indices_to_codes(LongTensor([0]))` call of train_synthetic.py:193-194 -> (1, dim).
-        A handful of codes: plain tensor indexing, not a kernel."""
-        if indices.ndim >= 3:
-            raise NotImplementedError("idee_amd LFQ.indices_to_codes: image/video index maps are not built")
+        """LFQ.indices_to_codes (LFQ.py:152-181): e.g. the `indices_to_codes(LongTensor([0]))` call of
+        train_synthetic.py:193-194 -> (1, dim); index maps with 3 or more dims return channels-first codes.
+        A table lookup of K codes: plain tensor indexing, not a kernel."""
         codes = self.codebook[indices]
         if project_out:
             codes = codes @ self.project_out.weight.t() + self.project_out.bias
+        if indices.ndim >= 3:      # image / video index maps: codes come back channels-first, 'b ... d -> b d ...' (:177-179)
+            codes = codes.permute(0, codes.ndim - 1, *range(1, codes.ndim - 1))
         return codes
 
     def quantize_tokens(self, z):

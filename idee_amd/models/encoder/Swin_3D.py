@@ -28,7 +28,16 @@ def relative_position_index(ws):
 def _check_no_dropout(training, **rates):
     bad = {k: v for k, v in rates.items() if v and v > 0.0}
     if training and bad:
-        raise NotImplementedError(f"idee_amd: stochastic regularisation {bad} is not built (reference defaults are 0)")
+        raise NotImplementedError(f"idee_amd: element-wise dropout inside the fused Swin block {bad} is not built (reference "
+                                  "defaults are 0); stochastic depth (drop_path_rate) is")
+
+
+def drop_path_factors(n_items, rate, device, generator=None):
+    """timm DropPath (Swin_3D.py:16) as per-sample factors: bernoulli(keep) / keep, two independent draws per item (the
+    attention branch and the MLP branch of a block each call the block's DropPath once, :280-285)."""
+    keep = 1.0 - float(rate)
+    m = (torch.rand((n_items, 2), device=device, generator=generator) < keep).float()
+    return m / keep if keep > 0 else m
 
 
 class PatchMerging(nn.Module):
@@ -71,8 +80,6 @@ class Swin_3D(_stacked.StackedModule):
         self.use_checkpoint = use_checkpoint    # backward always recomputes the block from its input
         if self.patch_size != (1, 1, 1):
             raise NotImplementedError("idee_amd Swin_3D: only patch_size (1,1,1) is built (the reference's setting)")
-        if not qkv_bias:
-            raise NotImplementedError("idee_amd Swin_3D: qkv_bias=False is not built")
         V = in_vars
         self._stages = []
         for s in range(self.num_layers):
@@ -91,6 +98,9 @@ class Swin_3D(_stacked.StackedModule):
                 for name, shape in (("table", (V, L, self.num_heads[s])), ("qkv_w", (V, 3 * C, C)), ("qkv_b", (V, 3 * C)),
                                     ("proj_w", (V, C, C)), ("proj_b", (V, C)), ("fc1_w", (V, hid, C)), ("fc1_b", (V, hid)),
                                     ("fc2_w", (V, C, hid)), ("fc2_b", (V, C))):
+                    if name == "qkv_b" and not qkv_bias:     # nn.Linear(dim, 3 dim, bias=False), Swin_3D.py:137: a zero, untrained bias
+                        self.register_buffer(p + name, torch.zeros(shape), persistent=False)
+                        continue
                     self.register_parameter(p + name, nn.Parameter(torch.zeros(shape)))
             self._stages.append((s, C, in_dim, has_ds))
         E = self.embed_dim[-1]
@@ -131,7 +141,7 @@ class Swin_3D(_stacked.StackedModule):
                     k, p = f"{base}blocks.{b}.", f"s{s}_b{b}_"
                     m += [(k + "attn.relative_position_bias_table", p + "table", v),
                           (k + "attn.relative_position_index", f"s{s}_index", None),
-                          (k + "attn.qkv.weight", p + "qkv_w", v), (k + "attn.qkv.bias", p + "qkv_b", v),
+                          (k + "attn.qkv.weight", p + "qkv_w", v)] + ([(k + "attn.qkv.bias", p + "qkv_b", v)] if self.qkv_bias else []) + [
                           (k + "attn.proj.weight", p + "proj_w", v), (k + "attn.proj.bias", p + "proj_b", v),
                           (k + "mlp.fc1.weight", p + "fc1_w", v), (k + "mlp.fc1.bias", p + "fc1_b", v),
                           (k + "mlp.fc2.weight", p + "fc2_w", v), (k + "mlp.fc2.bias", p + "fc2_b", v)]
@@ -151,8 +161,10 @@ class Swin_3D(_stacked.StackedModule):
     # ---- forward ----
     def forward_tokens(self, x):
         """x (N,V,C,T,H,W) -> channels-last tokens (N,V,T,H,W,E)."""
-        _check_no_dropout(self.training, drop_rate=self.drop_rate, attn_drop_rate=self.attn_drop_rate,
-                          drop_path_rate=self.drop_path_rate)
+        _check_no_dropout(self.training, drop_rate=self.drop_rate, attn_drop_rate=self.attn_drop_rate)
+        # stochastic depth decay rule: block i of sum(depths) gets linspace(0, drop_path_rate)[i] (Swin_3D.py:562)
+        dpr = torch.linspace(0, self.drop_path_rate, sum(self.depths)).tolist()
+        blk = 0
         if x.shape[1] != self.in_vars or x.shape[2] != self.in_chans:
             raise ValueError(f"Swin_3D: expected (N,{self.in_vars},{self.in_chans},T,H,W), got {tuple(x.shape)}")
         t = None
@@ -169,9 +181,13 @@ class Swin_3D(_stacked.StackedModule):
             index = getattr(self, f"s{s}_index")
             for b in range(self.depths[s]):
                 p = f"s{s}_b{b}_"
+                ps = None
+                if self.training and dpr[blk] > 0.0:
+                    ps = drop_path_factors(t.shape[0] * t.shape[1], dpr[blk], t.device)
+                blk += 1
                 t = ops.SwinBlock.apply(t, *(getattr(self, p + n) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w",
                                                                            "fc1_b", "fc2_w", "fc2_b", "table")),
-                                        index, self.num_heads[s], wsz, (0, 0, 0) if b % 2 == 0 else shift, self.qk_scale)
+                                        index, self.num_heads[s], wsz, (0, 0, 0) if b % 2 == 0 else shift, self.qk_scale, ps)
         return ops.ProjVar.apply(t, self.pv_w1, self.pv_b1, self.pv_w2, self.pv_b2)
 
     def forward(self, x):

@@ -192,7 +192,8 @@ class SwinBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, table, index, heads, window, shift,
-                qk_scale):
+                qk_scale, path_scale=None):
+        """path_scale (N*V, 2) | None: DropPath factors (mask / keep_prob) of the attention and MLP branch per batch item."""
         x = _f32c(x)
         params = [_f32c(t) for t in (qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b)]
         table = _f32c(table)
@@ -208,11 +209,14 @@ class SwinBlock(torch.autograd.Function):
         y = torch.empty_like(x)
         need_bwd = any(ctx.needs_input_grad)
         hs = torch.empty_like(x) if need_bwd else None      # block state before the MLP, for the backward
-        sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense))
+        ps = _f32c(path_scale) if path_scale is not None else None
+        if ps is not None and tuple(ps.shape) != (N * V, 2):
+            raise ValueError(f"SwinBlock: path_scale must be ({N * V}, 2), got {tuple(ps.shape)}")
+        sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense), ptr(ps))
         L.call("idee_swin_block_fwd", ptr(x), ptr(y), ptr(hs), C.byref(sp), C.byref(geom), L.stream())
         if need_bwd:
             ctx.save_for_backward(x, *params, table, idx, dense, hs)
-        ctx.geom = geom
+        ctx.geom, ctx.path_scale = geom, ps
         return y
 
     @staticmethod
@@ -225,13 +229,13 @@ class SwinBlock(torch.autograd.Function):
         dh = torch.empty_like(x)
         zs = _zeros_like_many(*params, dense, table)     # one fill for all accumulating gradient buffers
         grads, ddense, dtable = list(zs[:8]), zs[8], zs[9]
-        sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense))
+        sp = L.SwinParams(*[ptr(t) for t in params], ptr(dense), ptr(ctx.path_scale))
         sg = L.SwinGrads(*[ptr(t) for t in grads], ptr(ddense))
         L.call("idee_swin_block_bwd", ptr(x), ptr(hs), ptr(dy), ptr(dx), ptr(dh), C.byref(sp), C.byref(sg), C.byref(geom),
                L.stream())
         V, heads, Nw, _ = dense.shape
         L.call("idee_relpos_bias_scatter", ptr(ddense), ptr(idx), ptr(dtable), V, table.shape[1], heads, Nw, L.stream())
-        return (dx, *grads, dtable, None, None, None, None, None)
+        return (dx, *grads, dtable, None, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------------------

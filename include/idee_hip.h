@@ -85,6 +85,8 @@ typedef struct {
   const float *fc1_w, *fc1_b;   /* (V, hidden, C), (V, hidden) mlp.fc1   */
   const float *fc2_w, *fc2_b;   /* (V, C, hidden), (V, C)    mlp.fc2     */
   const float* rel_bias;        /* (V, heads, Nw, Nw) dense bias from idee_relpos_bias_gather */
+  const float* path_scale;      /* (N*V, 2) | NULL: DropPath factors mask / keep_prob of the attention and the MLP branch of
+                                   every batch item (timm DropPath, Swin_3D.py:16, :280-285); NULL = no stochastic depth */
 } idee_swin_params;
 
 typedef struct { /* all accumulate */

@@ -128,8 +128,10 @@ def window_attention(xw, sd, pre, num_heads, mask=None, qk_scale=None):
     return F.linear(out, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
 
 
-def swin_block(x, sd, pre, num_heads, window_size, shift_size, qk_scale=None):
-    """SwinTransformerBlock3D.forward, Swin_3D.py:224-287 (drop rates 0).  x (B,D,H,W,C)."""
+def swin_block(x, sd, pre, num_heads, window_size, shift_size, qk_scale=None, path_scale=None):
+    """SwinTransformerBlock3D.forward, Swin_3D.py:224-287 (dropout rates 0).  x (B,D,H,W,C).
+    path_scale (B, 2) | None: the DropPath factors mask / keep_prob timm's DropPath (:16) would draw for the attention
+    branch (:280) and the MLP branch (:265, :285) of every sample."""
     B, D, H, W, C = x.shape
     ws, ss = get_window_size((D, H, W), window_size, shift_size)
     h = F.layer_norm(x, (C,))                                  # norm1, non-affine :229-231
@@ -146,11 +148,15 @@ def swin_block(x, sd, pre, num_heads, window_size, shift_size, qk_scale=None):
     if shifted:
         h = torch.roll(h, shifts=ss, dims=(1, 2, 3))
     h = h[:, :D, :H, :W]
+    if path_scale is not None:
+        h = h * path_scale[:, 0].reshape(B, 1, 1, 1, 1)
     x = x + h                                                   # :280
     m = F.layer_norm(x, (C,))                                   # norm2 non-affine
     m = F.linear(m, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
     m = F.gelu(m)                                               # exact erf GELU, Swin_3D.py:31
     m = F.linear(m, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if path_scale is not None:
+        m = m * path_scale[:, 1].reshape(B, 1, 1, 1, 1)
     return x + m                                                # :285
 
 

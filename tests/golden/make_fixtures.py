@@ -434,6 +434,32 @@ def fx_vq(tag, K, training, seed):
     save("vq_" + tag, **out)
 
 
+def fx_misc(seed=1300):
+    """Small API corners: LFQ.indices_to_codes on a video-shaped index map (LFQ.py:152-181) and a Swin block built with
+    qkv_bias=False (WindowAttention3D, Swin_3D.py:137)."""
+    out = {}
+    q = RefLFQ(dim=16, codebook_size=4, entropy_loss_weight=0.1, diversity_gamma=0.1, commitment_loss_weight=3.0)
+    rerandomise(q, seed)
+    idx = torch.randint(0, 4, (2, 3, 4, 5), generator=torch.Generator().manual_seed(seed))
+    out.update({"lfq/indices": idx, "lfq/codes": q.indices_to_codes(idx).detach(), "lfq/codes_flat": q.indices_to_codes(idx[0, 0, 0]).detach()})
+    out.update(sd_arrays(q, prefix="lfq/sd/"))
+    blk = ref_swin.SwinTransformerBlock3D(16, 2, window_size=(2, 4, 4), shift_size=(1, 2, 2), qkv_bias=False)
+    rerandomise(blk, seed + 1)
+    x = rand((1, 8, 8, 8, 16), seed + 2).requires_grad_()
+    mask = ref_swin.compute_mask(8, 8, 8, (2, 4, 4), (1, 2, 2), x.device)
+    y = blk(x, mask)
+    r = rand(y.shape, seed + 3)
+    (y * r).sum().backward()
+    out.update({"nobias/x": x.detach(), "nobias/y": y.detach(), "nobias/r": r, "nobias/dx": x.grad})
+    out.update(sd_arrays(blk, prefix="nobias/sd/"))
+    out.update({"nobias/grad/" + k: p.grad for k, p in blk.named_parameters()})
+    save("misc", **out)
+
+
+if __name__ == "__main__" and "--misc-only" in sys.argv:
+    fx_misc()
+
+
 def fx_vq_ema(seed=830):
     """The reference VQ with the EMA codebook update (ema_update=True, learnable_codebook=False), k-means initialisation and
     dead-code expiry, its sample choices made deterministic by substituting `sample_fn` (the first `num` batch samples) —
@@ -610,7 +636,7 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
 
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
-                                                                "--era5-only", "--hier-only", "--vqema-only")):
+                                                                "--era5-only", "--hier-only", "--vqema-only", "--misc-only")):
     main()
     fx_swin_hier("16_32", (16, 32), 1200)
     fx_swin_hier("32_16", (32, 16), 1210)
@@ -621,4 +647,5 @@ if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "
     fx_vq("k2_eval", 2, False, 810)
     fx_vq("k8_train", 8, True, 820)
     fx_vq_ema()
+    fx_misc()
     fx_evaluators()

@@ -795,3 +795,76 @@ def test_vq_ema_kmeans_expire_golden(tag):
         for k in ("_codebook.embed", "_codebook.cluster_size", "_codebook.embed_avg"):
             close(f"step {step} {k}", sd[k], g("sd/" + k), atol=2e-5, rtol=1e-4)
         assert bool(sd["_codebook.initted"])
+
+
+def test_swin_block_qkv_bias_false_golden():
+    """SwinTransformerBlock3D built with qkv_bias=False (Swin_3D.py:137): the kernels get a zero, untrained bias."""
+    ops = _ops()
+    a, _, _ = load_golden("misc")
+    sd = {k[10:]: v for k, v in a.items() if k.startswith("nobias/sd/")}
+    grads = {k[12:]: v for k, v in a.items() if k.startswith("nobias/grad/")}
+    assert "attn.qkv.bias" not in sd
+    names = ["attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+             "mlp.fc2.weight", "mlp.fc2.bias", "attn.relative_position_bias_table"]
+    params = [(dev(sd[n]).unsqueeze(0).contiguous().requires_grad_() if n in sd else torch.zeros(1, 48, device=DEV)) for n in names]
+    x = dev(a["nobias/x"]).unsqueeze(1).contiguous().requires_grad_()
+    y = ops.SwinBlock.apply(x, *params, dev(sd["attn.relative_position_index"]), 2, (2, 4, 4), (1, 2, 2), None)
+    close("y", y[:, 0], a["nobias/y"])
+    (y[:, 0] * dev(a["nobias/r"])).sum().backward()
+    gclose("dx", x.grad[:, 0], a["nobias/dx"])
+    for p_, n in zip(params, names):
+        if n in grads:
+            gclose("d" + n, p_.grad[0], grads[n])
+
+
+@pytest.mark.parametrize("C", [16, 32])
+def test_swin_block_drop_path_vs_oracle(C):
+    """Stochastic depth: the kernels take the per-sample DropPath factors (mask / keep_prob, incl. dropped samples = 0) of
+    both residual branches; forward and every gradient against the oracle with the same factors.  C = 32 runs the exact-f32
+    kernels, C = 16 the split-precision ones."""
+    from oracle import idee_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(70 + C)
+    N, V, D, H, W, NH = 3, 2, 8, 8, 12, 2
+    x = torch.randn((N, V, D, H, W, C), generator=g)
+    r = torch.randn((N, V, D, H, W, C), generator=g)
+    shapes = {"attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,), "attn.proj.weight": (C, C), "attn.proj.bias": (C,),
+              "mlp.fc1.weight": (4 * C, C), "mlp.fc1.bias": (4 * C,), "mlp.fc2.weight": (C, 4 * C), "mlp.fc2.bias": (C,),
+              "attn.relative_position_bias_table": (147, 2)}
+    sds = [{k: (torch.randn(s, generator=g) * (0.7 / s[-1] ** 0.5 if len(s) > 1 else 0.1)).requires_grad_() for k, s in shapes.items()} for _ in range(V)]
+    ps = torch.tensor([[2.0, 0.0], [0.0, 2.0], [2.0, 2.0], [0.0, 0.0], [1.25, 1.25], [1.0, 1.0]])      # (N*V, 2), item b = n*V + v
+    index = O.relative_position_index((2, 4, 4))
+    xr = x.clone().requires_grad_()
+    outs = []
+    for v in range(V):
+        sdv = dict(sds[v]); sdv["attn.relative_position_index"] = index
+        outs.append(O.swin_block(xr[:, v], sdv, "", NH, (2, 4, 4), (1, 2, 2), path_scale=ps.reshape(N, V, 2)[:, v]))
+    yo = torch.stack(outs, 1)
+    (yo * r).sum().backward()
+    names = list(shapes)
+    params = [torch.stack([sds[v][n].detach() for v in range(V)]).to(DEV).requires_grad_() for n in names]
+    xd = x.to(DEV).requires_grad_()
+    y = ops.SwinBlock.apply(xd, *params, index.to(DEV), NH, (2, 4, 4), (1, 2, 2), None, ps.to(DEV))
+    close("y", y, yo)
+    assert torch.equal(y[1, 1].cpu(), x[1, 1]), "a sample with both branches dropped passes through unchanged"
+    (y * r.to(DEV)).sum().backward()
+    gclose("dx", xd.grad, xr.grad)
+    for p_, n in zip(params, names):
+        gclose("d" + n, p_.grad, torch.stack([sds[v][n].grad for v in range(V)]))
+
+
+def test_swin_encoder_drop_path_rate_module():
+    """Swin_3D(drop_path_rate > 0): identity in eval mode, stochastic in training (the decay rule gives block 0 rate 0)."""
+    from idee_amd.models.encoder.Swin_3D import Swin_3D
+    torch.manual_seed(3)
+    enc = Swin_3D(in_vars=2, in_chans=1, drop_path_rate=0.5).to(DEV)
+    x = torch.randn(4, 2, 1, 8, 8, 8, device=DEV)
+    enc.eval()
+    with torch.no_grad():
+        y0, y1 = enc(x), enc(x)
+    assert torch.equal(y0, y1)
+    enc.train()
+    ya, yb = enc(x), enc(x)
+    assert not torch.equal(ya, yb) and torch.isfinite(ya).all()
+    ya.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())

@@ -173,3 +173,21 @@ def test_bench_refuses_rank_count_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
                        env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"metric"' not in r.stdout
+
+
+def test_lfq_indices_to_codes_video_map_and_qkv_bias_false_keys():
+    """LFQ.indices_to_codes on an index map with >= 3 dims returns channels-first codes (LFQ.py:152-181; golden), and a
+    Swin_3D built with qkv_bias=False has no attn.qkv.bias keys (nn.Linear(bias=False), Swin_3D.py:137)."""
+    from idee_amd.models.codebook.LFQ import LFQ
+    from idee_amd.models.encoder.Swin_3D import Swin_3D
+    a, _, _ = load_golden("misc")
+    q = LFQ(dim=16, codebook_size=4, entropy_loss_weight=0.1, diversity_gamma=0.1, commitment_loss_weight=3.0)
+    q.load_state_dict({k[7:]: v for k, v in a.items() if k.startswith("lfq/sd/")}, strict=True)
+    codes = q.indices_to_codes(a["lfq/indices"])
+    assert tuple(codes.shape) == (2, 16, 3, 4, 5)
+    torch.testing.assert_close(codes, a["lfq/codes"], atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(q.indices_to_codes(a["lfq/indices"][0, 0, 0]), a["lfq/codes_flat"], atol=1e-6, rtol=1e-6)
+    enc = Swin_3D(in_vars=2, in_chans=1, qkv_bias=False)
+    keys = set(enc.state_dict())
+    assert not any(k.endswith("attn.qkv.bias") for k in keys) and any(k.endswith("attn.qkv.weight") for k in keys)
+    assert not any(n.endswith("qkv_b") for n, _ in enc.named_parameters())
