@@ -62,8 +62,9 @@ _SIGS = {
     "idee_conv_dgrad_add": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "idee_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "idee_conv_unpack_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P]),
-    "idee_ln_relu_res_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P]),
-    "idee_ln_relu_res_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P]),
+    "idee_ln_relu_res_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
+    "idee_ln_relu_res_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
+    "idee_dropout_mask_": (_I, [_P, _L, _F, C.c_uint64, _P]),
     "idee_lfq_workspace_floats": (_L, [_L, _I]),
     "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P]),
     "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _P]),

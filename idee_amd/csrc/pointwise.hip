@@ -726,10 +726,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 template <int E>
 __global__ __launch_bounds__(256) void ln_relu_res_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ sc,
-                                                              float* __restrict__ y, int V, long L) {
+                                                              float* __restrict__ y, int V, long L,
+                                                              const float* __restrict__ item_scale) {
   // E/4 adjacent lanes per token, 4 channels each (contiguous 16-byte streams in and out)
   constexpr int QE = E / 4;
   const int b = blockIdx.y, v = b % V, q = threadIdx.x % QE;
+  const float ps = item_scale ? item_scale[b] : 1.f;      // DropPath factor of this batch item (encoder/CNN_3D.py:140,142)
   const f32x4 gv = ld4(gamma + v * E + 4 * q), bv = ld4(beta + v * E + 4 * q);
   const long base = (long)b * L * E;
   for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(256) void ln_relu_res_fwd_kernel(const float* __res
     const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
     f32x4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = s4[k] + fmaxf(fmaf((x[k] - mean) * rstd, gv[k], bv[k]), 0.f);
+    for (int k = 0; k < 4; ++k) o[k] = fmaf(fmaxf(fmaf((x[k] - mean) * rstd, gv[k], bv[k]), 0.f), ps, s4[k]);
     st4(y + off, o);
   }
 }
@@ -751,9 +753,11 @@ template <int E>
 __global__ __launch_bounds__(256) void ln_relu_res_bwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ dy,
                                                               float* __restrict__ dc, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int V, long L) {
+                                                              float* __restrict__ dbeta, int V, long L,
+                                                              const float* __restrict__ item_scale) {
   constexpr int QE = E / 4;
   const int b = blockIdx.y, v = b % V, q = threadIdx.x % QE;
+  const float ps = item_scale ? item_scale[b] : 1.f;
   const f32x4 gv = ld4(gamma + v * E + 4 * q), bv = ld4(beta + v * E + 4 * q);
   const long base = (long)b * L * E;
   f32x4 gg = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(256) void ln_relu_res_bwd_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       xn[k] = (x[k] - mean) * rstd;
-      const float du = fmaf(xn[k], gv[k], bv[k]) > 0.f ? g[k] : 0.f;
+      const float du = fmaf(xn[k], gv[k], bv[k]) > 0.f ? g[k] * ps : 0.f;
       gg[k] = fmaf(du, xn[k], gg[k]);
       gb[k] += du;
       dxn[k] = du * gv[k];
@@ -794,6 +798,26 @@ __global__ __launch_bounds__(256) void ln_relu_res_bwd_kernel(const float* __res
     if (lane < QE) { atomicAdd(dgamma + v * E + 4 * q + k, a); atomicAdd(dbeta + v * E + 4 * q + k, bb); }
   }
 }
+
+// -------------------------------------------------------------------------------------------
+// nn.Dropout of the classifier heads (classifier/CNN_3D.py:41, :53 — after the first ReLU): x <- x * keep-mask, IN PLACE, the
+// 1 / (1 - p) factor being folded into the next convolution's weights by the caller.  Because the input is a ReLU output,
+// the masked activation alone carries both masks for the backward pass (x_masked > 0 <=> ReLU active and kept).
+// Counter-based generator: element i of call `seed` keeps iff hash(seed, i) >= p * 2^32 (murmur3 finaliser).
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ x, long n4, unsigned thr, unsigned long long seed) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = ld4(x + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned long long h = (unsigned long long)(4 * i + k) ^ (seed * 0x9E3779B97F4A7C15ull);
+      h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+      if ((unsigned)h < thr) v[k] = 0.f;
+    }
+    st4(x + 4 * i, v);
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 // Euclidean nearest-neighbour vector quantisation (models/codebook/VQ.py: cdist :44-48, argmax of -dist
 // in EuclideanCodebook.forward :477-555, straight-through :986, commitment mse :1056), reference defaults:
@@ -1465,25 +1489,36 @@ extern "C" int idee_adam_step(float* p, const float* g, float* m, float* v, long
 }
 
 extern "C" int idee_ln_relu_res_fwd(const float* c, const float* gamma, const float* beta, const float* shortcut, float* y,
-                                    int B, int V, long L, int E, idee_stream_t stream) {
+                                    int B, int V, long L, int E, const float* item_scale, idee_stream_t stream) {
   IDEE_CHECK_ARG(c && gamma && beta && shortcut && y && B > 0 && V > 0 && L > 0, "ln_relu_res_fwd: bad argument");
   const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, B)), B);
-  if (E == 16) hipLaunchKernelGGL((ln_relu_res_fwd_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, shortcut, y, V, L);
-  else if (E == 32) hipLaunchKernelGGL((ln_relu_res_fwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, shortcut, y, V, L);
+  if (E == 16) hipLaunchKernelGGL((ln_relu_res_fwd_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, shortcut, y, V, L, item_scale);
+  else if (E == 32) hipLaunchKernelGGL((ln_relu_res_fwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, shortcut, y, V, L, item_scale);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "ln_relu_res: E=%d not built", E);
   IDEE_LAUNCH_CHECK("ln_relu_res_fwd");
   return IDEE_OK;
 }
 
 extern "C" int idee_ln_relu_res_bwd(const float* c, const float* gamma, const float* beta, const float* dy, float* dc,
-                                    float* dgamma, float* dbeta, int B, int V, long L, int E, idee_stream_t stream) {
+                                    float* dgamma, float* dbeta, int B, int V, long L, int E, const float* item_scale,
+                                    idee_stream_t stream) {
   IDEE_CHECK_ARG(c && gamma && beta && dy && dc && dgamma && dbeta && B > 0 && V > 0 && L > 0, "ln_relu_res_bwd: bad argument");
   const int per_cu = E == 16 ? wg_per_cu(ln_relu_res_bwd_kernel<16>) : wg_per_cu(ln_relu_res_bwd_kernel<32>);
   const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * per_cu, B)), B);
-  if (E == 16) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L);
-  else if (E == 32) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L);
+  if (E == 16) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L, item_scale);
+  else if (E == 32) hipLaunchKernelGGL((ln_relu_res_bwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, c, gamma, beta, dy, dc, dgamma, dbeta, V, L, item_scale);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "ln_relu_res: E=%d not built", E);
   IDEE_LAUNCH_CHECK("ln_relu_res_bwd");
+  return IDEE_OK;
+}
+
+
+extern "C" int idee_dropout_mask_(float* x, long n, float p, uint64_t seed, idee_stream_t stream) {
+  IDEE_CHECK_ARG(x && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f, "dropout_mask_: bad argument (n must be a multiple of 4, 0 <= p < 1)");
+  const unsigned thr = (unsigned)((double)p * 4294967296.0);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, thr,
+                     (unsigned long long)seed);
+  IDEE_LAUNCH_CHECK("dropout_mask_");
   return IDEE_OK;
 }
 

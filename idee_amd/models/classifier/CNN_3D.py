@@ -59,23 +59,29 @@ class CNN_3D(_stacked.StackedModule):
                 m += [(f"layers.{v}.conv{i}.weight", f"h_w{i}", v), (f"layers.{v}.conv{i}.bias", f"h_b{i}", v)]
         return m
 
+    def _dropout_args(self):
+        """(p, seed) of nn.Dropout(drop_rate) after the first ReLU of the joint head and of every per-variable head
+        (classifier/CNN_3D.py:41,53,93,133): active in training only; the seed of the counter-based mask generator is drawn
+        from torch's default generator, so torch.manual_seed makes runs repeatable."""
+        if self.training and self.drop_rate and self.drop_rate > 0:
+            if self.drop_rate >= 1:
+                raise ValueError("classifier: drop_rate must be < 1")
+            return float(self.drop_rate), int(torch.randint(0, 2 ** 62, (1,)).item())
+        return 0.0, 0
+
     def forward_tokens(self, zq):
         """zq (N,V,T,H,W,C) channels-last -> (z (N,1,H,W), [y_v (N,1,H,W)] * V)."""
-        if self.training and self.drop_rate and self.drop_rate > 0:
-            raise NotImplementedError("idee_amd classifier: dropout > 0 is not built (cls_drop_rate default is 0)")
         z, y = ops.ClassifierHeads.apply(zq, self.j_w1, self.j_b1, self.j_w2, self.j_b2, self.j_w3, self.j_b3, self.h_w1,
-                                         self.h_b1, self.h_w2, self.h_b2, self.h_w3, self.h_b3)
+                                         self.h_b1, self.h_w2, self.h_b2, self.h_w3, self.h_b3, *self._dropout_args())
         return z, [y[:, v:v + 1] for v in range(self.in_var)]      # (N,1,H,W) each; (N,1,T/8,H,W) when T > 8, as the reference
 
     def forward_signs(self, signs, project_out):
         """The same outputs as forward_tokens(z_q) for z_q = project_out(signs): LFQ's output has rank
         codebook_dim per variable, so conv1 of every head runs on the (N,T,H,W,16)-channel sign field with
         weights folded through project_out (ops.ClassifierHeadsSigns).  signs (N,V,T,H,W,d)."""
-        if self.training and self.drop_rate and self.drop_rate > 0:
-            raise NotImplementedError("idee_amd classifier: dropout > 0 is not built (cls_drop_rate default is 0)")
         z, y = ops.ClassifierHeadsSigns.apply(signs, project_out.weight, project_out.bias, self.j_w1, self.j_b1, self.j_w2,
                                               self.j_b2, self.j_w3, self.j_b3, self.h_w1, self.h_b1, self.h_w2, self.h_b2,
-                                              self.h_w3, self.h_b3)
+                                              self.h_w3, self.h_b3, *self._dropout_args())
         return z, [y[:, v:v + 1] for v in range(self.in_var)]
 
     def forward(self, x):

@@ -87,8 +87,8 @@ class CNN_3D(_stacked.StackedModule):
 
     def forward_tokens(self, x):
         """x (N,V,C,T,H,W) -> channels-last tokens (N,V,T,H,W,E)."""
-        if self.training and (self.drop_rate > 0 or self.drop_path_rate > 0):
-            raise NotImplementedError("idee_amd CNN_3D: dropout / stochastic depth > 0 is not built (reference defaults are 0)")
+        # drop_rate is stored but never applied by the reference's conv_block.forward (encoder/CNN_3D.py:96, :120-144): a no-op
+        # here too.  drop_path_rate: every block's two units call DropPath(drop_path_rate) (:97, :140, :142).
         if x.shape[1] != self.in_vars or x.shape[2] != self.in_channels[0]:
             raise ValueError(f"CNN_3D: expected (N,{self.in_vars},{self.in_channels[0]},T,H,W), got {tuple(x.shape)}")
         t = None
@@ -98,8 +98,12 @@ class CNN_3D(_stacked.StackedModule):
             elif l == 0:
                 raise NotImplementedError("idee_amd CNN_3D: in_channels == out_channels[0] (no patch embedding) is not built")
             for u in (1, 2):
+                ps = None
+                if self.training and self.drop_path_rate > 0:
+                    from .Swin_3D import drop_path_factors
+                    ps = drop_path_factors(t.shape[0] * t.shape[1], self.drop_path_rate, t.device)[:, 0].contiguous()
                 t = ops.ConvLNUnit.apply(t, getattr(self, f"l{l}_conv{u}_w"), getattr(self, f"l{l}_norm{u}_g"),
-                                         getattr(self, f"l{l}_norm{u}_b"))
+                                         getattr(self, f"l{l}_norm{u}_b"), ps)
         return ops.ProjVar.apply(t, self.pv_w1, self.pv_b1, self.pv_w2, self.pv_b2)
 
     def forward(self, x):

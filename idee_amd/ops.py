@@ -329,6 +329,11 @@ class ProjVar(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2
 
 
+def _dropout_(t, p, seed):
+    """nn.Dropout's mask applied in place to a ReLU output (the 1/(1-p) factor is folded into the next conv's weights)."""
+    L.call("idee_dropout_mask_", ptr(t), t.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, L.stream())
+
+
 class ClassifierHeads(torch.autograd.Function):
     """The whole classifier: joint head on the V*C channels + V per-variable heads, each
     conv(2,3,3)s(2,1,1) -> ReLU -> conv -> ReLU -> conv -> squeeze.  Reference:
@@ -339,9 +344,14 @@ class ClassifierHeads(torch.autograd.Function):
     -> z (N,1,H,W), y (N,V,H,W)"""
 
     @staticmethod
-    def forward(ctx, zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3):
+    def forward(ctx, zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3, drop_p=0.0, drop_seed=0):
+        """drop_p, drop_seed: nn.Dropout(drop_rate) after the first ReLU of every head (classifier/CNN_3D.py:41,53,93,133) in
+        training: keep-mask in place on the activation, 1/(1-p) folded into conv2's weights."""
         ts = [_f32c(t) for t in (zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3)]
         zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3 = ts
+        inv = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        if drop_p > 0:
+            jw2, hw2 = jw2 * inv, hw2 * inv
         N, V, T, H, W, Cc = zq.shape
         dim = hw1.shape[1]
         Dj = jw1.shape[0]
@@ -371,13 +381,17 @@ class ClassifierHeads(torch.autograd.Function):
         ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=torch.float32)
         y = torch.empty((N, V, H, W) if T3 == 1 else (N, V, T3, H, W), device=dev, dtype=torch.float32)
         j1.fwd(zq, packs[0][0], jb1, ja1)
+        if drop_p > 0:
+            _dropout_(ja1, drop_p, drop_seed)
         j2.fwd(ja1, packs[1][0], jb2, ja2)
         j3.fwd(ja2, packs[2][0], jb3, z)
         h1.fwd(zq, packs[3][0], hb1, ha1)
+        if drop_p > 0:
+            _dropout_(ha1, drop_p, drop_seed + 1)
         h2.fwd(ha1, packs[4][0], hb2, ha2)
         h3.fwd(ha2, packs[5][0], hb3, y)
         ctx.save_for_backward(zq, ja1, ja2, ha1, ha2, *weights, *[p[1] for p in packs])
-        ctx.convs = convs
+        ctx.convs, ctx.inv = convs, inv
         return z, y
 
     @staticmethod
@@ -409,8 +423,10 @@ class ClassifierHeads(torch.autograd.Function):
             dzq = torch.empty_like(zq)
             j1.dgrad(dja1, pd[0], None, dzq)
             h1.dgrad(dha1, pd[3], None, dzq, accumulate=True)
+        if ctx.inv != 1.0:      # conv2 ran with weights * 1/(1-p)
+            djw2, dhw2 = djw2 * ctx.inv, dhw2 * ctx.inv
         return (dzq, djw1, djb1.reshape(-1), djw2, djb2.reshape(-1), djw3, djb3.reshape(-1), dhw1, dhb1, dhw2, dhb2, dhw3,
-                dhb3)
+                dhb3, None, None)
 
 
 class ClassifierHeadsSigns(torch.autograd.Function):
@@ -422,9 +438,12 @@ class ClassifierHeadsSigns(torch.autograd.Function):
       signs (N,V,T,H,W,D) +-1;  w_out (C,D), b_out (C): LFQ.project_out;  remaining arguments as ClassifierHeads."""
 
     @staticmethod
-    def forward(ctx, signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3):
+    def forward(ctx, signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3, drop_p=0.0, drop_seed=0):
         ts = [_f32c(t) for t in (signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3)]
         signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3 = ts
+        inv = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0      # nn.Dropout after the first ReLU, as ClassifierHeads
+        if drop_p > 0:
+            jw2, hw2 = jw2 * inv, hw2 * inv
         N, V, T, H, W, D = signs.shape
         Cc = w_out.shape[0]
         dim = hw1.shape[1]
@@ -467,14 +486,18 @@ class ClassifierHeadsSigns(torch.autograd.Function):
         ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=torch.float32)
         y = torch.empty((N, V, H, W) if T3 == 1 else (N, V, T3, H, W), device=dev, dtype=torch.float32)
         j1.fwd(sx, packs[0][0], jb1, ja1)
+        if drop_p > 0:
+            _dropout_(ja1, drop_p, drop_seed)
         j2.fwd(ja1, packs[1][0], jb2, ja2)
         j3.fwd(ja2, packs[2][0], jb3, z)
         h1.fwd(sx, packs[3][0], hb1.reshape(-1), ha1)
+        if drop_p > 0:
+            _dropout_(ha1, drop_p, drop_seed + 1)
         h2.fwd(ha1, packs[4][0], hb2, ha2)
         h3.fwd(ha2, packs[5][0], hb3, y)
         pd = [p[1] if p[1] is not None else torch.empty(0, device=dev) for p in packs]
         ctx.save_for_backward(sx, ja1, ja2, ha1, ha2, jw1, hw1, w_out, b_out, *weights, *pd)
-        ctx.convs = convs
+        ctx.convs, ctx.inv = convs, inv
         ctx.geom = (N, V, T, H, W, D, CS, Cc, dim, Dj)
         return z, y
 
@@ -517,8 +540,10 @@ class ClassifierHeadsSigns(torch.autograd.Function):
             h1.dgrad(dha1, pd[3], None, dsx, accumulate=True)
             dsigns = torch.empty((N, V, T, H, W, D), device=dev, dtype=torch.float32)
             L.call("idee_lfq_sign_field_bwd", ptr(dsx), ptr(dsigns), N, V, T, H * W, D, CS, st)
+        if ctx.inv != 1.0:      # conv2 ran with weights * 1/(1-p)
+            djw2, dhw2 = djw2 * ctx.inv, dhw2 * ctx.inv
         return (dsigns, dw_out, db_out, djw1, djb1.reshape(-1), djw2, djb2.reshape(-1), djw3, djb3.reshape(-1), dhw1,
-                dhb1.reshape(V, dim), dhw2, dhb2, dhw3, dhb3)
+                dhb1.reshape(V, dim), dhw2, dhb2, dhw3, dhb3, None, None)
 
 
 # ----------------------------------------------------------------------------------------
@@ -647,8 +672,10 @@ class ConvLNUnit(torch.autograd.Function):
     Reference: conv_block.forward, models/encoder/CNN_3D.py:131-142."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta):
+    def forward(ctx, x, w, gamma, beta, item_scale=None):
+        """item_scale (N*V,) | None: DropPath factors mask / keep_prob of the ReLU(LN(conv)) branch per batch item."""
         x, w, gamma, beta = (_f32c(t) for t in (x, w, gamma, beta))
+        item_scale = _f32c(item_scale) if item_scale is not None else None
         N, V, T, H, W, Cc = x.shape
         s = _cl_strides(T, H, W, Cc)
         conv = ConvLayer(L.CONV_K333_REPLICATE, N * V, V, T, H, W, Cc, Cc, s, s, False)
@@ -656,9 +683,10 @@ class ConvLNUnit(torch.autograd.Function):
         c = torch.empty_like(x)
         conv.fwd(x, pf, None, c)
         y = torch.empty_like(x)
-        L.call("idee_ln_relu_res_fwd", ptr(c), ptr(gamma), ptr(beta), ptr(x), ptr(y), N * V, V, T * H * W, Cc, L.stream())
+        L.call("idee_ln_relu_res_fwd", ptr(c), ptr(gamma), ptr(beta), ptr(x), ptr(y), N * V, V, T * H * W, Cc, ptr(item_scale),
+               L.stream())
         ctx.save_for_backward(x, c, w, gamma, beta, pd)
-        ctx.conv = conv
+        ctx.conv, ctx.item_scale = conv, item_scale
         return y
 
     @staticmethod
@@ -670,13 +698,13 @@ class ConvLNUnit(torch.autograd.Function):
         dc = torch.empty_like(c)
         dgamma, dbeta = _zeros_like_many(gamma, beta)
         L.call("idee_ln_relu_res_bwd", ptr(c), ptr(gamma), ptr(beta), ptr(dy), ptr(dc), ptr(dgamma), ptr(dbeta), N * V, V,
-               T * H * W, Cc, L.stream())
+               T * H * W, Cc, ptr(ctx.item_scale), L.stream())
         dw, _ = conv.wgrad(x, dc, w, want_bias=False)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(dy)            # shortcut gradient (dy) + the conv's data gradient, without a copy of dy
             conv.dgrad_add(dc, pd, dy, dx)
-        return dx, dw, dgamma, dbeta
+        return dx, dw, dgamma, dbeta, None
 
 
 class VQNearest(torch.autograd.Function):

@@ -181,9 +181,14 @@ int idee_conv_unpack_wgrad(const idee_conv_desc* d, const float* dw_packed, floa
  * bwd: dc overwritten; dgamma, dbeta accumulate; d(shortcut) = dy is the caller's.
  * ---------------------------------------------------------------------------------------- */
 int idee_ln_relu_res_fwd(const float* c, const float* gamma, const float* beta, const float* shortcut, float* y, int B,
-                         int V, long L, int E, idee_stream_t stream);
+                         int V, long L, int E, const float* item_scale, idee_stream_t stream);
 int idee_ln_relu_res_bwd(const float* c, const float* gamma, const float* beta, const float* dy, float* dc, float* dgamma,
-                         float* dbeta, int B, int V, long L, int E, idee_stream_t stream);
+                         float* dbeta, int B, int V, long L, int E, const float* item_scale, idee_stream_t stream);
+/* item_scale (B) | NULL: DropPath factor mask / keep_prob of each batch item on the ReLU(LN(c)) branch (CNN_3D.py:97,140,142) */
+
+/* nn.Dropout after the first ReLU of the classifier heads (classifier/CNN_3D.py:41,53): x <- x * keep-mask IN PLACE (the caller
+ * folds 1 / (1 - p) into the next convolution's weights); element i keeps iff hash(seed, i) >= p * 2^32.  n % 4 == 0. */
+int idee_dropout_mask_(float* x, long n, float p, uint64_t seed, idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Lookup-free quantisation with projections (dim -> log2 K -> dim), straight-through gradient,

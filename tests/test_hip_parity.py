@@ -868,3 +868,84 @@ def test_swin_encoder_drop_path_rate_module():
     assert not torch.equal(ya, yb) and torch.isfinite(ya).all()
     ya.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+
+
+def test_conv_block_drop_path_vs_oracle():
+    """CNN_3D encoder unit with stochastic depth: y = x + s_b * ReLU(LN(conv(x))) with the per-item factor s_b (0 = dropped),
+    forward and gradients against the oracle formula."""
+    import torch.nn.functional as F
+    ops = _ops()
+    g = torch.Generator().manual_seed(91)
+    N, V, T, H, W, C = 2, 2, 4, 6, 20, 16
+    x = torch.randn((N, V, T, H, W, C), generator=g)
+    r = torch.randn((N, V, T, H, W, C), generator=g)
+    w = torch.randn((V, C, C, 3, 3, 3), generator=g) * 0.06
+    gam, bet = 1 + 0.1 * torch.randn((V, C), generator=g), 0.1 * torch.randn((V, C), generator=g)
+    ps = torch.tensor([2.0, 0.0, 1.0, 2.0])                       # item b = n*V + v
+    leaves = [t.clone().requires_grad_() for t in (x, w, gam, bet)]
+    outs = []
+    for v in range(V):
+        xv = leaves[0][:, v].permute(0, 4, 1, 2, 3)
+        c = F.conv3d(F.pad(xv, (1,) * 6, mode="replicate"), leaves[1][v])
+        u = F.relu(F.layer_norm(c.permute(0, 2, 3, 4, 1), (C,), leaves[2][v], leaves[3][v]))
+        outs.append(leaves[0][:, v] + u * ps.reshape(N, V)[:, v].reshape(N, 1, 1, 1, 1))
+    yo = torch.stack(outs, 1)
+    (yo * r).sum().backward()
+    dl = [t.to(DEV).requires_grad_() for t in (x, w, gam, bet)]
+    y = ops.ConvLNUnit.apply(*dl, ps.to(DEV))
+    close("y", y, yo)
+    (y * r.to(DEV)).sum().backward()
+    for n, a_, b_ in zip(("dx", "dw", "dgamma", "dbeta"), dl, leaves):
+        gclose(n, a_.grad, b_.grad, rtol=2e-3, floor=2e-4)
+
+
+def test_classifier_dropout_statistics_and_gradients():
+    """cls_drop_rate > 0 (nn.Dropout after the first ReLU of every head, classifier/CNN_3D.py:41,53,93,133): identity in eval
+    mode; repeatable under torch.manual_seed; the keep-mask generator drops a fraction p; and — with the second ReLU made
+    inactive by a large positive bias, so that the head is LINEAR in the masked activation — the mean over many masks
+    reproduces the eval output, which pins the 1/(1-p) scaling folded into conv2's weights."""
+    from idee_amd.models.classifier.CNN_3D import CNN_3D
+    ops = _ops()
+    t = torch.ones(1 << 20, device=DEV)
+    ops._dropout_(t, 0.3, 12345)
+    assert abs(float((t == 0).float().mean()) - 0.3) < 5e-3 and set(t.unique().tolist()) == {0.0, 1.0}
+    t2 = torch.ones(1 << 20, device=DEV)
+    ops._dropout_(t2, 0.3, 12345)
+    assert torch.equal(t, t2)
+    ops._dropout_(t2, 0.3, 999)
+    assert abs(float((t2 == 0).float().mean()) - 0.51) < 1e-2          # an independent second mask: 1 - 0.7^2
+    torch.manual_seed(5)
+    V, N, T, H, W = 2, 2, 8, 12, 16
+    c = CNN_3D(in_var=V, embed_dim=16, dim=16, drop_rate=0.5).to(DEV)
+    with torch.no_grad():
+        c.j_b2.fill_(50.0)
+        c.h_b2.fill_(50.0)
+    x = torch.randn(N, V, 16, T, H, W, device=DEV)
+    c.eval()
+    with torch.no_grad():
+        z0, y0 = c(x)
+        z1, _ = c(x)
+    assert torch.equal(z0, z1)
+    c.train()
+    torch.manual_seed(1)
+    za, ya = c(x)
+    torch.manual_seed(1)
+    zb, yb = c(x)
+    assert torch.equal(za, zb), "same torch seed -> same dropout masks"
+    zc, _ = c(x)
+    assert not torch.equal(za, zc)
+    acc, accy = torch.zeros_like(z0), torch.zeros_like(torch.stack(y0))
+    n_draw = 200
+    with torch.no_grad():
+        for _ in range(n_draw):
+            zz, yy = c(x)
+            acc += zz
+            accy += torch.stack(yy)
+    for name, mean, ref in (("joint", acc / n_draw, z0), ("heads", accy / n_draw, torch.stack(y0))):
+        signal = (ref - ref.mean()).abs().mean()
+        err = (mean - ref).abs().mean() / signal
+        assert float(err) < 0.05, (name, float(err))
+    xg = x.clone().requires_grad_()
+    z, y = c(xg)
+    (z.sum() + sum(t_.sum() for t_ in y)).backward()
+    assert torch.isfinite(xg.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in c.parameters())
