@@ -47,7 +47,11 @@ def test_two_ranks_product_step_equals_one_rank(kind, tmp_path):
     g2, g1 = two["grad"], one["grad"]
     tol = 2e-4 * float(g1.abs().max())
     assert float((g2 - g1).abs().max()) <= tol, f"flat gradient: max err {float((g2 - g1).abs().max()):.3e} > {tol:.3e}"
-    torch.testing.assert_close(two["p1"], one["p1"], atol=2e-6, rtol=1e-4)
+    # Adam's first step moves every element by lr * g / (|g| + eps): an element whose gradient is at the eps = 1e-8 level is
+    # sensitive to rounding-level gradient differences; bound those few (<= 2 % of lr), everything else tight
+    d1 = (two["p1"] - one["p1"]).abs()
+    loose1 = d1 > 2e-6 + 1e-4 * one["p1"].abs()
+    assert float(d1.max()) <= 2e-5 and float(loose1.float().mean()) <= 1e-3, (float(d1.max()), float(loose1.float().mean()))
     # second step: Adam divides by sqrt(v) ~ |g|, so an element whose gradient is at rounding-noise level moves by up to ~lr
     # in a direction the noise decides; bound those (<= 0.3 lr, <= 0.5 % of the elements), everything else tight
     d = (two["p2"] - one["p2"]).abs()
