@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libidee_hip.so")
+# IDEE_HIP_LIB: another build of the same library (A/B timing of kernel variants on one GPU box); default: the in-tree build
+LIB_PATH = os.environ.get("IDEE_HIP_LIB") or os.path.join(_HERE, "libidee_hip.so")
 
 c_float_p = C.c_void_p  # raw device pointers travel as void*
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-OUT = os.path.join(PKG, "libidee_hip.so")
+OUT = os.environ.get("IDEE_BUILD_OUT") or os.path.join(PKG, "libidee_hip.so")
 SRCS = ["api.cpp", "swin_mfma.hip", "conv_mfma.hip", "pointwise.hip"]
 DEPS = ["common.h", os.path.join("..", "..", "include", "idee_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -259,20 +259,26 @@ __device__ __forceinline__ void mm_b(f32x4 (&Y)[OT][M], const unsigned* wl, int 
     }
 }
 
-// bf16 piece images for the token-reduction GEMMs: one row per token, kImgRow words = [16 positions hi | 16 positions lo |
-// pad] (96 bytes: the 8 token rows a 32-lane half of ds_read_b64_tr_b16 touches fall on distinct banks).  A lane of the
-// token layout owns positions 4kq..4kq+3 of its token: one 8-byte store per piece.  Read back TRANSPOSED by
-// ds_read_b64_tr_b16: lane (row i, group g) receives position i of tokens 4g..4g+3 — the K = tokens operand layout.
-constexpr int kImgRow = 24;   // 32-bit words per token row
+// bf16 piece images for the token-reduction GEMMs: one 64-byte row per token = 8 slots of 8 bytes (slots 0-3: the hi
+// pieces of positions 4s..4s+3, slots 4-7: their lo pieces).  A lane of the token layout owns positions 4kq..4kq+3 of its
+// token: one 8-byte store per piece.  Read back TRANSPOSED by ds_read_b64_tr_b16: lane (row i, group g) receives position i
+// of tokens 4g..4g+3 — the K = tokens operand layout.  The slot index is XOR-swizzled with the row,
+//     slot' = slot ^ (row & 7) ^ ((row >> 3) & 1),
+// which makes BOTH access patterns bank-conflict-free: the 16 lanes of a ds_write_b64 group (16 consecutive rows, one slot;
+// LDS writes bank on 32 words) land on 32 distinct words, and the 32 lanes of a transposed-read half (8 consecutive rows x
+// 4 slots; reads bank on 64 words) on 64 distinct words.  (An un-swizzled padded 96-byte row was 4-way conflicted on the
+// writes: SQ_LDS_BANK_CONFLICT was 59 % of SQ_LDS_IDX_ACTIVE in the attention backward, profiles/r02_sq_counters.txt.)
+constexpr int kImgRow = 16;   // 32-bit words per token row
+__device__ __forceinline__ int img_word(int row, int slot) { return row * kImgRow + 2 * (slot ^ (row & 7) ^ ((row >> 3) & 1)); }
 __device__ __forceinline__ void put_img_b(unsigned* img, int row, int kq, const Split& p) {
   typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-  *reinterpret_cast<u32x2v*>(img + row * kImgRow + 2 * kq) = u32x2v{p.h01, p.h23};
-  *reinterpret_cast<u32x2v*>(img + row * kImgRow + 8 + 2 * kq) = u32x2v{p.l01, p.l23};
+  *reinterpret_cast<u32x2v*>(img + img_word(row, kq)) = u32x2v{p.h01, p.h23};
+  *reinterpret_cast<u32x2v*>(img + img_word(row, 4 + kq)) = u32x2v{p.l01, p.l23};
 }
 // the 4 tokens 16 m + 4 g + {0..3} of position (lane & 15), piece `lo`
 __device__ __forceinline__ unsigned long long tr_read(const unsigned* img, int m, int lo, int lane) {
   const int row = 16 * m + 4 * (lane >> 4) + ((lane & 15) >> 2);
-  const unsigned* p = img + row * kImgRow + lo * 8 + 2 * (lane & 3);
+  const unsigned* p = img + img_word(row, 4 * lo + (lane & 3));
   const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
   return __builtin_bit_cast(unsigned long long, t);
 }
@@ -1562,8 +1568,8 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
   static_assert(MTK % TPW == 0 && NG >= 1, "a work item holds whole windows");
   constexpr int IMGW = 16 * MTK * kImgRow;      // words per piece image of one 16-position chunk
   constexpr int TILEW = 16 * kImgRow;           // words per 16 x 16 scratch tile
-  // per wave: [0,CT) K  [CT,2CT) Q  [2CT,3CT) V  [3CT,4CT) dO, then two scratch tiles
-  __shared__ __attribute__((aligned(16))) unsigned s_img[WPB][4 * CT * IMGW + 2 * TILEW];
+  // per wave: [0,CT) K  [CT,2CT) Q  [2CT,3CT) V  [3CT,4CT) dO  [4CT,5CT) XN  [5CT,6CT) dH, then two scratch tiles
+  __shared__ __attribute__((aligned(16))) unsigned s_img[WPB][6 * CT * IMGW + 2 * TILEW];
   __shared__ __attribute__((aligned(16))) int s_rid[WPB][16 * MTK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -1641,7 +1647,9 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
   unsigned* imgQ = img + CT * IMGW;
   unsigned* imgV = img + 2 * CT * IMGW;
   unsigned* imgDO = img + 3 * CT * IMGW;
-  unsigned* tileP = img + 4 * CT * IMGW;
+  unsigned* imgXN = img + 4 * CT * IMGW;
+  unsigned* imgDH = img + 5 * CT * IMGW;
+  unsigned* tileP = img + 6 * CT * IMGW;
   unsigned* tileS = tileP + TILEW;
   int* rid_l = s_rid[wave];
 
@@ -1662,18 +1670,19 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
     f32x4 XN[CT][MTK];
     float rstd[MTK];
     layer_norm_tl(X, XN, rstd, keep);
-    Split sXN[CT][MTK], sDH[CT][MTK];
     f32x4 QKV[3 * CT][MTK], DO[CT][MTK];
+    wave_sync();   // previous iteration's image readers are done
     {
       u32x4 bXN[CT][MTK], bDH[CT][MTK];
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int m = 0; m < MTK; ++m) {
-          sXN[c][m] = split2<false>(XN[c][m]);
-          sDH[c][m] = split2<false>(DH[c][m] * ps1);     // gradient entering the attention branch (drop_path factor of this item)
-          bXN[c][m] = frag_b(sXN[c][m]);
-          bDH[c][m] = frag_b(sDH[c][m]);
+          const Split sx = split2<false>(XN[c][m]), sd = split2<false>(DH[c][m] * ps1);   // ps1: drop_path factor of the attention branch
+          bXN[c][m] = frag_b(sx);
+          bDH[c][m] = frag_b(sd);
+          put_img_b(imgXN + c * IMGW, 16 * m + j, kq, sx);     // kept for the weight-gradient GEMMs at the end
+          put_img_b(imgDH + c * IMGW, 16 * m + j, kq, sd);
           DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
           pbp[c] += DH[c][m] * ps1;
         }
@@ -1686,7 +1695,6 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
       mm_b<false, 3 * CT, CT, MTK>(QKV, s_wf, W_Q, bXN, lane);
       mm_b<false, CT, CT, MTK>(DO, s_wf, W_PT, bDH, lane);       // dO = proj_w^T dH
     }
-    wave_sync();   // previous iteration's image readers are done
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -1867,19 +1875,13 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 
     // ---- token-reduction GEMMs (weight gradients) from piece images that reuse the Q / K / V / dO slots ----
     // dproj_w[c][c'] += dH[c] O[c'] ; dqkv_w[o][c] += dQKV[o] XN[c] ; K = tokens
-    unsigned* imgDH = imgQ;   // CT chunks each
-    unsigned* imgO = imgK;
-    unsigned* imgXN = imgV;
+    unsigned* imgO = imgK;    // CT chunks
     unsigned* imgG = imgDO;   // one dQKV chunk at a time
     wave_sync();
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MTK; ++m) {
-        put_img_b(imgDH + c * IMGW, 16 * m + j, kq, sDH[c][m]);
-        put_img_b(imgO + c * IMGW, 16 * m + j, kq, sO[c][m]);
-        put_img_b(imgXN + c * IMGW, 16 * m + j, kq, sXN[c][m]);
-      }
+      for (int m = 0; m < MTK; ++m) put_img_b(imgO + c * IMGW, 16 * m + j, kq, sO[c][m]);
     wave_sync();
 #pragma unroll
     for (int ca = 0; ca < CT; ++ca)
