@@ -59,6 +59,7 @@ def parse():
                     help="f32 (default): convolutions on the exact-f32 MFMA.  split: the opt-in split-precision 16->16 "
                          "convolution kernels (IDEE_CONV_MATH=split) — a separately labelled line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fwd-eval", action="store_true", help="skip the eval-mode forward timing (profiling runs: every launch then belongs to a train step)")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-entry-point / per-shape time table (stderr)")
     return ap.parse_args()
 
@@ -333,17 +334,19 @@ def main():
                     share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
 
     # ---- second half of BASELINE.json's metric: forward ms per clip (eval mode, no autograd), outside the timed region ----
-    ts.model.eval()
-    with torch.no_grad():
-        for _ in range(2):
-            ts.model(x)
-        barrier()
-        f0 = time.perf_counter()
-        for _ in range(5):
-            ts.model(x)
-        barrier()
-        fwd_ms_clip = (time.perf_counter() - f0) / 5 / batch * 1e3
-    ts.model.train()
+    fwd_ms_clip = float("nan")
+    if not a.no_fwd_eval:
+        ts.model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                ts.model(x)
+            barrier()
+            f0 = time.perf_counter()
+            for _ in range(5):
+                ts.model(x)
+            barrier()
+            fwd_ms_clip = (time.perf_counter() - f0) / 5 / batch * 1e3
+        ts.model.train()
 
     if rank != 0:
         return
@@ -361,7 +364,7 @@ def main():
                config=dict(workload=f"#{a.config}: {label}, V={cfg.in_channels_dynamic}, batch {batch}/GPU" +
                                     (f", grid overridden to {H}x{W}" if a.hw else ""), global_batch=world * batch,
                            parallelism=f"dp{world}"),
-               roofline=roof, fwd_ms_per_clip=round(fwd_ms_clip, 3), peak_hbm_alloc_gb=round(torch.cuda.max_memory_allocated() / 1e9, 2))
+               roofline=roof, fwd_ms_per_clip=None if a.no_fwd_eval else round(fwd_ms_clip, 3), peak_hbm_alloc_gb=round(torch.cuda.max_memory_allocated() / 1e9, 2))
     if world > 1:
         out["backend"] = torch.distributed.get_backend()
         out["ranks"] = ranks_report

@@ -2,9 +2,9 @@
 """Summarise two rocprofv3 PMC passes of bench.py into profiles/<tag>_pmc_traffic.json.
 
 On the GPU box (separate passes: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2 — MI355X_MICROARCH.md):
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-then:  python profiles/collect_pmc.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv profiles/r01_pmc_traffic.json
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fwd-eval
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fwd-eval
+then:  python profiles/collect_pmc.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv profiles/r02_pmc_traffic.json [train steps in the run = 3] [commit]
 
 Counter unit is KB.  FETCH_SIZE is doubled: on gfx950 it reports 1/2 of the bytes of a wide coalesced (16 B/lane)
 read (MI355X_MICROARCH.md, HBM section); all kernels here read with 16-byte pieces.  WRITE_SIZE is taken as is."""
@@ -23,7 +23,8 @@ def load(path, counter):
     return d
 
 
-def main(fcsv, wcsv, out):
+def main(fcsv, wcsv, out, steps="3", commit="?"):
+    steps = int(steps)
     f, w = load(fcsv, "FETCH_SIZE"), load(wcsv, "WRITE_SIZE")
     rows = []
     for k in f:
@@ -33,10 +34,10 @@ def main(fcsv, wcsv, out):
         name = re.sub(r"\(.*", "", name).replace("void ", "")
         fv, wv, dur = [x[0] for x in f[k]], [x[0] for x in w.get(k, [(0, 0)])], [x[1] for x in f[k]]
         fetch, write = sum(fv) / len(fv) * 1024 * 2, sum(wv) / len(wv) * 1024
-        rows.append(dict(kernel=name, launches=len(fv), avg_us_profiled=sum(dur) / len(dur) / 1e3, fetch_bytes_corrected=fetch,
-                         write_bytes=write, hbm_bytes_per_launch=fetch + write))
+        rows.append(dict(kernel=name, launches=len(fv), launches_per_step=len(fv) / steps, avg_us_profiled=sum(dur) / len(dur) / 1e3,
+                         fetch_bytes_corrected=fetch, write_bytes=write, hbm_bytes_per_launch=fetch + write))
     rows.sort(key=lambda r: -r["avg_us_profiled"] * r["launches"])
-    json.dump(dict(note=__doc__, kernels=rows), open(out, "w"), indent=1)
+    json.dump(dict(note=__doc__, source_commit=commit, train_steps_in_run=steps, kernels=rows), open(out, "w"), indent=1)
     print("%-46s %4s %9s %10s %10s %8s" % ("kernel", "n", "avg us", "fetch MB", "write MB", "GB/s"))
     for r in rows[:30]:
         print("%-46s %4d %9.1f %10.1f %10.1f %8.0f" % (r["kernel"][:46], r["launches"], r["avg_us_profiled"], r["fetch_bytes_corrected"] / 1e6,
@@ -44,4 +45,4 @@ def main(fcsv, wcsv, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])
