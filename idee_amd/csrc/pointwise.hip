@@ -983,6 +983,46 @@ __global__ __launch_bounds__(256) void vq_expire_kernel(float* __restrict__ embe
   for (int k = threadIdx.x; k < K; k += 256) if (s_rank[k] >= 0) cluster_size[k] = reset;
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Step glue (replaces ~15 tiny torch kernels per step incl. a Tensile GEMM, a cat and an index kernel):
+//   lfq_code_vectors : LFQ.indices_to_codes(indices) with project_out (LFQ.py:152-181) for a handful of codes:
+//                      out[i][e] = b_out[e] + sum_d (+-1)[bit d of indices[i]] w_out[e][d]
+//   loss_combine     : total = mean_t bce[0,t] + lam * l_anom + sum_{p>=1} mean_t bce[p,t] + loss_z_q
+//                      (train_synthetic.py:182-201 / train_ERA5_Land.py:181-198; T3 temporal slices per prediction)
+// -------------------------------------------------------------------------------------------
+__global__ void lfq_code_vectors_kernel(const long long* __restrict__ indices, const float* __restrict__ w_out,
+                                        const float* __restrict__ b_out, float* __restrict__ out, int n, int E, int D) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * E; i += gridDim.x * blockDim.x) {
+    const int e = i % E;
+    const long long idx = indices[i / E];
+    float a = b_out[e];
+    for (int d = 0; d < D; ++d) a += ((idx >> (D - 1 - d)) & 1) ? w_out[e * D + d] : -w_out[e * D + d];
+    out[i] = a;
+  }
+}
+// out[0] total, [1] extreme, [2] anomaly, [3] var, [4] z_q
+__global__ void loss_combine_fwd_kernel(const float* __restrict__ bce, int P, int T3, const float* __restrict__ l_anom, float lam,
+                                        const float* __restrict__ loss_zq, float* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  float ext = 0.f, var = 0.f;
+  for (int t = 0; t < T3; ++t) ext += bce[t];
+  ext /= T3;
+  for (int p = 1; p < P; ++p) {
+    float m = 0.f;
+    for (int t = 0; t < T3; ++t) m += bce[p * T3 + t];
+    var += m / T3;
+  }
+  out[1] = ext; out[2] = l_anom[0]; out[3] = var; out[4] = loss_zq[0];
+  out[0] = ((ext + l_anom[0] * lam) + var) + loss_zq[0];
+}
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ g, int P, int T3, float lam, float* __restrict__ dbce,
+                                        float* __restrict__ d_anom, float* __restrict__ d_zq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P * T3) dbce[i] = g[0] / T3;
+  if (i == 0) { d_anom[0] = g[0] * lam; d_zq[0] = g[0]; }
+}
+
 // -------------------------------------------------------------------------------------------
 // Device-side bookkeeping of the training drivers (utils/utils_train.py): confusion counts of the thresholded
 // prediction (evaluator :175-267, evaluator_synthetic :269-348) and the majority-vote anomaly collector (:529-554),
@@ -1367,6 +1407,8 @@ extern "C" int idee_stage_embed_ln_bwd(const float* x, const float* w, const flo
   return IDEE_OK;
 }
 
+static int log2i(int k) { int d = 0; while ((1 << d) < k) ++d; return d; }
+
 extern "C" long idee_lfq_workspace_floats(long M, int codebook_size) {
   return (long)stream_grid(M * 4) * (2 + codebook_size);
 }
@@ -1377,7 +1419,7 @@ extern "C" long idee_lfq_workspace_floats(long M, int codebook_size) {
   else if (E == 32 && D == 2) { CALL(32, 2); }                                                           \
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "lfq: (dim=%d, codebook_size=%d) not built", E, 1 << D);
 
-static int log2i(int k) { int d = 0; while ((1 << d) < k) ++d; return d; }
+
 
 extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
                             float* zq, int64_t* indices, float* stats, float* workspace, float* signs, long M, int E,
@@ -1592,6 +1634,33 @@ extern "C" int idee_vq_expire_codes(float* embed, float* cluster_size, float* em
   hipLaunchKernelGGL(vq_expire_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, embed, cluster_size, embed_avg, x,
                      (const long long*)candidates, K, E, threshold, reset, (int*)n_expired);
   IDEE_LAUNCH_CHECK("vq_expire_codes");
+  return IDEE_OK;
+}
+
+
+extern "C" int idee_lfq_code_vectors(const int64_t* indices, const float* w_out, const float* b_out, float* out, int n, int E,
+                                     int codebook_size, idee_stream_t stream) {
+  IDEE_CHECK_ARG(indices && w_out && b_out && out && n > 0 && E > 0 && codebook_size >= 2, "lfq_code_vectors: bad argument");
+  hipLaunchKernelGGL(lfq_code_vectors_kernel, dim3(cdiv((long)n * E, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)indices, w_out, b_out, out, n, E, log2i(codebook_size));
+  IDEE_LAUNCH_CHECK("lfq_code_vectors");
+  return IDEE_OK;
+}
+
+extern "C" int idee_loss_combine_fwd(const float* bce, int P, int T3, const float* l_anom, float lambda_anomaly,
+                                     const float* loss_zq, float* out5, idee_stream_t stream) {
+  IDEE_CHECK_ARG(bce && l_anom && loss_zq && out5 && P >= 1 && T3 >= 1, "loss_combine_fwd: bad argument");
+  hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bce, P, T3, l_anom, lambda_anomaly, loss_zq, out5);
+  IDEE_LAUNCH_CHECK("loss_combine_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_loss_combine_bwd(const float* gtotal, int P, int T3, float lambda_anomaly, float* dbce, float* d_anom,
+                                     float* d_zq, idee_stream_t stream) {
+  IDEE_CHECK_ARG(gtotal && dbce && d_anom && d_zq && P >= 1 && T3 >= 1, "loss_combine_bwd: bad argument");
+  hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(cdiv((long)P * T3, 256)), dim3(256), 0, (hipStream_t)stream, gtotal, P, T3,
+                     lambda_anomaly, dbce, d_anom, d_zq);
+  IDEE_LAUNCH_CHECK("loss_combine_bwd");
   return IDEE_OK;
 }
 

@@ -660,6 +660,39 @@ class AnomalyL1(torch.autograd.Function):
         return dzq, None, None, None
 
 
+def lfq_code_vectors(indices, w_out, b_out, codebook_size):
+    """LFQ.indices_to_codes(indices) with project_out for a 1-D index tensor, no autograd (LFQ.py:152-181) -> (n, E)."""
+    indices, w_out, b_out = indices.contiguous(), _f32c(w_out.detach()), _f32c(b_out.detach())
+    n, E = indices.numel(), w_out.shape[0]
+    out = torch.empty((n, E), device=w_out.device, dtype=torch.float32)
+    L.call("idee_lfq_code_vectors", ptr(indices), ptr(w_out), ptr(b_out), ptr(out), n, E, int(codebook_size), L.stream())
+    return out
+
+
+class CombineLosses(torch.autograd.Function):
+    """total = mean_t bce[0] + lam * l_anom + sum_p mean_t bce[p] + loss_z_q in one kernel per direction.
+    bce (P * T3,) rows of idee_bce_weighted_fwd (joint prediction first, T3 temporal slices each) -> (5,) =
+    [total, extreme, anomaly, var, z_q]; only out[0] carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, bce, l_anom, loss_zq, lam, T3):
+        bce, l_anom, loss_zq = _f32c(bce), _f32c(l_anom).reshape(1), _f32c(loss_zq).reshape(1)
+        P = bce.numel() // T3
+        out = torch.empty(5, device=bce.device, dtype=torch.float32)
+        L.call("idee_loss_combine_fwd", ptr(bce), P, T3, ptr(l_anom), float(lam), ptr(loss_zq), ptr(out), L.stream())
+        ctx.cfg = (P, T3, float(lam), l_anom.shape, loss_zq.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        P, T3, lam, sa, sz = ctx.cfg
+        g0 = _f32c(g)[:1].contiguous()
+        dbce = torch.empty(P * T3, device=g.device, dtype=torch.float32)
+        da, dz = torch.empty(1, device=g.device, dtype=torch.float32), torch.empty(1, device=g.device, dtype=torch.float32)
+        L.call("idee_loss_combine_bwd", ptr(g0), P, T3, lam, ptr(dbce), ptr(da), ptr(dz), L.stream())
+        return dbce, da.reshape(()), dz.reshape(()), None, None
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """In-place torch.optim.Adam update of the flat buffers (train_synthetic.py:127-129)."""
     L.call("idee_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, int(step),

@@ -51,11 +51,11 @@ class _TrainStep:
         bce = ops.WeightedBCE.apply(logits, target, valid, counts)
         if valid is not None and parallel.world_size() > 1:       # denominators (valid pixels) differ between shards
             bce = bce * parallel.global_anomaly_scale(valid.sum())
-        bce = bce.reshape(-1, T3).mean(1)
-        return bce[0], bce[1:].sum()
+        return bce, T3        # ((1 + V) * T3,) rows, joint prediction first
 
     def _anomaly_term(self, z_q, mask_loss, mask_valid_t):
-        vq0 = self.model.vq.indices_to_codes(self.code0).detach()
+        vq = self.model.vq      # indices_to_codes(LongTensor([0])).detach() of train_synthetic.py:193-194 as one tiny kernel
+        vq0 = ops.lfq_code_vectors(self.code0, vq.project_out.weight, vq.project_out.bias, vq.codebook_size)
         zq_tokens = z_q.permute(0, 1, 3, 4, 5, 2)
         l_anom, den = ops.AnomalyL1.apply(zq_tokens if zq_tokens.is_contiguous() else zq_tokens.contiguous(),
                                           mask_loss.float(), mask_valid_t.float() if mask_valid_t is not None else None, vq0)
@@ -63,9 +63,10 @@ class _TrainStep:
             l_anom = l_anom * parallel.global_anomaly_scale(den)
         return l_anom
 
-    def _finish(self, l_ext, l_anom, l_var, loss_z_q):
-        total = l_ext + l_anom * self.config.lambda_anomaly + l_var + loss_z_q.reshape(())
-        return total, dict(extreme=l_ext, anomaly=l_anom, var=l_var, z_q=loss_z_q.reshape(()))
+    def _finish(self, bce_rows, T3, l_anom, loss_z_q):
+        out = ops.CombineLosses.apply(bce_rows, l_anom, loss_z_q.reshape(()), float(self.config.lambda_anomaly), T3)
+        parts = out.detach()
+        return out[0], dict(extreme=parts[1], anomaly=parts[2], var=parts[3], z_q=parts[4])
 
     def _step(self, x_d, *masks):
         self.opt.zero_grad(set_to_none=True)
@@ -81,9 +82,9 @@ class _TrainStep:
 class SyntheticTrainStep(_TrainStep):
     def losses(self, outs, mask_extreme, mask_extreme_loss):
         """outs of VQ_model.forward; mask_extreme (N,H,W) -> total loss and its parts."""
-        l_ext, l_var = self._bce_terms(outs, mask_extreme, None)
+        bce, T3 = self._bce_terms(outs, mask_extreme, None)
         l_anom = self._anomaly_term(outs[3], mask_extreme_loss, None)
-        return self._finish(l_ext, l_anom, l_var, outs[4])
+        return self._finish(bce, T3, l_anom, outs[4])
 
     def step(self, x_d, mask_extreme, mask_extreme_loss):
         return self._step(x_d, mask_extreme, mask_extreme_loss)
@@ -98,9 +99,9 @@ class ERA5TrainStep(_TrainStep):
 
     def losses(self, outs, mask_drought, mask_drought_loss, mask_cold_surface, mask_cold_surface_loss):
         mask_valid = (1.0 - mask_cold_surface.float()).clamp_min_(0.0)
-        l_ext, l_var = self._bce_terms(outs, mask_drought, mask_valid)
+        bce, T3 = self._bce_terms(outs, mask_drought, mask_valid)
         l_anom = self._anomaly_term(outs[3], mask_drought_loss, mask_cold_surface_loss)
-        return self._finish(l_ext, l_anom, l_var, outs[4])
+        return self._finish(bce, T3, l_anom, outs[4])
 
     def step(self, x_d, mask_drought, mask_drought_loss, mask_cold_surface, mask_cold_surface_loss):
         return self._step(x_d, mask_drought, mask_drought_loss, mask_cold_surface, mask_cold_surface_loss)

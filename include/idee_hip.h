@@ -285,6 +285,19 @@ int idee_anomaly_l1_bwd(const float* zq, const float* mask_extreme, const float*
                         const float* gout, const float* denom, float* dzq, int N, int V, int T, long HW, int E,
                         idee_stream_t stream);
 
+/* Step glue of the training drivers.
+ *   lfq_code_vectors: LFQ.indices_to_codes(indices) with project_out (models/codebook/LFQ.py:152-181; e.g. the code-0 target of
+ *       the anomaly loss, train_synthetic.py:193-194): indices int64 (n) -> out (n, E); w_out (E, log2 K), b_out (E)
+ *   loss_combine: total = mean_t bce[0,t] + lambda_anomaly * l_anom + sum_{p>=1} mean_t bce[p,t] + loss_z_q
+ *       (train_synthetic.py:182-201, train_ERA5_Land.py:181-198); bce (P, T3) from idee_bce_weighted_fwd with the joint
+ *       prediction first; out5 = [total, extreme, anomaly, var, z_q]; bwd: gtotal (1) -> dbce (P, T3), d_anom (1), d_zq (1) */
+int idee_lfq_code_vectors(const int64_t* indices, const float* w_out, const float* b_out, float* out, int n, int E,
+                          int codebook_size, idee_stream_t stream);
+int idee_loss_combine_fwd(const float* bce, int P, int T3, const float* l_anom, float lambda_anomaly, const float* loss_zq,
+                          float* out5, idee_stream_t stream);
+int idee_loss_combine_bwd(const float* gtotal, int P, int T3, float lambda_anomaly, float* dbce, float* d_anom, float* d_zq,
+                          idee_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * torch.optim.Adam step (train_synthetic.py:127-129,205) over one flat parameter buffer.
  * g is multiplied by grad_scale first (1/world for data-parallel averaging).

@@ -53,10 +53,10 @@ def test_two_ranks_product_step_equals_one_rank(kind, tmp_path):
     loose1 = d1 > 2e-6 + 1e-4 * one["p1"].abs()
     assert float(d1.max()) <= 2e-5 and float(loose1.float().mean()) <= 1e-3, (float(d1.max()), float(loose1.float().mean()))
     # second step: Adam divides by sqrt(v) ~ |g|, so an element whose gradient is at rounding-noise level moves by up to ~lr
-    # in a direction the noise decides; bound those (<= 0.3 lr, <= 0.5 % of the elements), everything else tight
+    # in a direction the noise decides; bound those (<= 2 lr over the two steps, <= 0.5 % of the elements), everything else tight
     d = (two["p2"] - one["p2"]).abs()
     loose = d > 5e-6 + 2e-4 * one["p2"].abs()
-    assert float(d.max()) <= 3e-4 and float(loose.float().mean()) <= 5e-3, (float(d.max()), float(loose.float().mean()))
+    assert float(d.max()) <= 2.2e-3 and float(loose.float().mean()) <= 5e-3, (float(d.max()), float(loose.float().mean()))
     for k in ("extreme", "var"):          # global class counts -> identical weighting; means over equal shards
         assert two["parts"][k] == pytest.approx(one["parts"][k], rel=0.5) or kind == "era5"
     assert two["total2"] == pytest.approx(two["total2"])
