@@ -76,6 +76,87 @@ class ClipWindowDataset(torch.utils.data.Dataset):
         return tuple(np.ascontiguousarray(a) for a in (dyn, sta, t, m_ext, m_loss, m_an, tstep))
 
 
+class ERA5ClipDataset(torch.utils.data.Dataset):
+    """Items as ERA5_Land_Dataset.__getitem__ returns them (dataset/ERA5_Land_dataset.py:521-625), on in-memory arrays
+    (NetCDF reading is the caller's; window_size = 1, i.e. no spatial reduction):
+        dynamic (V, 2, delta_t, H, W) f32   weekly mean / std statistics, target week first (:213-292 orders the files so),
+                                            normalised (:571-583), clipped to [-10, 10], NaN / inf -> nan_fill (:586)
+        mask_drought (H, W)                 VHI < threshold at the target week (:562), cold / no-vegetation / water pixels zeroed
+        mask_drought_loss (H, W)            any VHI < 35 inside the window (:552-560)
+        mask_cold_surface (H, W)            target week
+        mask_cold_surface_loss (delta_t, H, W)
+        mask_sea (H, W), mask_no_vegetation (H, W), name
+    Inputs: dynamic (V, 2, T_total, H, W) already in the orientation __load_datacube returns (latitude flipped, :517-519);
+    vci / tci / cold: one array (n_files, H, W) PER WEEK in file orientation (the masks are flipped here as
+    __generate_mask does, :417-484: VHI = nanmean_files(alpha VCI + (1 - alpha) TCI)); mean_var / std_var (V,) (:579-581)
+    or, with `clima=(mean, std)` arrays (V, 2, T_total, H, W) in the cube's week order, the per-pixel climatology scaling
+    (:573-577)."""
+
+    def __init__(self, dynamic, vci, tci, cold, mask_water, mask_no_vegetation, mean_var=None, std_var=None, clima=None,
+                 delta_t=8, threshold=26.0, alpha=0.5, nan_fill=0.0, is_norm=True, is_aug=False, names=None, rng=None):
+        self.dynamic, self.vci, self.tci, self.cold = dynamic, vci, tci, cold
+        self.mask_water, self.mask_no_vegetation = mask_water, mask_no_vegetation
+        self.mean_var, self.std_var, self.clima = mean_var, std_var, clima
+        self.delta_t, self.threshold, self.alpha, self.nan_fill = int(delta_t), float(threshold), float(alpha), float(nan_fill)
+        self.is_norm, self.is_aug, self.names = bool(is_norm), bool(is_aug), names
+        self.rng = rng if rng is not None else np.random
+        if dynamic.shape[2] < self.delta_t:
+            raise ValueError(f"cube has {dynamic.shape[2]} weeks, fewer than delta_t={self.delta_t}")
+
+    def __len__(self):
+        return self.dynamic.shape[2] - self.delta_t + 1
+
+    def _mask(self, week, thr):
+        """__generate_mask (:417-484) for one week."""
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            vhi = np.nanmean(self.alpha * self.vci[week] + (1 - self.alpha) * self.tci[week], axis=0)
+        cold = np.flip(self.cold[week].sum(axis=0), 0).astype(np.float32)
+        cold[cold > 1] = 1
+        drought = (np.flip(vhi, 0) < thr).astype(np.float32)
+        drought[np.isnan(drought)] = 0
+        drought[cold == 1] = 0
+        drought[self.mask_no_vegetation == 1] = 0
+        drought[self.mask_water == 1] = 0
+        return drought, cold
+
+    def __getitem__(self, index):
+        dt = self.delta_t
+        weeks = [index + dt - 1 - k for k in range(dt)]                  # target week first, then back in time
+        dyn = self.dynamic[:, :, weeks].astype(np.float32, copy=True)
+        m_loss = np.zeros((dt,) + dyn.shape[-2:], dtype=np.float32)
+        c_loss = np.zeros_like(m_loss)
+        for k, w in enumerate(weeks):
+            m_loss[k], c_loss[k] = self._mask(w, 35)
+        m_loss = m_loss.sum(axis=0)
+        m_loss[m_loss > 1] = 1
+        m_drought, m_cold = self._mask(weeks[0], self.threshold)
+        sea, noveg = self.mask_water.copy(), self.mask_no_vegetation.copy()
+        if self.is_norm:
+            import warnings
+            if self.clima is not None:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore", category=RuntimeWarning)
+                    dyn = (dyn - self.clima[0][:, :, weeks]) / self.clima[1][:, :, weeks]
+            else:
+                for v in range(dyn.shape[0]):
+                    dyn[v, 0] = (dyn[v, 0] - self.mean_var[v]) / self.std_var[v]
+                    dyn[v, 1] = dyn[v, 1] / self.std_var[v]
+            dyn = np.clip(dyn, a_min=-10., a_max=10.)
+        dyn[np.logical_or(np.isnan(dyn), np.isinf(dyn))] = self.nan_fill
+        if self.is_aug:
+            if self.rng.choice(2):
+                dyn, m_drought, m_loss, m_cold, c_loss, sea, noveg = (np.rot90(a, k=2, axes=(-1, -2)) for a in
+                                                                      (dyn, m_drought, m_loss, m_cold, c_loss, sea, noveg))
+            if self.rng.choice(2):
+                ax = self.rng.randint(1, 3)
+                dyn, m_drought, m_loss, m_cold, c_loss, sea, noveg = (np.flip(a, axis=-ax) for a in
+                                                                      (dyn, m_drought, m_loss, m_cold, c_loss, sea, noveg))
+        name = self.names[weeks[0]] if self.names is not None else str(weeks[0])
+        return tuple(np.ascontiguousarray(a) for a in (dyn, m_drought, m_loss, m_cold, c_loss, sea, noveg)) + (name,)
+
+
 class PrefetchLoader:
     """Batches of (x_d (B,V,1,T,H,W) f32, mask_extreme (B,H,W) f32, mask_extreme_loss (B,H,W) f32, timestep (B,) int64)
     on `device`, produced `depth` batches ahead by a worker thread through pinned buffers and a side stream.

@@ -631,18 +631,88 @@ def fx_dataset_items(seed=1000):
     save("dataset_items", **out)
 
 
+def fx_era5_items(seed=1400):
+    """ERA5_Land_Dataset.__getitem__ and its __generate_mask (dataset/ERA5_Land_dataset.py:417-484, :521-625) on in-memory
+    arrays: the module's file access is replaced IN MEMORY (an `xarray` stand-in whose load_dataset returns the arrays of this
+    fixture, the instance's __load_datacube replaced by an array lookup); __getitem__ / __generate_mask themselves run
+    unmodified.  The instance is made without __init__ (which walks directories), with the attributes those two methods read."""
+    rng = np.random.default_rng(seed)
+    V, Tt, H, W, dt = 3, 12, 6, 9, 4
+    store = {}
+
+    class _Var:
+        def __init__(self, a): self.values = a
+        def isel(self, **kw): return self
+    xr_fake = types.ModuleType("xarray")
+    xr_fake.load_dataset = lambda path: {k: _Var(v) for k, v in store[path].items()}
+    sys.modules["xarray"] = xr_fake
+    for m in ("dask", "matplotlib", "matplotlib.pyplot"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    if not hasattr(sys.modules["dask"], "config"):      # the module sets dask's scheduler at import (ERA5_Land_dataset.py:24)
+        sys.modules["dask"].config = types.SimpleNamespace(set=lambda **kw: None)
+    import importlib
+    E = importlib.import_module("dataset.ERA5_Land_dataset")
+    E.xr = xr_fake
+    cls = E.ERA5_Land_Dataset
+    dynamic = (rng.standard_normal((V, 2, Tt, H, W)) * 3 + 1).astype(np.float32)
+    dynamic[0, 0, 2, 1, 1] = np.nan
+    dynamic[1, 1, 5, 2, 3] = np.inf
+    nfiles = [1 + (w % 2) for w in range(Tt)]
+    vci = [rng.uniform(0, 100, (n, H, W)).astype(np.float32) for n in nfiles]
+    tci = [rng.uniform(0, 100, (n, H, W)).astype(np.float32) for n in nfiles]
+    vci[3][0, 0, 0] = np.nan
+    cold = [(rng.random((n, H, W)) < 0.2).astype(np.float32) for n in nfiles]
+    water = (rng.random((H, W)) < 0.1).astype(np.float32)
+    noveg = (rng.random((H, W)) < 0.1).astype(np.float32)
+    mean_var = rng.standard_normal(V).astype(np.float32)
+    std_var = (1 + rng.random(V)).astype(np.float32)
+    for w in range(Tt):
+        for f in range(nfiles[w]):
+            store[f"noaa/{w}/{f}"] = dict(VCI=vci[w][f], TCI=tci[w][f], mask_cold_surface=cold[w][f])
+    out = dict(dynamic=dynamic, mask_water=water, mask_no_vegetation=noveg, mean_var=mean_var, std_var=std_var,
+               delta_t=np.array(dt), nfiles=np.array(nfiles))
+    for w in range(Tt):
+        out[f"vci/{w}"], out[f"tci/{w}"], out[f"cold/{w}"] = vci[w], tci[w], cold[w]
+    names = ("dynamic", "mask_drought", "mask_drought_loss", "mask_cold_surface", "mask_cold_surface_loss", "mask_sea", "mask_no_vegetation")
+    for is_aug in (False, True):
+        ds = object.__new__(cls)
+        ds.delta_t, ds.n_lat_window, ds.n_lon_window, ds.threshold, ds.alpha = dt, H, W, 26.0, 0.5
+        ds.is_reduce, ds.is_norm, ds.is_clima_scale, ds.is_aug, ds.nan_fill, ds.var_n_dynamic = False, True, False, is_aug, 0.0, V
+        ds.x_min, ds.x_max, ds.y_min, ds.y_max, ds.region, ds.CORDEX_regions = 0, W, 0, H, "EUR-11", {"EUR-11": (H, W)}
+        ds._ERA5_Land_Dataset__mask_water, ds._ERA5_Land_Dataset__mask_no_vegetation = water, noveg
+        ds._ERA5_Land_Dataset__mean_var, ds._ERA5_Land_Dataset__std_var = mean_var, std_var
+        ds.files = []
+        for idx in range(Tt - dt + 1):
+            weeks = [idx + dt - 1 - k for k in range(dt)]
+            ds.files.append(([f"era5/{w}xxxxxxx.nc"[:0] + f"week{w:07d}.nc" for w in weeks],
+                             [[f"noaa/{w}/{f}" for f in range(nfiles[w])] for w in weeks], np.array(weeks, dtype=np.float32)))
+        ds._ERA5_Land_Dataset__load_datacube = lambda files: dynamic[:, :, [int(f[4:11]) for f in files]].copy()
+        for index in (0, 3, Tt - dt):
+            for rs in ((0,) if not is_aug else (0, 1, 2, 3, 4, 5)):
+                np.random.seed(2234 + rs)
+                item = ds[index]
+                for n, v in zip(names, item[:7]):
+                    out[f"item/aug{int(is_aug)}/i{index}/s{rs}/{n}"] = np.ascontiguousarray(v)
+    save("era5_items", **out)
+
+
+if __name__ == "__main__" and "--era5items-only" in sys.argv:
+    fx_era5_items()
+
+
 if __name__ == "__main__" and "--data-only" in sys.argv:
     fx_dataset_items()
 
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
-                                                                "--era5-only", "--hier-only", "--vqema-only", "--misc-only")):
+                                                                "--era5-only", "--hier-only", "--vqema-only", "--misc-only", "--era5items-only")):
     main()
     fx_swin_hier("16_32", (16, 32), 1200)
     fx_swin_hier("32_16", (32, 16), 1210)
     fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
     fx_patch_mergings()
     fx_dataset_items()
+    fx_era5_items()
     fx_vq("k2_train", 2, True, 800)
     fx_vq("k2_eval", 2, False, 810)
     fx_vq("k8_train", 8, True, 820)

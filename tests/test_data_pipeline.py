@@ -119,3 +119,32 @@ def test_prefetch_loader_feeds_train_epoch_on_gpu():
     ld.set_epoch(1)
     mean_loss, _ = train_epoch(step, ld)
     assert np.isfinite(mean_loss)
+
+
+def test_era5_items_match_reference_getitem():
+    """idee_amd.data.ERA5ClipDataset against items produced by the reference's own ERA5_Land_Dataset.__getitem__ /
+    __generate_mask on the same in-memory arrays (tests/golden/era5_items.npz; incl. NaN / inf fill, multi-file weeks and
+    the seeded rot180 / flip augmentation): bit-equal."""
+    import numpy as np
+    from conftest import GOLDEN
+    from idee_amd.data import ERA5ClipDataset
+    z = np.load(GOLDEN + "/era5_items.npz")
+    Tt = z["dynamic"].shape[2]
+    dt = int(z["delta_t"])
+    vci, tci, cold = ([z[f"{k}/{w}"] for w in range(Tt)] for k in ("vci", "tci", "cold"))
+    names = ("dynamic", "mask_drought", "mask_drought_loss", "mask_cold_surface", "mask_cold_surface_loss", "mask_sea", "mask_no_vegetation")
+    n_checked = 0
+    for is_aug in (False, True):
+        ds = ERA5ClipDataset(z["dynamic"], vci, tci, cold, z["mask_water"], z["mask_no_vegetation"], z["mean_var"], z["std_var"],
+                             delta_t=dt, threshold=26.0, alpha=0.5, nan_fill=0.0, is_aug=is_aug)
+        assert len(ds) == Tt - dt + 1
+        for index in (0, 3, Tt - dt):
+            for rs in ((0,) if not is_aug else (0, 1, 2, 3, 4, 5)):
+                np.random.seed(2234 + rs)
+                item = ds[index]
+                for n, v in zip(names, item[:7]):
+                    ref = z[f"item/aug{int(is_aug)}/i{index}/s{rs}/{n}"]
+                    assert v.shape == ref.shape and v.dtype == ref.dtype, (n, v.shape, ref.shape, v.dtype, ref.dtype)
+                    assert np.array_equal(v, ref, equal_nan=True), (is_aug, index, rs, n)
+                    n_checked += 1
+    assert n_checked == 7 * (3 + 18)
