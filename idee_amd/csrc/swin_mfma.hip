@@ -244,6 +244,43 @@ __device__ __forceinline__ void put_wfrag_b(unsigned* wl, int tile, f32x4 w, int
 __device__ __forceinline__ u32x4 get_wfrag_b(const unsigned* wl, int tile, int piece, int lane) {
   return *reinterpret_cast<const u32x4*>(wl + ((tile * 2 + piece) * 64 + lane) * 4);
 }
+// The same with ONE weight fragment per tile, [w_hi | w_lo] (half the LDS: what lets the C = 32 attention backward keep four
+// waves per workgroup), the duplication moved to the B side: B1 = [x_hi | x_hi], B2 = [x_lo | x_lo] (register moves).
+// WDUP selects the layout: tile t lives at (t * 2 + piece) * 256 words (duplicated) or at t * 256 words (single).
+template <bool F16>
+__device__ __forceinline__ void put_wfrag_u(unsigned* wl, int tile, f32x4 w, int lane) {
+  const Split p = split2<F16>(w);
+  *reinterpret_cast<u32x4*>(wl + (tile * 64 + lane) * 4) = u32x4{p.h01, p.h23, p.l01, p.l23};
+}
+template <bool F16, bool WDUP>
+__device__ __forceinline__ void put_wfrag_x(unsigned* wl, int tile, f32x4 w, int lane) {
+  if (WDUP) put_wfrag_b<F16>(wl, tile, w, lane); else put_wfrag_u<F16>(wl, tile, w, lane);
+}
+// acc += W-tile x B for M column blocks, both layouts (xb = [x_hi | x_lo] fragments)
+template <bool F16, bool WDUP, int M>
+__device__ __forceinline__ void mma_tile(f32x4 (&acc)[M], const unsigned* wl, int tile, const u32x4 (&xb)[M], int lane) {
+  if (WDUP) {
+    const u32x4 ah = get_wfrag_b(wl, tile, 0, lane), al = get_wfrag_b(wl, tile, 1, lane);
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(ah, xb[m], acc[m]);
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(al, xb[m], acc[m]);
+  } else {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(wl + (tile * 64 + lane) * 4);
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(a, u32x4{xb[m][0], xb[m][1], xb[m][0], xb[m][1]}, acc[m]);
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(a, u32x4{xb[m][2], xb[m][3], xb[m][2], xb[m][3]}, acc[m]);
+  }
+}
+template <bool F16, bool WDUP, int OT, int KT, int M>
+__device__ __forceinline__ void mm_x(f32x4 (&Y)[OT][M], const unsigned* wl, int tile0, const u32x4 (&XB)[KT][M], int lane) {
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) mma_tile<F16, WDUP, M>(Y[o], wl, tile0 + o * KT + k, XB[k], lane);
+}
+
 // Y[OT][M] += W X with the weight fragments of tiles tile0 + o * KT + k in LDS and X already split (B fragments)
 template <bool F16, int OT, int KT, int M>
 __device__ __forceinline__ void mm_b(f32x4 (&Y)[OT][M], const unsigned* wl, int tile0, const u32x4 (&XB)[KT][M], int lane) {
@@ -1028,7 +1065,7 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
 // VALU work) instead of 160 f32 MFMAs (32 cycles each, serialised with it) + 20 operand splits.
 // ---------------------------------------------------------------------------------------------
 template <int C, int M>
-__global__ __launch_bounds__(256, 2) void swin_mlp_bwd_b_kernel(
+__global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_b_kernel(
     const float* __restrict__ hs, const float* __restrict__ dy, float* __restrict__ dh, const float* __restrict__ fc1_w,
     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float* __restrict__ g_fc1_w,
     float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L,
@@ -1555,7 +1592,7 @@ __device__ __forceinline__ void flush_acc_perm(float* dst, int ld, const f32x4& 
 }
 __device__ __forceinline__ u32x4 dup2(unsigned long long a) { return u32x4{(unsigned)a, (unsigned)(a >> 32), (unsigned)a, (unsigned)(a >> 32)}; }
 
-template <int C, int NH, int NW, int WPB, int MTK>
+template <int C, int NH, int NW, int WPB, int MTK, bool WDUP>
 __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
     const float* __restrict__ x, const float* __restrict__ dh, float* __restrict__ dx, const float* __restrict__ qkv_w,
     const float* __restrict__ qkv_b, const float* __restrict__ proj_w, const float* __restrict__ rel_bias,
@@ -1583,7 +1620,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
   constexpr int NRB = NH * TPW * TPW;
   constexpr int W_Q = 0, W_QT = 3 * CT * CT, W_PT = 6 * CT * CT, NWT = 7 * CT * CT;
   __shared__ __attribute__((aligned(16))) float s_rb[NRB * 256];
-  __shared__ __attribute__((aligned(16))) unsigned s_wf[NWT * 2 * 256];
+  __shared__ __attribute__((aligned(16))) unsigned s_wf[NWT * (WDUP ? 2 : 1) * 256];
   __shared__ __attribute__((aligned(16))) float s_bq[3 * CT * 256];
   {
     int i = 0;
@@ -1593,16 +1630,16 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
       if ((i++) % WPB == wave) st4(s_bq + o * 256 + lane * 4, vfrag<HPC>(qkv_b, 16 * o, lane, mul));
 #pragma unroll
       for (int k = 0; k < CT; ++k) {
-        if ((i++) % WPB == wave) put_wfrag_b<false>(s_wf, W_Q + o * CT + k, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul), lane);
+        if ((i++) % WPB == wave) put_wfrag_x<false, WDUP>(s_wf, W_Q + o * CT + k, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul), lane);
         // [c][o] = qkv_w[o][c] (q rows carry the scale)
-        if ((i++) % WPB == wave) put_wfrag_b<false>(s_wf, W_QT + k * 3 * CT + o, wfrag<true, 1, HPC>(qkv_w, C, 16 * k, 16 * o, lane, mul), lane);
+        if ((i++) % WPB == wave) put_wfrag_x<false, WDUP>(s_wf, W_QT + k * 3 * CT + o, wfrag<true, 1, HPC>(qkv_w, C, 16 * k, 16 * o, lane, mul), lane);
       }
     }
 #pragma unroll
     for (int o = 0; o < CT; ++o)
 #pragma unroll
       for (int k = 0; k < CT; ++k)   // [c'][c] = proj_w[c][c']
-        if ((i++) % WPB == wave) put_wfrag_b<false>(s_wf, W_PT + o * CT + k, wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane), lane);
+        if ((i++) % WPB == wave) put_wfrag_x<false, WDUP>(s_wf, W_PT + o * CT + k, wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane), lane);
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -1692,8 +1729,8 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 #pragma unroll
         for (int m = 0; m < MTK; ++m) QKV[o][m] = bqo;
       }
-      mm_b<false, 3 * CT, CT, MTK>(QKV, s_wf, W_Q, bXN, lane);
-      mm_b<false, CT, CT, MTK>(DO, s_wf, W_PT, bDH, lane);       // dO = proj_w^T dH
+      mm_x<false, WDUP, 3 * CT, CT, MTK>(QKV, s_wf, W_Q, bXN, lane);
+      mm_x<false, WDUP, CT, CT, MTK>(DO, s_wf, W_PT, bDH, lane);       // dO = proj_w^T dH
     }
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -1853,18 +1890,14 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 #pragma unroll
     for (int oc = 0; oc < CT; ++oc)
 #pragma unroll
-      for (int k = 0; k < CT; ++k)
+      for (int k = 0; k < CT; ++k) {
+        u32x4 bq_[MTK], bk_[MTK], bv_[MTK];
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-          const u32x4 wa = get_wfrag_b(s_wf, W_QT + oc * 3 * CT + k, pc, lane), wb = get_wfrag_b(s_wf, W_QT + oc * 3 * CT + CT + k, pc, lane),
-                      wc = get_wfrag_b(s_wf, W_QT + oc * 3 * CT + 2 * CT + k, pc, lane);
-#pragma unroll
-          for (int m = 0; m < MTK; ++m) dXN[oc][m] = mfma_s<false>(wa, frag_b(sDQ[k][m]), dXN[oc][m]);
-#pragma unroll
-          for (int m = 0; m < MTK; ++m) dXN[oc][m] = mfma_s<false>(wb, frag_b(sDK[k][m]), dXN[oc][m]);
-#pragma unroll
-          for (int m = 0; m < MTK; ++m) dXN[oc][m] = mfma_s<false>(wc, frag_b(sDV[k][m]), dXN[oc][m]);
-        }
+        for (int m = 0; m < MTK; ++m) { bq_[m] = frag_b(sDQ[k][m]); bk_[m] = frag_b(sDK[k][m]); bv_[m] = frag_b(sDV[k][m]); }
+        mma_tile<false, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + k, bq_, lane);
+        mma_tile<false, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + CT + k, bk_, lane);
+        mma_tile<false, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + 2 * CT + k, bv_, lane);
+      }
     f32x4 DX[CT][MTK];
     layer_norm_bwd_tl(dXN, XN, rstd, DH, DX);
 #pragma unroll
@@ -2006,12 +2039,12 @@ extern "C" int idee_swin_block_fwd(const float* x, float* y, float* h_save, cons
   const bool split = split_math();
   const dim3 grid = swin_grid(cdiv(g.items, 4), B, C == 16 ? (split ? 3 : 2) : 1);
 #define CALL(C_, NH_, NW_)                                                                                   \
-  if (C_ == 16 && split) {                                                                                   \
+  if (split) {                                                                                               \
     if (h_save)                                                                                              \
-      hipLaunchKernelGGL((swin_fwd_b_kernel<C_ == 16 ? C_ : 16, NH_, NW_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
+      hipLaunchKernelGGL((swin_fwd_b_kernel<C_, NH_, NW_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
                          p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
     else                                                                                                     \
-      hipLaunchKernelGGL((swin_fwd_b_kernel<C_ == 16 ? C_ : 16, NH_, NW_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
+      hipLaunchKernelGGL((swin_fwd_b_kernel<C_, NH_, NW_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
                          p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
   } else if (h_save)                                                                                         \
     hipLaunchKernelGGL((swin_fwd_mfma_kernel<C_, NH_, NW_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
@@ -2036,7 +2069,11 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
   const long L = (long)s->D * s->H * s->W;
   hipStream_t st = (hipStream_t)stream;
   {   // part 1: MLP + norm2 (token order)
-    if (C == 16 && split_math()) {
+    if (C == 32 && split_math()) {      // one workgroup per CU: 96 KB of weight fragments + 48 KB of piece images
+      const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 1);
+      hipLaunchKernelGGL((swin_mlp_bwd_b_kernel<32, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
+                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L, p->path_scale);
+    } else if (C == 16 && split_math()) {
       const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 2);
       hipLaunchKernelGGL((swin_mlp_bwd_b_kernel<16, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
                          p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L, p->path_scale);
@@ -2054,14 +2091,18 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
   // C = 16: 32 tokens per wave and work item, 8 waves per workgroup (LDS images 13.8 KB per wave): at most 256 registers
   // per lane, so two waves share a SIMD and one's LDS / global latency hides under the other's MFMA chain.
   // C = 32: 64 tokens per wave, 2 waves (48 KB of images each).
-  const int WPB = C == 16 ? 8 : 2, MTK = C == 16 ? 2 : 4;
   const bool split = split_math();
+  const int WPB = C == 16 ? 8 : (split ? 4 : 2), MTK = C == 16 ? 2 : (split ? 2 : 4);
   Geom ga = g;
   ga.items = cdiv(g.nWin, (16 * MTK) / NW);
   const dim3 grid = swin_grid(cdiv(ga.items, WPB), B, 1);
 #define CALL(C_, NH_, NW_)                                                                                           \
-  if (C_ == 16 && split)                                                                                             \
-    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<16, NH_, NW_, 8, 2>), grid, dim3(512), 0, st, x,                      \
+  if (C_ == 32 && split)                                                                                             \
+    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<32, NH_, NW_, 4, 2, false>), grid, dim3(256), 0, st, x,               \
+                       dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,  \
+                       d->proj_b, d->rel_bias, ga);                                                                  \
+  else if (C_ == 16 && split)                                                                                        \
+    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<16, NH_, NW_, 8, 2, true>), grid, dim3(512), 0, st, x,                \
                        dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,  \
                        d->proj_b, d->rel_bias, ga);                                                                  \
   else                                                                                                               \
