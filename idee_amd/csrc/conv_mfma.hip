@@ -941,7 +941,10 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
   const int r16 = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
   float* s_x = s_xw[wave];
-  const int gb0 = blockIdx.z * NB;            // first output block of this workgroup
+  // blockIdx.z = (input 16-channel block) * (output block groups) + (output block group): any Cin, Cout multiples of 16
+  const int ngb = (a.CoutPad / 16) / NB;
+  const int ga = blockIdx.z / ngb;            // input block of this workgroup
+  const int gb0 = (blockIdx.z % ngb) * NB;    // first output block of this workgroup
   f32x4 acc[NTAPS][NB];
   float bsum[NB];
 #pragma unroll
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
     const int rowlen = my_sub * 16 + 2;
     const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
     int res0 = -1, res1 = -1, res2 = -1;
-    const float* x_b = a.x + (long)b * a.x_sB;
+    const float* x_b = a.x + (long)b * a.x_sB + goff(ga, a.x_gpu, a.x_sU, a.x_sG);
     const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
     int tsrc[TSL];
 #pragma unroll
@@ -1047,15 +1050,15 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
           }
     }
   }
-  float* dw = a.dwp + (long)wset * NTAPS * 16 * a.CoutPad;
+  float* dw = a.dwp + ((long)wset * NTAPS * a.Cin + ga * 16) * a.CoutPad;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
   for (int tp = 0; tp < NTAPS; ++tp)
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + (gb0 + n) * 16 + col, acc[tp][n][r]);
-  if (a.dbias) {
+      for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * a.Cin + r0 + r) * a.CoutPad + (gb0 + n) * 16 + col, acc[tp][n][r]);
+  if (a.dbias && ga == 0) {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       float v = bsum[n];
@@ -1894,11 +1897,11 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     a.row_chunks = gx;                                                                                       \
     hipLaunchKernelGGL((wgrad_kernel<MODE_, TPW_, NTA_, NTB_>), dim3(gx, gy, d->wsets), dim3(256), 0, st, a); \
   } while (0)
-  if (Ga == 1 && d->Cout % 16 == 0 && (Gb == 1 || (d->mode == IDEE_CONV_K133_ZERO && Gb % 3 == 0))) {
+  if (d->Cout % 16 == 0 && ((Ga <= 2 && Gb <= 2 && d->mode != IDEE_CONV_K133_ZERO) || (Ga == 1 && (Gb == 1 || (d->mode == IDEE_CONV_K133_ZERO && Gb % 3 == 0))))) {
     // wave-private strip kernel: strips of 32 pixels, runs of rows per (b, t); 16 -> 16 in every mode, and the
     // (1,3,3) sign-field convs 16 -> 48k with 3 output blocks per wave
     const int nstrip = cdiv(cdiv(d->W, 16), 2);
-    const int gz = (d->mode == IDEE_CONV_K133_ZERO && Gb > 1) ? Gb / 3 : 1;
+    const int gz = (d->mode == IDEE_CONV_K133_ZERO && Gb > 1) ? Gb / 3 : Ga * Gb;      // (input block, output block group) pairs
     const long btr = (long)(d->B / d->wsets) * a.To;
     int hr2 = d->H;                                       // runs short enough for ~5 work units per resident wave
     while (hr2 > 8 && btr * cdiv(d->H, hr2) * nstrip * d->wsets * gz < 5L * kCUs * 8) hr2 = (hr2 + 1) / 2;
@@ -1910,7 +1913,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), (long)d->wsets * gz, wg_per_cu(kern, 256)), d->wsets, gz), \
                        dim3(256), 0, st, a, nstrip, hr2, nhr2);                                               \
   } while (0)
-    const bool split = conv_split_math() && Gb == 1;
+    const bool split = conv_split_math() && Gb == 1 && Ga == 1;
     if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSTRIP((wgrad16_split_kernel<FWD_S2, 2>));
     else if (rep) LSTRIP((wgrad16_strip_kernel<FWD_REP, 3, 1>));
