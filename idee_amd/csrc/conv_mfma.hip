@@ -1239,8 +1239,11 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
 #pragma unroll
   for (int n = 0; n < GB; ++n) bsum[n] = 0.f;
 
-  // every workgroup keeps ONE kt for its whole life (so its accumulators belong to 9 fixed taps)
-  const int kt = blockIdx.z;
+  // every workgroup keeps ONE kt for its whole life (so its accumulators belong to 9 fixed taps) and one (input, output)
+  // channel sub-block of GA x GB 16-channel groups: blockIdx.z = kt + a.kt * (xsub * (CoutTot / CO) + ysub)
+  const int kt = blockIdx.z % a.kt;
+  const int nys = a.CoutPad / CO;
+  const int xg0 = ((blockIdx.z / a.kt) / nys) * GA, yg0 = ((blockIdx.z / a.kt) % nys) * GB;
   const int nb = a.B / a.wsets;
   const long nchunks = (long)nb * a.To * nhrun * nseg;
   for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
@@ -1275,7 +1278,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
           const int px = u / (CI / 4), q = u % (CI / 4);       // q: 16-byte unit inside the pixel's channels
           const int w = w0 + px - 1;
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + goff(q >> 2, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q & 3));
+          if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + goff(xg0 + (q >> 2), a.x_gpu, a.x_sU, a.x_sG) + 4 * (q & 3));
           st4(dst + px * PSX + 4 * q, v);
         }
       }
@@ -1285,7 +1288,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
           const int px = u / (CO / 4), q = u % (CO / 4);
           const int w = w0 + px;
           const bool in = px < seg && w < a.W;
-          st4(s_dy + px * PSY + 4 * q, in ? ld4(src + (long)w * a.y_sW + goff(q >> 2, a.y_gpu, a.y_sU, a.y_sG) + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f});
+          st4(s_dy + px * PSY + 4 * q, in ? ld4(src + (long)w * a.y_sW + goff(yg0 + (q >> 2), a.y_gpu, a.y_sU, a.y_sG) + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f});
         }
       }
       __syncthreads();
@@ -1316,7 +1319,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
       }
     }
   }
-  float* dw = a.dwp + (long)wset * a.ntaps * CI * CO;
+  float* dw = a.dwp + (long)wset * a.ntaps * a.Cin * a.CoutPad;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
   for (int f = 0; f < FPW; ++f) {
@@ -1327,15 +1330,15 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
     for (int n = 0; n < GB; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(dw + ((long)tap * CI + 16 * ga + r0 + r) * CO + 16 * n + col, acc[f][n][r]);
+        atomicAdd(dw + ((long)tap * a.Cin + 16 * (xg0 + ga) + r0 + r) * a.CoutPad + 16 * (yg0 + n) + col, acc[f][n][r]);
   }
-  if (a.dbias && wave == 0 && kt == 0) {
+  if (a.dbias && wave == 0 && kt == 0 && xg0 == 0) {
 #pragma unroll
     for (int n = 0; n < GB; ++n) {
       float v = bsum[n];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
-      if (lane < 16) atomicAdd(a.dbias + (long)wset * CO + 16 * n + lane, v);
+      if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + 16 * (yg0 + n) + lane, v);
     }
   }
 }
@@ -1922,9 +1925,11 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     else LSTRIP((wgrad16_strip_kernel<FWD_S2, 1, 3>));
 #undef LSTRIP
   }
-  else if (!rep && (Ga == Gb || Ga == 1) && (Gb == 6 || Gb == 3 || Gb == 2) && d->Cout % 16 == 0) {
+  else if (!rep && (Ga == Gb || Ga == 1) && (Gb == 6 || Gb == 3 || Gb == 2 || (Gb % 6 == 0 && Ga % 6 == 0)) && d->Cout % 16 == 0) {
     // wide LDS-staged kernel: segment width from the LDS budget (ring of 3 x rows + dy row, padded pixel strides)
-    const int PSX = d->Cin + ((48 - d->Cin % 32) % 32), PSY = a.CoutPad + ((48 - a.CoutPad % 32) % 32);
+    // channel sub-blocks of at most 6 x 6 groups per workgroup (wider convolutions: a grid of sub-blocks)
+    const int ga_k = Ga > 6 ? 6 : Ga, gb_k = Gb > 6 ? 6 : Gb, nsubz = (Ga / ga_k) * (Gb / gb_k);
+    const int PSX = 16 * ga_k + ((48 - (16 * ga_k) % 32) % 32), PSY = 16 * gb_k + ((48 - (16 * gb_k) % 32) % 32);
     const long budget = 150 * 1024 / 4;                                   // floats
     int segmax = (int)((budget - 6L * PSX) / (3L * PSX + PSY)) & ~3;
     if (segmax > 256) segmax = 256;
@@ -1932,11 +1937,11 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const int seg = ((cdiv(d->W, nseg) + 3) / 4) * 4;
     const long btk = (long)(d->B / d->wsets) * a.To * a.kt;
     int hrun = d->H;
-    while (hrun > 8 && btk * cdiv(d->H, hrun) * nseg * d->wsets < 3L * kCUs) hrun = (hrun + 1) / 2;
+    while (hrun > 8 && btk * cdiv(d->H, hrun) * nseg * d->wsets * nsubz < 3L * kCUs) hrun = (hrun + 1) / 2;
     const int nhrun = cdiv(d->H, hrun);
     const long nchunks = (long)(d->B / d->wsets) * a.To * nhrun * nseg;
     const size_t lds = (size_t)(3L * (seg + 2) * PSX + (long)((seg + 3) & ~3) * PSY) * 4;
-    const dim3 grid(one_round(nchunks, (long)a.kt * d->wsets, 1), d->wsets, a.kt);
+    const dim3 grid(one_round(nchunks, (long)a.kt * d->wsets * nsubz, 1), d->wsets, a.kt * nsubz);
 #define LWW(GA_, GB_, WAVES_)                                                                                         \
   do {                                                                                                                \
     auto kern = wgrad_wide_lds_kernel<GA_, GB_, WAVES_>;                                                              \
@@ -1946,7 +1951,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
   } while (0)
     // 16 input channels (the sign field): one tap per wave, 9 waves
     if (Ga == 1) { if (Gb == 6) LWW(1, 6, 9); else if (Gb == 3) LWW(1, 3, 9); else LWW(1, 2, 9); }
-    else if (Ga == 6) LWW(6, 6, 8); else if (Ga == 3) LWW(3, 3, 8); else LWW(2, 2, 8);
+    else if (ga_k == 6) LWW(6, 6, 8); else if (Ga == 3) LWW(3, 3, 8); else LWW(2, 2, 8);
 #undef LWW
   }
   else if (Ga == 1 && Gb == 1) { if (rep) LW(FWD_REP, 27, 1, 1); else if (a.kt == 2) LW(FWD_S2, 18, 1, 1); else LW(FWD_S2, 9, 1, 1); }

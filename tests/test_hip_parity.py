@@ -309,18 +309,21 @@ def test_classifier_golden():
         gclose("d" + k, g if idx is None else g[idx], gref)
 
 
-@pytest.mark.parametrize("V,H,W", [(3, 7, 72), (6, 5, 40), (1, 3, 3), (5, 4, 20), (6, 6, 200), (2, 3, 200)])
-def test_classifier_vs_oracle(V, H, W):
+@pytest.mark.parametrize("V,H,W,E", [(3, 7, 72, 16), (6, 5, 40, 16), (1, 3, 3, 16), (5, 4, 20, 16), (6, 6, 200, 16), (2, 3, 200, 16),
+                                     (6, 4, 24, 32), (3, 3, 20, 32)])
+def test_classifier_vs_oracle(V, H, W, E):
     """Plain path (convolutions on z_q).  W = 200: the frame-wide row-wrapping column-block numbering of conv_wide,
-    its zero borders, the wide weight-gradient kernel and the heads' strip kernels at both frame edges."""
+    its zero borders, the wide weight-gradient kernel and the heads' strip kernels at both frame edges.  E = 32 (config #4's
+    width): the 192 -> 192 joint head (weight gradient as a grid of 6 x 6-block sub-problems) and the 32 -> 32 heads (strip
+    weight gradient over (input block, output block) pairs)."""
     from oracle import idee_oracle as O
     from idee_amd.models.classifier.CNN_3D import CNN_3D
     N, T = (1 if W == 200 else 2), 8
 
     torch.manual_seed(V * 100 + W)
-    c = CNN_3D(in_var=V, embed_dim=16, dim=16, drop_rate=0.0)
+    c = CNN_3D(in_var=V, embed_dim=E, dim=E, drop_rate=0.0)
     sd = {k: v.clone() for k, v in c.state_dict().items()}
-    x = torch.randn(N, V, 16, T, H, W)
+    x = torch.randn(N, V, E, T, H, W)
     rz, ry = torch.randn(N, 1, H, W), torch.randn(V, N, 1, H, W)
     runs = []
     for mode in (0, 1):                      # oracle backward with the ReLU derivative at tie units forced to 0 / to 1
