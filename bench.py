@@ -353,9 +353,9 @@ def main():
     out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * batch * a.steps / dt, 3),
                unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
                ms_per_step_median=round(statistics.median(step_ms), 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f32" if a.math == "f32" else "f32 storage/accumulate, 16->16 convolutions on f16x3 (fwd) / bf16x3 (bwd) split MFMAs",
+               dtype="f32" if a.math == "f32" else "f32 storage/accumulate, 16->16 and 96-wide 3x3 convolutions (fwd, data gradient; 16->16 weight gradient) on f16x3 (fwd) / bf16x3 (bwd) split MFMAs",
                math=dict(conv="exact f32 MFMA (v_mfma_f32_16x16x4_f32)" if a.math == "f32" else
-                              "16->16 convs: two 16-bit pieces per operand, 3 piece products (f16 fwd, bf16 bwd); other convs exact f32 MFMA",
+                              "16->16 convs and the forward / data gradient of the 96-wide convs: two 16-bit pieces per operand, 3 piece products (f16 fwd, bf16 bwd); every other conv kernel exact f32 MFMA",
                          swin_gemm=("exact f32 MFMA" if os.environ.get("IDEE_SWIN_MATH") == "f32" or cfg.en_embed_dim[0] != 16 else
                                     "two 16-bit pieces per operand, all 4 piece products, f32 accumulate (f16 pieces fwd: 2^-22 operand "
                                     "rounding; bf16 pieces bwd: 2^-18); attention scores on the f32 MFMA"),

@@ -532,6 +532,175 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// conv_wide_kernel on split-precision MFMAs (opt-in, IDEE_CONV_MATH=split): K = 32 = TWO 16-channel groups of one tap, three
+// piece products per (tap, group pair, output block) — 18 f16 / bf16 MFMAs of 16 cycles where the f32 kernel issues 48 of 32.
+// f16 pieces in the forward mode (operands O(1): absolute piece floor 2^-25), bf16 pieces in the data gradient.  The tap's
+// weight slab is converted to piece fragments [w(group a) | w(group b)] (hi and lo) while it is staged into LDS, double
+// buffered as before; the activations of the two groups are split in registers right after their loads.  Gk even.
+// ---------------------------------------------------------------------------------------------
+template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT>
+__global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
+  constexpr int MT = 4, WAVES = 8;
+  constexpr bool F16 = MODE == FWD_S2;
+  extern __shared__ __attribute__((aligned(16))) unsigned s_ws[];   // [2][Gk/2 * NT * 2 pieces * 256 words]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  const int wset = b % a.wsets;
+  const int GP = a.Gk / 2;                                // channel-group pairs
+  const int slab = a.Gk * NT * 256;                       // f32 floats per tap in the packed buffer == words per split slab
+  const float* wp = a.wp + (long)wset * a.ntaps * slab;
+  const int npu = GP * NT * 64;                           // (pair, output block, lane) units per tap
+  const int NOT = (MODE == FWD_S2) ? a.kt : 1;
+  const int nblk = a.Ho * a.nsub;
+  // unit u = (gp * NT + n) * 64 + l: fragments of groups 2gp and 2gp+1 for output block n, lane l
+  auto load_unit = [&](int tap, int u, f32x4& fa, f32x4& fb) __attribute__((always_inline)) {
+    const int l = u & 63, r = u >> 6, n = r % NT, gp = r / NT;
+    const float* src = wp + (long)tap * slab;
+    fa = ld4(src + ((2 * gp) * NT + n) * 256 + l * 4);
+    fb = ld4(src + ((2 * gp + 1) * NT + n) * 256 + l * 4);
+  };
+  auto store_unit = [&](unsigned* dst, int u, f32x4 fa, f32x4 fb) __attribute__((always_inline)) {
+    const Split sa = split2<F16>(fa), sb = split2<F16>(fb);
+    const int l = u & 63, r = u >> 6;
+    *reinterpret_cast<u32x4*>(dst + ((r * 2 + 0) * 64 + l) * 4) = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
+    *reinterpret_cast<u32x4*>(dst + ((r * 2 + 1) * 64 + l) * 4) = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
+  };
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    const int tb = tile % a.hgroups, t = tile / a.hgroups;
+    const int blk0 = (tb * WAVES + wave) * MT;
+    const bool row_ok = blk0 < nblk;
+    int hm[MT], wm[MT];
+    bool vm[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int blk = blk0 + m;
+      vm[m] = blk < nblk;
+      hm[m] = blk / a.nsub;
+      wm[m] = (blk - hm[m] * a.nsub) * 16 + j;
+      vm[m] = vm[m] && wm[m] < a.Wo;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* in_b = a.in + (long)b * a.i_sB + 4 * kq;
+    const int ntap_it = NOT * 9;
+    auto tap_of = [&](int it) {
+      const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
+      const int tt = (MODE == FWD_S2) ? ot : (a.kt == 2 ? (t & 1) : 0);
+      return (tt * 3 + oh) * 3 + ow;
+    };
+    __syncthreads();                                     // previous tile's readers done
+    for (int u = tid; u < npu; u += 512) { f32x4 fa, fb; load_unit(tap_of(0), u, fa, fb); store_unit(s_ws, u, fa, fb); }
+    __syncthreads();
+
+    struct TapSrc { long off[MT]; bool okm[MT]; };
+    auto tap_src = [&](int it) {
+      TapSrc sx;
+      const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
+      const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const Slot sh = slot_h<MODE>(oh, hm[m], a.Hi);
+        bool ok;
+        const int q = src_w<MODE>(ow, wm[m], a.Wi, ok);
+        sx.okm[m] = vm[m] && st.ok && sh.ok && ok;
+        sx.off[m] = sx.okm[m] ? (long)st.src * a.i_sT + (long)sh.src * a.i_sH + (long)q * a.i_sW : 0;
+      }
+      return sx;
+    };
+    TapSrc cur = tap_src(0);
+    f32x4 xa[MT], xb[MT], na[MT], nb_[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xa[m] = cur.okm[m] ? ld4(in_b + cur.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xb[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int it = 0; it < ntap_it; ++it) {
+      const unsigned* wcur = s_ws + (it & 1) * slab;
+      unsigned* wnext = s_ws + ((it + 1) & 1) * slab;
+      // prefetch the next tap's raw fragments into registers (up to 3 units = 6 x 16 bytes per thread at 6 x 6 blocks)
+      f32x4 pa[3], pb[3];
+      const bool more = it + 1 < ntap_it;
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const int u = tid + q * 512; if (u < npu) load_unit(tap_of(it + 1), u, pa[q], pb[q]); }
+      }
+      TapSrc nxt = cur;
+      if (more) nxt = tap_src(it + 1);
+      for (int gp = 0; gp < GP; ++gp) {
+        if (gp + 1 < GP) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            na[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(2 * gp + 2, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            nb_[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(2 * gp + 3, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        } else if (more) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            na[m] = nxt.okm[m] ? ld4(in_b + nxt.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            nb_[m] = nxt.okm[m] ? ld4(in_b + nxt.off[m] + goff(1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        if (row_ok) {
+          u32x4 bh[MT], bl[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const Split sa = split2<F16>(xa[m]), sb = split2<F16>(xb[m]);
+            bh[m] = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
+            bl[m] = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
+          }
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const u32x4 ah = *reinterpret_cast<const u32x4*>(wcur + (((gp * NT + n) * 2 + 0) * 64 + lane) * 4);
+            const u32x4 al = *reinterpret_cast<const u32x4*>(wcur + (((gp * NT + n) * 2 + 1) * 64 + lane) * 4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(ah, bh[m], acc[m][n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(ah, bl[m], acc[m][n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(al, bh[m], acc[m][n]);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { xa[m] = na[m]; xb[m] = nb_[m]; }
+      }
+      cur = nxt;
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const int u = tid + q * 512; if (u < npu) store_unit(wnext, u, pa[q], pb[q]); }
+      }
+      __syncthreads();
+    }
+    if (!row_ok) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (!vm[m]) continue;
+      const long ro = (long)b * a.o_sB + (long)t * a.o_sT + (long)hm[m] * a.o_sH + (long)wm[m] * a.o_sW + 4 * kq;
+      float* out_r = a.out + ro;
+      const float* ref_r = a.relu_ref ? a.relu_ref + ro : nullptr;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 v = acc[m][n];
+        if (a.bias) v += ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq);
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const long o = goff(n, a.o_gpu, a.o_sU, a.o_sG);
+        if (ref_r) {
+          const f32x4 rr = ld4(ref_r + o);
+          v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+          v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+        }
+        if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
+        st4(out_r + o, v);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 16 -> 16 3x3x3 replicate convolution, forward and data gradient, activations staged through LDS.
 // (LDS row layout [channel quad][pixel][4 channels]: the 16 lanes of a quad read consecutive 16-byte chunks — the
@@ -1727,6 +1896,20 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
     if (!cin1 && gz == 1 && (NT >= 2 || (a.Gk >= 2 && a.Gk <= 6)) && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
       a.hgroups = cdiv((long)a.Ho * a.nsub, 32);            // workgroup tiles (8 waves x 4 column blocks) per plane
       a.tiles = a.To * a.hgroups;
+      if (conv_split_math() && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2)) {
+        const long lds2 = 2 * slab_bytes;
+#define LCS(NT_)                                                                                               \
+  do {                                                                                                         \
+    auto kern = conv_wide_split_kernel<MODE, NT_>;                                                             \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) \
+      return idee::fail(IDEE_ERR_LAUNCH, "conv: cannot reserve %ld bytes of LDS", lds2);                         \
+    const dim3 grid(one_round(a.tiles, a.B, 1), a.B);                                                          \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds2, stream, a);                                                \
+  } while (0)
+        if (NT == 6) LCS(6); else if (NT == 3) LCS(3); else LCS(2);
+#undef LCS
+        return IDEE_OK;
+      }
       const bool res = a.ntaps * slab_bytes <= 150 * 1024;      // every tap's weights stay in LDS
       const long lds_bytes = res ? a.ntaps * slab_bytes : 2 * slab_bytes;
 #define LCW2(NT_, RES_)                                                                                        \
