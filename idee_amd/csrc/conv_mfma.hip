@@ -887,6 +887,226 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
 
 
 // ---------------------------------------------------------------------------------------------
+// conv16_lds_kernel for the replicate modes with the row staging taken off the critical path: the source rows of the NEXT
+// output row are fetched by LDS-DMA (global_load_lds_dwordx4: no staging registers — the kernel sits at the 256-VGPR cap)
+// while the current row's MFMA chain runs.  Moving down one row replaces exactly the ring slot of the oldest source row,
+// so the 9 taps that read that row go FIRST and the DMA is issued right after their fragment reads have returned; the other
+// 18 taps (4,600 MFMA cycles) cover its latency.  (The register-staged kernel waits out every row's loads: two waves per
+// SIMD that interleave their MFMAs finish together and then wait together — 66 % MFMA-busy.)
+// An LDS-DMA writes 64 consecutive 16-byte chunks, so a staged row is pixel-major [pixel][4 chunks] — the global reads
+// stay coalesced — with the chunk position XOR-ed by (pixel >> 2) & 3 on the SOURCE side, which keeps the fragment reads
+// (16 lanes = 16 consecutive pixels, one channel quad) on 16 distinct bank groups.  The zero columns of the data
+// gradient's padded frame are written once per work unit; the DMA never touches them.
+// The DMA is inline asm (hipcc would drain it at the next LDS read of the same array): completion is counted here, with an
+// explicit s_waitcnt vmcnt(0) at the top of each row; asm loads older than a compiler load only make hipcc's own counted
+// waits stricter.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int MODE /*FWD_REP or DGRAD_REP*/>
+__global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
+  constexpr int MT = 2;
+  constexpr bool FWD = MODE == FWD_REP;
+  constexpr int kRowB = kC16Row * 64;                 // bytes of one staged row
+  __shared__ __attribute__((aligned(1024))) float s_xw[4][9 * kC16Row * 16];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  float* s_x = s_xw[wave];
+  const unsigned s_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)s_x);   // LDS byte address of this wave's ring
+  f32x4 wr[27];
+  int wkey = -1;
+  const f32x4 bias = a.bias ? ld4(a.bias + (long)wset * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wp = a.wp + (long)wset * a.ntaps * 256;
+  const int Wi = a.Wi;
+  const long i_sT = a.i_sT, i_sH = a.i_sH, i_sW = a.i_sW;
+  const int Wframe = FWD ? a.Wo : a.Wo + 2;
+  const int nsub = (Wframe + 15) / 16;
+  const int nb = a.B / a.wsets;
+  const long nunits = (long)nb * a.To * nhrun * nstrip;
+  // fragment read offsets (bytes inside a staged row) of the three W taps: pixel j + shift, chunk kq ^ ((pixel >> 2) & 3)
+  int lo[3];
+#pragma unroll
+  for (int ow = 0; ow < 3; ++ow) {
+    const int px = j + (FWD ? ow : 2 - ow);
+    lo[ow] = px * 64 + ((kq ^ ((px >> 2) & 3)) * 16);
+  }
+
+  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+    long r = un;      // t fastest: see conv16_lds_kernel
+    const int t = (int)(r % a.To); r /= a.To;
+    const int sp = (int)(r % nstrip); r /= nstrip;
+    const int hr = (int)(r % nhrun);
+    const int b = (int)(r / nhrun) * a.wsets + wset;
+    const int my_sub = min(MT, nsub - sp * MT);
+    const int p0 = sp * MT * 16;
+    const int rowlen = my_sub * 16 + 2;
+    const int h0 = hr * hrun, h1 = min(a.Ho, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;
+    const float* in_b = a.in + (long)b * a.i_sB;
+    Slot st[3];
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti, a.kt);
+    const int blk1 = my_sub > 1 ? 1024 : 0;           // a lone block re-reads block 0 (result unused)
+
+    // per-lane source of the three DMA pieces of a row: chunk c = lane + 64 k -> pixel c >> 2, stored position c & 3
+    long src_off0, src_off1, src_off2;
+    bool src_ok0, src_ok1, src_ok2;
+    {
+      auto piece = [&](int k, long& off, bool& ok) __attribute__((always_inline)) {
+        const int c = lane + 64 * k, px = c >> 2, q4 = (c & 3) ^ ((px >> 2) & 3);
+        int w;
+        ok = c < rowlen * 4;
+        if (FWD) w = min(max(p0 + px - 1, 0), Wi - 1);
+        else { w = p0 + px - 2; ok = ok && w >= 0 && w < Wi; w = min(max(w, 0), Wi - 1); }
+        off = (long)w * i_sW + 4 * q4;
+      };
+      piece(0, src_off0, src_ok0); piece(1, src_off1, src_ok1); piece(2, src_off2, src_ok2);
+    }
+    const int st_src[3] = {st[0].src, st[1].src, st[2].src};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_fence();                                     // the previous unit's reads and DMA are done
+    if (!FWD) {                                       // zero columns of the padded frame, all 9 staged rows
+      const bool zk[3] = {!src_ok0, !src_ok1, !src_ok2};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = lane + 64 * k;
+        if (c < rowlen * 4 && zk[k]) {
+#pragma unroll
+          for (int sr = 0; sr < 9; ++sr) st4(s_x + sr * (kC16Row * 16) + c * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+      }
+    }
+    // STAGE_ROWS(h): DMA the source rows output row `h` needs and the ring does not hold (completion awaited by the caller)
+#define STAGE_ROWS(H_)                                                                                         \
+  _Pragma("unroll") for (int oh_ = 0; oh_ < 3; ++oh_) {                                                        \
+    const int hs_ = slot_h<MODE>(oh_, (H_), a.Hi).src;                                                         \
+    const int slot_ = hs_ % 3;                                                                                 \
+    const int cur_ = slot_ == 0 ? res0 : slot_ == 1 ? res1 : res2;                                             \
+    if (cur_ != hs_ + 1) {                                                                                     \
+      if (slot_ == 0) res0 = hs_ + 1; else if (slot_ == 1) res1 = hs_ + 1; else res2 = hs_ + 1;                \
+      _Pragma("unroll") for (int ot_ = 0; ot_ < 3; ++ot_) {                                                    \
+        const float* src_ = in_b + (long)st_src[ot_] * i_sT + (long)hs_ * i_sH;                                \
+        const unsigned dst_ = s_base + (unsigned)((ot_ * 3 + slot_) * kRowB);                                  \
+        if (src_ok0) glds16(src_ + src_off0, dst_);                                                            \
+        if (src_ok1) glds16(src_ + src_off1, dst_ + 1024);                                                     \
+        if (src_ok2) glds16(src_ + src_off2, dst_ + 2048);                                                     \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+    STAGE_ROWS(h0)
+
+    // VM operations certain to be issued after a row's DMA: the epilogue's stores / atomics (its loads are not counted: a
+    // lower bound keeps the counted wait below safe).  Same for every row of the unit.
+    int n_late = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m >= my_sub) continue;
+      const int pb = p0 + m * 16, pe = min(pb + 15, Wframe - 1);
+      if (FWD) n_late += 1;
+      else { n_late += (max(pb, 2) <= min(pe, a.Wo - 1)) ? 1 : 0; n_late += (pb <= 1 || pe >= a.Wo) ? 4 : 0; }
+    }
+
+    for (int h = h0; h < h1; ++h) {
+      // the DMA of this row's sources must have landed; the previous row's stores (younger, retired in order after it) need not
+      if (h == h0 || n_late == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (n_late == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if (n_late <= 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      wave_fence();
+      Slot sh[3];
+      int slot_of[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) { sh[oh] = slot_h<MODE>(oh, h, a.Hi); slot_of[oh] = sh[oh].src % 3; }
+      {
+        const int key = ((((st[0].tap * 3 + st[1].tap) * 3 + st[2].tap) * 3 + sh[0].tap) * 3 + sh[1].tap) * 3 + sh[2].tap;
+        if (key != wkey) {
+          wkey = key;
+#pragma unroll
+          for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+            for (int oh = 0; oh < 3; ++oh)
+#pragma unroll
+              for (int ow = 0; ow < 3; ++ow)
+                wr[(ot * 3 + oh) * 3 + ow] = ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * 256 + lane * 4);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      f32x4 acc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* rowq[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) rowq[oh] = reinterpret_cast<const char*>(s_x) + slot_of[oh] * kRowB;
+      // tap order: the source row the next output row replaces first (fwd: oh = 0; data gradient: oh = 2)
+      f32x4 xb[2][2];
+      auto rd = [&](int tp, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
+        const int oi = tp / 9, ot = (tp / 3) % 3, ow = tp % 3;
+        const int oh = FWD ? oi : 2 - oi;
+        const char* rp = rowq[oh] + ot * 3 * kRowB + lo[ow];
+        x0 = *reinterpret_cast<const f32x4*>(rp);
+        x1 = *reinterpret_cast<const f32x4*>(rp + blk1);
+      };
+#define TAPS(T0_, T1_)                                                                                         \
+  _Pragma("unroll") for (int tp = (T0_); tp < (T1_); ++tp) {                                                   \
+    if (tp + 1 < 27) rd(tp + 1, xb[(tp + 1) & 1][0], xb[(tp + 1) & 1][1]);                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    const int oi = tp / 9, ot = (tp / 3) % 3, ow = tp % 3;                                                     \
+    const f32x4 wf = wr[(ot * 3 + (FWD ? oi : 2 - oi)) * 3 + ow];                                              \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                            \
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][0][s], acc[0], 0, 0, 0);                 \
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][1][s], acc[1], 0, 0, 0);                 \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+      rd(0, xb[0][0], xb[0][1]);
+      TAPS(0, 9)
+      // the fragments of the first 9 taps have been read (tap 9's were issued after them; DS ops complete in order)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (h + 1 < h1) { STAGE_ROWS(h + 1) }
+      __builtin_amdgcn_sched_barrier(0);
+      TAPS(9, 27)
+#undef TAPS
+      // epilogue (as conv16_lds_kernel)
+      float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+      const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (m >= my_sub) continue;
+        const int p = p0 + m * 16 + j;
+        if (p >= Wframe) continue;
+        int wdst = p;
+        bool atomic = false;
+        if (!FWD) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
+        f32x4 v = acc[m];
+        v += bias;
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const long o = (long)wdst * a.o_sW + 4 * kq;
+        if (ref_r) {
+          const f32x4 rr = ld4(ref_r + o);
+          v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+          v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+        }
+        if (atomic) {
+          atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
+          atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
+        } else {
+          if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
+          st4(out_r + o, v);
+        }
+      }
+    }
+  }
+#undef STAGE_ROWS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // conv16_lds_kernel on split-precision MFMAs (opt-in: IDEE_CONV_MATH=split; reported as its own bench line).
 // Every f32 operand is cut into two 16-bit pieces x = hi + lo (common.h split2): f16 pieces in the FORWARD modes (11 + 11
 // mantissa bits: f32-level, operands are O(1); the weights are pre-scaled by a power of two into f16's normal range and the
@@ -1849,6 +2069,26 @@ inline int one_round(long work_items, long others, int per_cu) {
   return (int)gx;
 }
 
+// Rows per run for the wave-private strip kernels: a work unit is one run of `hrun` rows of one (strip, frame); every wave of a
+// grid slice takes ceil(units / waves) of them, so the makespan is that count x (hrun + the unit's start-up, ~1.5 row times)
+// — minimised over the number of runs (runs of at least 8 rows).  (A fixed "about 5 units per wave" rule cost 12 % at the
+// headline shape: 5.27 units per wave means some waves run 6.)
+inline int pick_hrun(int H, long base_units, long slices, int per_cu) {
+  long gx_full = ((long)kCUs * per_cu) / (slices > 0 ? slices : 1);
+  if (gx_full < 1) gx_full = 1;
+  int best = H;
+  double best_cost = 1e30;
+  for (int nhr = 1; nhr <= (H + 7) / 8; ++nhr) {
+    const int hrun = cdiv(H, nhr);
+    const long units = base_units * cdiv(H, hrun);
+    const long gx = gx_full < cdiv(units, 4) ? gx_full : cdiv(units, 4);
+    const long per = cdiv(units, gx * 4);
+    const double cost = (double)per * (hrun + 1.5);
+    if (cost < best_cost * 0.995) { best_cost = cost; best = hrun; }
+  }
+  return best;
+}
+
 void split_tiles(ConvArgs& a, int Wframe) {
   a.nsub = cdiv(Wframe, 16);
   a.wtiles = cdiv(a.nsub, 4);
@@ -1875,8 +2115,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
       const int nstrip = cdiv(cdiv(Wframe, 16), 2);
       const long bt = (long)(a.B / a.wsets) * a.To;
-      int hrun = a.Ho;                                      // runs short enough for ~5 work units per resident wave
-      while (hrun > 8 && bt * cdiv(a.Ho, hrun) * nstrip * a.wsets < 5L * kCUs * 8) hrun = (hrun + 1) / 2;
+      const int hrun = pick_hrun(a.Ho, bt * nstrip, a.wsets, 2);
       const int nhrun = cdiv(a.Ho, hrun);
       const long nunits = bt * nhrun * nstrip;
       if (conv_split_math()) {      // opt-in split-precision path: f16 pieces forward, bf16 pieces in the data gradient
@@ -1884,6 +2123,15 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
         hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
         return IDEE_OK;
+      }
+      if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
+        static const bool reg_staged = [] { const char* e = getenv("IDEE_CONV16"); return e && strcmp(e, "regs") == 0; }();
+        if (!reg_staged) {
+          auto kern = conv16_glds_kernel<MODE>;
+          const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
+          hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
+          return IDEE_OK;
+        }
       }
       auto kern = conv16_lds_kernel<MODE>;
       const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
@@ -2089,8 +2337,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const int nstrip = cdiv(cdiv(d->W, 16), 2);
     const int gz = (d->mode == IDEE_CONV_K133_ZERO && Gb > 1) ? Gb / 3 : Ga * Gb;      // (input block, output block group) pairs
     const long btr = (long)(d->B / d->wsets) * a.To;
-    int hr2 = d->H;                                       // runs short enough for ~5 work units per resident wave
-    while (hr2 > 8 && btr * cdiv(d->H, hr2) * nstrip * d->wsets * gz < 5L * kCUs * 8) hr2 = (hr2 + 1) / 2;
+    const int hr2 = pick_hrun(d->H, btr * nstrip, (long)d->wsets * gz, 2);
     const int nhr2 = cdiv(d->H, hr2);
     const long nunits = btr * nhr2 * nstrip;
 #define LSTRIP(KERN)                                                                                          \
