@@ -46,3 +46,6 @@ int main() {
   return 0;
 }
 // build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfma_clock tools/micro/mfma_clock.hip && ./tools/micro/mfma_clock
+// measured (MI355X): constant operands 34.52 ms 155.5 TFLOP/s | random operands 34.79 ms 154.3 TFLOP/s  -> 99 % of the 157.3 TFLOP/s
+// f32 MFMA peak is reachable chip-wide with random data (no clock drop); the two counters above do not tick at the core / 100 MHz
+// rates on this part (ratio 23.9), so the rate comes from the event time.
