@@ -28,6 +28,7 @@ int fail(int code, const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int imin(long a, long b) { return (int)(a < b ? a : b); }
+static inline int imax(long a, long b) { return (int)(a > b ? a : b); }
 
 // number of workgroups that fills the chip a few times over (256 CUs)
 constexpr int kCUs = 256;

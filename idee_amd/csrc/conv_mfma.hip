@@ -344,19 +344,25 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
   const int slab4 = slab / 4;
   const int NOT = (MODE == FWD_S2) ? a.kt : 1;            // T-slots
 
-  // a (b, t) plane is cut into 16-pixel column blocks, numbered row-major; a wave owns MT consecutive blocks (they
-  // may wrap to the next row), a workgroup WAVES * MT of them: no partially filled wave tiles at any width
+  // a (b, t) plane is cut into 16-pixel column blocks, numbered row-major; the `hgroups` workgroups of a plane take equal
+  // contiguous ranges of them and walk their range in chunks of WAVES * MT blocks — a wave owns up to MT consecutive blocks
+  // (they may wrap to the next row) and issues MFMAs only for the `nm` it has, so a range that is not a whole number of chunks
+  // costs its last chunk pro rata (fixed tiles of 32 blocks gave 2.56 tiles per workgroup at the headline shape: 3 rounds)
   const int nblk = a.Ho * a.nsub;
-  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
-    const int tb = tile % a.hgroups, t = tile / a.hgroups;      // hgroups = workgroup tiles per plane
-    const int blk0 = (tb * WAVES + wave) * MT;
-    const bool row_ok = blk0 < nblk;
+  bool first = true;
+  for (int wgp = blockIdx.x; wgp < a.To * a.hgroups; wgp += gridDim.x) {
+   const int t = wgp / a.hgroups, rg = wgp - t * a.hgroups;
+   const int r_lo = (int)((long)rg * nblk / a.hgroups), r_hi = (int)((long)(rg + 1) * nblk / a.hgroups);
+   for (int c0 = r_lo; c0 < r_hi; c0 += WAVES * MT) {
+    const int blk0 = c0 + wave * MT;
+    const int nm = __builtin_amdgcn_readfirstlane(min(max(r_hi - blk0, 0), MT));
+    const bool row_ok = nm > 0;
     int hm[MT], wm[MT];
     bool vm[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int blk = blk0 + m;
-      vm[m] = blk < nblk;
+      vm[m] = m < nm;
       hm[m] = blk / a.nsub;
       wm[m] = (blk - hm[m] * a.nsub) * 16 + j;
       vm[m] = vm[m] && wm[m] < a.Wo;
@@ -375,7 +381,8 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
       return (tt * 3 + oh) * 3 + ow;
     };
     if constexpr (RES) {
-      if (tile == (int)blockIdx.x) {                       // once per workgroup
+      if (first) {                                         // once per workgroup
+        first = false;
         for (int u = tid; u < a.ntaps * slab4; u += 512) st4(s_wd + 4 * u, ld4(wp + 4 * u));
         __syncthreads();
       }
@@ -447,10 +454,11 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
           const int g = step / ntap_it, it = step - g * ntap_it;
           const f32x4 wf = ld4(s_wd + tap_of(it) * slab + g * 256 + lane * 4);
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+          for (int m = 0; m < MT; ++m)
+            if (m < nm) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xq[r][m][s], acc[m][0], 0, 0, 0);
+              for (int s = 0; s < 4; ++s) acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xq[r][m][s], acc[m][0], 0, 0, 0);
+            }
           if (step + 3 < total) issue(step + 3, xq[r]);
         }
       }
@@ -486,10 +494,11 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
             for (int n = 0; n < NT; ++n) {
               const f32x4 wf = ld4(wcur + (g * NT + n) * 256 + lane * 4);
   #pragma unroll
-              for (int s = 0; s < 4; ++s)
+              for (int m = 0; m < MT; ++m)
+                if (m < nm) {
   #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
+                  for (int s = 0; s < 4; ++s) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
+                }
             }
           }
   #pragma unroll
@@ -529,6 +538,7 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
         st4(out_r + o, v);
       }
     }
+   }
   }
 }
 
@@ -568,16 +578,19 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
     *reinterpret_cast<u32x4*>(dst + ((r * 2 + 0) * 64 + l) * 4) = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
     *reinterpret_cast<u32x4*>(dst + ((r * 2 + 1) * 64 + l) * 4) = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
   };
-  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
-    const int tb = tile % a.hgroups, t = tile / a.hgroups;
-    const int blk0 = (tb * WAVES + wave) * MT;
-    const bool row_ok = blk0 < nblk;
+  for (int wgp = blockIdx.x; wgp < a.To * a.hgroups; wgp += gridDim.x) {     // ranges and chunks: see conv_wide_kernel
+   const int t = wgp / a.hgroups, rg = wgp - t * a.hgroups;
+   const int r_lo = (int)((long)rg * nblk / a.hgroups), r_hi = (int)((long)(rg + 1) * nblk / a.hgroups);
+   for (int c0 = r_lo; c0 < r_hi; c0 += WAVES * MT) {
+    const int blk0 = c0 + wave * MT;
+    const int nm = __builtin_amdgcn_readfirstlane(min(max(r_hi - blk0, 0), MT));
+    const bool row_ok = nm > 0;
     int hm[MT], wm[MT];
     bool vm[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int blk = blk0 + m;
-      vm[m] = blk < nblk;
+      vm[m] = m < nm;
       hm[m] = blk / a.nsub;
       wm[m] = (blk - hm[m] * a.nsub) * 16 + j;
       vm[m] = vm[m] && wm[m] < a.Wo;
@@ -659,11 +672,12 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
             const u32x4 ah = *reinterpret_cast<const u32x4*>(wcur + (((gp * NT + n) * 2 + 0) * 64 + lane) * 4);
             const u32x4 al = *reinterpret_cast<const u32x4*>(wcur + (((gp * NT + n) * 2 + 1) * 64 + lane) * 4);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(ah, bh[m], acc[m][n]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(ah, bl[m], acc[m][n]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(al, bh[m], acc[m][n]);
+            for (int m = 0; m < MT; ++m)
+              if (m < nm) {
+                acc[m][n] = mfma_s<F16>(ah, bh[m], acc[m][n]);
+                acc[m][n] = mfma_s<F16>(ah, bl[m], acc[m][n]);
+                acc[m][n] = mfma_s<F16>(al, bh[m], acc[m][n]);
+              }
           }
         }
 #pragma unroll
@@ -698,6 +712,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
         st4(out_r + o, v);
       }
     }
+   }
   }
 }
 
@@ -2142,8 +2157,12 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   if constexpr (MODE == FWD_S2 || MODE == DGRAD_S2) {
     const long slab_bytes = (long)a.Gk * NT * 256 * 4;
     if (!cin1 && gz == 1 && (NT >= 2 || (a.Gk >= 2 && a.Gk <= 6)) && a.cout_real != 1 && 2 * slab_bytes <= 150 * 1024 && a.Gk * NT * 64 <= 5 * 512) {
-      a.hgroups = cdiv((long)a.Ho * a.nsub, 32);            // workgroup tiles (8 waves x 4 column blocks) per plane
-      a.tiles = a.To * a.hgroups;
+      {   // workgroups per (b, t) plane: the chip's workgroups of this batch item spread over its To planes, and no more than
+          // the plane has chunks of 32 column blocks (8 waves x 4)
+        const int g_b = kCUs / a.B > 0 ? kCUs / a.B : 1;
+        a.hgroups = imin(imax(g_b / a.To, 1), cdiv((long)a.Ho * a.nsub, 32));
+        a.tiles = a.To * a.hgroups;
+      }
       if (conv_split_math() && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2)) {
         const long lds2 = 2 * slab_bytes;
 #define LCS(NT_)                                                                                               \

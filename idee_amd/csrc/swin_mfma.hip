@@ -21,7 +21,7 @@ namespace {
 using namespace idee;
 
 struct Geom {
-  int V, D, H, W, Dp, Hp, Wp;
+  int N, V, D, H, W, Dp, Hp, Wp;   // N: batch items per variable (batch index b = n * V + v)
   int wd, wh, ww, sd, sh, sw;
   int nWh, nWw, nWin;   // windows per batch item
   int items;            // window groups (64 tokens) per batch item
@@ -1610,12 +1610,14 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
   __shared__ __attribute__((aligned(16))) int s_rid[WPB][16 * MTK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.y, v = b % g.V;
+  // grid: (workgroups, V).  A workgroup stays with ONE variable's weights (its gradient accumulators live in registers across
+  // the loop) and walks the window groups of all N batch items of that variable — with one grid row per batch item the
+  // 256 CUs took floor(256 / (N V)) N V = 240 workgroups at the headline shape.
+  const int v = blockIdx.y;
   qkv_w += (long)v * 3 * C * C;  qkv_b += v * 3 * C;  proj_w += (long)v * C * C;
   rel_bias += (long)v * NH * NW * NW;
   g_qkv_w += (long)v * 3 * C * C;  g_qkv_b += v * 3 * C;  g_proj_w += (long)v * C * C;  g_proj_b += v * C;
   g_rel_bias += (long)v * NH * NW * NW;
-  const float ps1 = g.path_scale ? g.path_scale[2 * b] : 1.f;
 
   constexpr int NRB = NH * TPW * TPW;
   constexpr int W_Q = 0, W_QT = 3 * CT * CT, W_PT = 6 * CT * CT, NWT = 7 * CT * CT;
@@ -1690,7 +1692,10 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
   unsigned* tileS = tileP + TILEW;
   int* rid_l = s_rid[wave];
 
-  for (int it0 = blockIdx.x * WPB; it0 < g.items; it0 += gridDim.x * WPB) {
+  const int gpb = (g.items + WPB - 1) / WPB;            // window groups of WPB work items per batch item
+  for (int grp = blockIdx.x; grp < g.N * gpb; grp += gridDim.x) {
+    const int n = grp / gpb, it0 = (grp - n * gpb) * WPB, b = n * g.V + v;
+    const float ps1 = g.path_scale ? g.path_scale[2 * b] : 1.f;
     Tok t[MTK];
     bool keep[MTK];
     f32x4 X[CT][MTK], DH[CT][MTK];
@@ -1987,7 +1992,7 @@ int make_geom(const idee_swin_geom* s, Geom& g, int& NW) {
                  "swin: shift must lie in [0, window)");
   IDEE_CHECK_ARG(s->hidden == 4 * s->C, "swin: only mlp_ratio 4 is built (hidden %d, C %d)", s->hidden, s->C);
   NW = s->wd * s->wh * s->ww;
-  g.V = s->V; g.D = s->D; g.H = s->H; g.W = s->W;
+  g.N = s->N; g.V = s->V; g.D = s->D; g.H = s->H; g.W = s->W;
   g.wd = s->wd; g.wh = s->wh; g.ww = s->ww; g.sd = s->sd; g.sh = s->sh; g.sw = s->sw;
   g.Dp = cdiv(s->D, s->wd) * s->wd; g.Hp = cdiv(s->H, s->wh) * s->wh; g.Wp = cdiv(s->W, s->ww) * s->ww;
   g.nWh = g.Hp / s->wh; g.nWw = g.Wp / s->ww;
@@ -2096,13 +2101,14 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
   Geom ga = g;
   ga.items = cdiv(g.nWin, (16 * MTK) / NW);
   const dim3 grid = swin_grid(cdiv(ga.items, WPB), B, 1);
+  const dim3 grid_v = swin_grid(cdiv(ga.items, WPB) * s->N, s->V, 1);      // split kernels: one grid row per variable
 #define CALL(C_, NH_, NW_)                                                                                           \
   if (C_ == 32 && split)                                                                                             \
-    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<32, NH_, NW_, 4, 2, false>), grid, dim3(256), 0, st, x,               \
+    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<32, NH_, NW_, 4, 2, false>), grid_v, dim3(256), 0, st, x,             \
                        dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,  \
                        d->proj_b, d->rel_bias, ga);                                                                  \
   else if (C_ == 16 && split)                                                                                        \
-    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<16, NH_, NW_, 8, 2, true>), grid, dim3(512), 0, st, x,                \
+    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<16, NH_, NW_, 8, 2, true>), grid_v, dim3(512), 0, st, x,              \
                        dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,  \
                        d->proj_b, d->rel_bias, ga);                                                                  \
   else                                                                                                               \
