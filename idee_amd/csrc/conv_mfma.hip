@@ -454,11 +454,10 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
           const int g = step / ntap_it, it = step - g * ntap_it;
           const f32x4 wf = ld4(s_wd + tap_of(it) * slab + g * 256 + lane * 4);
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            if (m < nm) {
+          for (int s = 0; s < 4; ++s)      // all MT blocks unconditionally: branches here break the load / MFMA interleave
 #pragma unroll
-              for (int s = 0; s < 4; ++s) acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xq[r][m][s], acc[m][0], 0, 0, 0);
-            }
+            for (int m = 0; m < MT; ++m)
+              acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xq[r][m][s], acc[m][0], 0, 0, 0);
           if (step + 3 < total) issue(step + 3, xq[r]);
         }
       }
