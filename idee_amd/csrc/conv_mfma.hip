@@ -2088,6 +2088,10 @@ inline int one_round(long work_items, long others, int per_cu) {
 // — minimised over the number of runs (runs of at least 8 rows).  (A fixed "about 5 units per wave" rule cost 12 % at the
 // headline shape: 5.27 units per wave means some waves run 6.)
 inline int pick_hrun(int H, long base_units, long slices, int per_cu) {
+  if (const char* e = getenv("IDEE_CONV_HRUN")) {       // test knob: force short runs so small shapes cross run boundaries
+    const int v = atoi(e);
+    if (v > 0) return v < H ? v : H;
+  }
   long gx_full = ((long)kCUs * per_cu) / (slices > 0 ? slices : 1);
   if (gx_full < 1) gx_full = 1;
   int best = H;

@@ -185,13 +185,15 @@ def test_conv_block_golden(tag, cin):
         gclose("d" + k, p.grad[0], gref)
 
 
-@pytest.mark.parametrize("T,H,W", [(8, 9, 72), (3, 5, 200), (8, 6, 200), (1, 1, 1), (2, 2, 17)])
-def test_proj_var_vs_oracle(T, H, W):
+@pytest.mark.parametrize("T,H,W", [(8, 9, 72), (3, 5, 200), (8, 6, 200), (1, 1, 1), (2, 2, 17), (3, 21, 40)])
+def test_proj_var_vs_oracle(T, H, W, monkeypatch):
     """Multi-tile widths (72 = 3+2 column blocks, 200 = 4+3+3+3 incl. both frame edges), thin extents
     (clamp-everything cases).  Strict gradient tolerance on a tie-free case."""
     from oracle import idee_oracle as O
     ops = _ops()
     N, V, C = 2, 2, 16
+    if H == 21:      # rows walked in runs of 8, 8, 5: the strip kernels' run starts away from row 0 (the headline shape's 67-row
+        monkeypatch.setenv("IDEE_CONV_HRUN", "8")    # runs are otherwise only reached by the full-size tests)
 
     def build(seed):
         g = torch.Generator().manual_seed(seed)
@@ -310,8 +312,8 @@ def test_classifier_golden():
 
 
 @pytest.mark.parametrize("V,H,W,E", [(3, 7, 72, 16), (6, 5, 40, 16), (1, 3, 3, 16), (5, 4, 20, 16), (6, 6, 200, 16), (2, 3, 200, 16),
-                                     (6, 4, 24, 32), (3, 3, 20, 32)])
-def test_classifier_vs_oracle(V, H, W, E):
+                                     (6, 4, 24, 32), (3, 3, 20, 32), (2, 19, 40, 16)])
+def test_classifier_vs_oracle(V, H, W, E, monkeypatch):
     """Plain path (convolutions on z_q).  W = 200: the frame-wide row-wrapping column-block numbering of conv_wide,
     its zero borders, the wide weight-gradient kernel and the heads' strip kernels at both frame edges.  E = 32 (config #4's
     width): the 192 -> 192 joint head (weight gradient as a grid of 6 x 6-block sub-problems) and the 32 -> 32 heads (strip
@@ -319,6 +321,8 @@ def test_classifier_vs_oracle(V, H, W, E):
     from oracle import idee_oracle as O
     from idee_amd.models.classifier.CNN_3D import CNN_3D
     N, T = (1 if W == 200 else 2), 8
+    if H == 19:      # the heads' strip kernels in runs of 8, 8, 3 rows (run starts away from row 0)
+        monkeypatch.setenv("IDEE_CONV_HRUN", "8")
 
     torch.manual_seed(V * 100 + W)
     c = CNN_3D(in_var=V, embed_dim=E, dim=E, drop_rate=0.0)
