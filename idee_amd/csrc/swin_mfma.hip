@@ -115,13 +115,16 @@ __device__ __forceinline__ Tok locate(const Geom& g, int b, int item, int tau, i
   const int wlc = active ? wl : 0;
   // x / d for small non-negative x: (x + 0.5) * (1/d) truncated is exact while x < 2^22 (grids here are < 2^21 windows)
   auto fdiv = [](int x, float inv) { return (int)(((float)x + 0.5f) * inv); };
-  const int nWhW = g.nWh * g.nWw;
-  const int iwd = fdiv(wlc, g.inv_nWhW), r = wlc - iwd * nWhW;
-  const int iwh = fdiv(r, g.inv_nWw), iww = r - iwh * g.nWw;
-  const int whww = g.wh * g.ww;
-  const int dt = fdiv(i, g.inv_whww), r2 = i - dt * whww;
-  const int dh = fdiv(r2, g.inv_ww), dw = r2 - dh * g.ww;
-  const int pd = iwd * g.wd + dt, ph = iwh * g.wh + dh, pw = iww * g.ww + dw;   // rolled frame
+  // every factor below is < 2^24 (window and frame extents, window indices < 2^22), so the products go through the
+  // full-rate 24-bit multiplier (v_mul_u32_u24 / v_mad_u32_u24; v_mul_lo_u32 issues at a quarter of that rate)
+  auto m24 = [](int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); };
+  const int nWhW = m24(g.nWh, g.nWw);
+  const int iwd = fdiv(wlc, g.inv_nWhW), r = wlc - m24(iwd, nWhW);
+  const int iwh = fdiv(r, g.inv_nWw), iww = r - m24(iwh, g.nWw);
+  const int whww = m24(g.wh, g.ww);
+  const int dt = fdiv(i, g.inv_whww), r2 = i - m24(dt, whww);
+  const int dh = fdiv(r2, g.inv_ww), dw = r2 - m24(dh, g.ww);
+  const int pd = m24(iwd, g.wd) + dt, ph = m24(iwh, g.wh) + dh, pw = m24(iww, g.ww) + dw;   // rolled frame
   auto axis = [](int p, int P, int w, int s) { return s == 0 ? 2 : (int)(p >= P - w) + (int)(p >= P - s); };
   t.rid = axis(pd, g.Dp, g.wd, g.sd) * 9 + axis(ph, g.Hp, g.wh, g.sh) * 3 + axis(pw, g.Wp, g.ww, g.sw);
   int sd_ = pd + g.sd, sh_ = ph + g.sh, sw_ = pw + g.sw;                         // un-rolled frame
@@ -129,7 +132,10 @@ __device__ __forceinline__ Tok locate(const Geom& g, int b, int item, int tau, i
   if (sh_ >= g.Hp) sh_ -= g.Hp;
   if (sw_ >= g.Wp) sw_ -= g.Wp;
   t.valid = active && sd_ < g.D && sh_ < g.H && sw_ < g.W;
-  t.off = ((((long)b * g.D + sd_) * g.H + sh_) * g.W + sw_) * C;
+  // token index: (b D + sd) H + sh < 2^24 and the token count of the tensor < 2^32 (checked in make_geom)
+  const unsigned row = (unsigned)m24(m24(b, g.D) + sd_, g.H) + (unsigned)sh_;
+  const unsigned tok = __umul24(row, (unsigned)g.W) + (unsigned)sw_;
+  t.off = (long)tok * C;
   return t;
 }
 
@@ -2006,6 +2012,11 @@ int make_geom(const idee_swin_geom* s, Geom& g, int& NW) {
   g.inv_nWhW = 1.0f / (float)(g.nWh * g.nWw); g.inv_nWw = 1.0f / (float)g.nWw;
   g.inv_whww = 1.0f / (float)(g.wh * g.ww);   g.inv_ww = 1.0f / (float)g.ww;
   if ((long)g.nWin >= (1L << 22)) return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: %d windows per batch item exceeds 2^22", g.nWin);
+  // the token addressing multiplies 24-bit factors (locate()): rows (N V D H) and the frame width below 2^24, tokens below 2^32
+  if ((long)s->N * s->V * s->D * s->H >= (1L << 24) || s->W >= (1 << 24) || g.Dp >= (1 << 24) || g.Hp >= (1 << 24) ||
+      (long)s->N * s->V * s->D * s->H * s->W >= (1L << 32))
+    return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: tensor of %d x %d x %d x %d x %d tokens is beyond the 24-bit index arithmetic",
+                      s->N, s->V, s->D, s->H, s->W);
   return IDEE_OK;
 }
 
