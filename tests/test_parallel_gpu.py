@@ -60,3 +60,66 @@ def test_two_ranks_product_step_equals_one_rank(kind, tmp_path):
     for k in ("extreme", "var"):          # global class counts -> identical weighting; means over equal shards
         assert two["parts"][k] == pytest.approx(one["parts"][k], rel=0.5) or kind == "era5"
     assert two["total2"] == pytest.approx(two["total2"])
+
+
+def test_two_host_threads_step_concurrently_on_their_own_streams():
+    """The library is re-entrant (forward on the caller's thread, backward on autograd engine threads, one
+    thread per replica under DataParallel): two host threads, each with its own model, optimizer and HIP stream, run train
+    steps at the same time on one device; each must reproduce what it computes alone (the only run-to-run difference the
+    kernels allow is the order of float atomics in the weight-gradient flushes)."""
+    import threading
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    from idee_amd.train import SyntheticTrainStep
+
+    kw = dict(encoder="Swin_3D", in_channels=1, in_channels_dynamic=3)
+    N, T, H, W = 2, 8, 24, 40
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn((N, 3, 1, T, H, W), generator=g).clamp_(-10, 10)
+        me = (torch.rand((N, H, W), generator=g) < 0.10).float()
+        ml = (torch.rand((N, H, W), generator=g) < 0.20).float()
+        return [t.to("cuda") for t in (x, me, ml)]
+
+    def make(seed):            # on the main thread: model initialisation draws from the process-wide CPU generator
+        torch.manual_seed(100 + seed)
+        st = SyntheticTrainStep(default_config(**kw), model=VQ_model(default_config(**kw)))
+        with torch.no_grad():
+            st.model.vq.project_in.weight.mul_(20.0)     # keep tokens off the LFQ sign boundary (parameters are views of flat_p)
+        return st, [batch(seed * 10 + k) for k in range(3)]
+
+    def run(seed, st, batches, stream, out):
+        try:
+            with torch.cuda.stream(stream):
+                losses = []
+                for b in batches:
+                    total, parts, _ = st.step(*b)
+                    losses.append(torch.stack([total.reshape(())] + [parts[n].reshape(()) for n in ("extreme", "anomaly", "var", "z_q")]))
+                stream.synchronize()
+                out[seed] = (torch.stack(losses).float().cpu(), st.opt.flat_p.detach().float().cpu().clone())
+        except BaseException as e:          # surfaced by the main thread
+            out[seed] = e
+
+    alone, together = {}, {}
+    for seed in (1, 2):
+        st, bs = make(seed)
+        torch.cuda.synchronize()
+        run(seed, st, bs, torch.cuda.Stream(), alone)
+    jobs = [(seed,) + make(seed) for seed in (1, 2)]
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=run, args=(seed, st, bs, torch.cuda.Stream(), together)) for seed, st, bs in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for seed in (1, 2):
+        for res in (alone[seed], together[seed]):
+            if isinstance(res, BaseException):
+                raise res
+        la, pa = alone[seed]
+        lt, pt = together[seed]
+        assert torch.isfinite(lt).all()
+        torch.testing.assert_close(lt, la, rtol=2e-4, atol=1e-6)
+        d = (pt - pa).abs()
+        assert float(d.max()) <= 2.5e-3 and float((d > 2e-5).float().mean()) < 5e-3, (float(d.max()), float((d > 2e-5).float().mean()))
