@@ -922,7 +922,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
 }
 
 template <int MODE /*FWD_REP or DGRAD_REP*/>
-__global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
+__global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nstrip, int nfull) {
   constexpr int MT = 2;
   constexpr bool FWD = MODE == FWD_REP;
   constexpr int kRowB = kC16Row * 64;                 // bytes of one staged row
@@ -941,7 +941,6 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
   const int Wframe = FWD ? a.Wo : a.Wo + 2;
   const int nsub = (Wframe + 15) / 16;
   const int nb = a.B / a.wsets;
-  const long nunits = (long)nb * a.To * nhrun * nstrip;
   // fragment read offsets (bytes inside a staged row) of the three W taps: pixel j + shift, chunk kq ^ ((pixel >> 2) & 3)
   int lo[3];
 #pragma unroll
@@ -950,22 +949,51 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
     lo[ow] = px * 64 + ((kq ^ ((px >> 2) & 3)) * 16);
   }
 
-  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
-    long r = un;      // t fastest: see conv16_lds_kernel
-    const int t = (int)(r % a.To); r /= a.To;
-    const int sp = (int)(r % nstrip); r /= nstrip;
-    const int hr = (int)(r % nhrun);
-    const int b = (int)(r / nhrun) * a.wsets + wset;
+  // Work partition (static, cost-balanced): the 4 waves of a workgroup take 4 CONSECUTIVE output frames (a frame group) of one
+  // strip — the source rows they share are fetched from HBM once — and walk rows of the strip's (batch item, frame group, row)
+  // space.  All rows of all strips are laid on one COST axis (a row of a two-block strip weighs kWF, a row of the one-block
+  // last strip of an odd block count kWL: half the MFMAs, the same staging and epilogue) and every workgroup takes an equal
+  // interval of it — at most two segments of consecutive rows, each inside one strip.  (Work units of whole row runs left
+  // 5.3 units per wave = 6 rounds at the headline shape, and a one-block code path could not pay under them.)
+  constexpr unsigned kWF = 10, kWL = 6;     // measured: a one-block row costs 0.55-0.6 of a two-block row (sweep 4..8: 6 is best)
+  // 32-bit arithmetic throughout (the host checks Rtot * kWF * nstrip < 2^31): 64-bit divisions by run-time values are
+  // ~150-instruction routines, and a workgroup decodes several positions per segment
+  // frame groups of 4 when the frame count allows it; otherwise every WAVE takes its own interval of single frames (always
+  // balanced, at the price of the shared fetches)
+  const bool grouped = (a.To & 3) == 0;
+  const int TG = grouped ? a.To / 4 : a.To;
+  const unsigned Ho = (unsigned)a.Ho;
+  const unsigned Rtot = (unsigned)nb * TG * Ho;              // rows of the (batch item, frame group, row) space
+  const unsigned CF = Rtot * kWF, Cfull = (unsigned)nfull * CF, Ctot = Cfull + (nfull < nstrip ? Rtot * kWL : 0u);
+  const unsigned part = grouped ? blockIdx.x : blockIdx.x * 4 + wave, nparts = grouped ? gridDim.x : gridDim.x * 4;
+  const unsigned c_lo = (unsigned)((unsigned long long)Ctot * part / nparts);
+  const unsigned c_hi = (unsigned)((unsigned long long)Ctot * (part + 1) / nparts);
+  for (unsigned cc = c_lo; cc < c_hi;) {
+   const bool in_full = cc < Cfull;
+   int sp = 0;
+   if (in_full) { while (cc >= (unsigned)(sp + 1) * CF) ++sp; } else sp = nfull;
+   const unsigned cbase = in_full ? (unsigned)sp * CF : Cfull;
+   const unsigned cend = in_full ? (cbase + CF < c_hi ? cbase + CF : c_hi) : c_hi;
+   // rows whose cost position starts inside [cc, cend)
+   const unsigned r_lo = in_full ? (cc - cbase + kWF - 1) / kWF : (cc - cbase + kWL - 1) / kWL;
+   const unsigned r_hi = in_full ? (cend - cbase + kWF - 1) / kWF : (cend - cbase + kWL - 1) / kWL;
+   cc = cend;
+   for (unsigned rho = r_lo; rho < r_hi;) {
+    const unsigned plane = rho / Ho;
+    const int h0 = (int)(rho - plane * Ho);
+    const int tg = (int)(plane % (unsigned)TG);
+    const int b = (int)(plane / (unsigned)TG) * a.wsets + wset;
+    const int h1 = (int)(Ho < h0 + (r_hi - rho) ? Ho : h0 + (r_hi - rho));
+    rho += h1 - h0;
+    const int t = grouped ? tg * 4 + wave : tg;
     const int my_sub = min(MT, nsub - sp * MT);
     const int p0 = sp * MT * 16;
     const int rowlen = my_sub * 16 + 2;
-    const int h0 = hr * hrun, h1 = min(a.Ho, h0 + hrun);
     int res0 = -1, res1 = -1, res2 = -1;
     const float* in_b = a.in + (long)b * a.i_sB;
     Slot st[3];
 #pragma unroll
     for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti, a.kt);
-    const int blk1 = my_sub > 1 ? 1024 : 0;           // a lone block re-reads block 0 (result unused)
 
     // per-lane source of the three DMA pieces of a row: chunk c = lane + 64 k -> pixel c >> 2, stored position c & 3
     long src_off0, src_off1, src_off2;
@@ -1058,32 +1086,42 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
       for (int oh = 0; oh < 3; ++oh) rowq[oh] = reinterpret_cast<const char*>(s_x) + slot_of[oh] * kRowB;
       // tap order: the source row the next output row replaces first (fwd: oh = 0; data gradient: oh = 2)
       f32x4 xb[2][2];
-      auto rd = [&](int tp, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
+      auto rd = [&](int nb_, int tp, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
         const int oi = tp / 9, ot = (tp / 3) % 3, ow = tp % 3;
         const int oh = FWD ? oi : 2 - oi;
         const char* rp = rowq[oh] + ot * 3 * kRowB + lo[ow];
         x0 = *reinterpret_cast<const f32x4*>(rp);
-        x1 = *reinterpret_cast<const f32x4*>(rp + blk1);
+        if (nb_ == 2) x1 = *reinterpret_cast<const f32x4*>(rp + 1024);
       };
-#define TAPS(T0_, T1_)                                                                                         \
+#define TAPS(T0_, T1_, NB_)                                                                                    \
   _Pragma("unroll") for (int tp = (T0_); tp < (T1_); ++tp) {                                                   \
-    if (tp + 1 < 27) rd(tp + 1, xb[(tp + 1) & 1][0], xb[(tp + 1) & 1][1]);                                     \
+    if (tp + 1 < 27) rd(NB_, tp + 1, xb[(tp + 1) & 1][0], xb[(tp + 1) & 1][1]);                              \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     const int oi = tp / 9, ot = (tp / 3) % 3, ow = tp % 3;                                                     \
     const f32x4 wf = wr[(ot * 3 + (FWD ? oi : 2 - oi)) * 3 + ow];                                              \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                            \
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][0][s], acc[0], 0, 0, 0);                 \
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][1][s], acc[1], 0, 0, 0);                 \
+      if (NB_ == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][1][s], acc[1], 0, 0, 0);   \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
-      rd(0, xb[0][0], xb[0][1]);
-      TAPS(0, 9)
-      // the fragments of the first 9 taps have been read (tap 9's were issued after them; DS ops complete in order)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (h + 1 < h1) { STAGE_ROWS(h + 1) }
-      __builtin_amdgcn_sched_barrier(0);
-      TAPS(9, 27)
+      // the source row the next output row replaces is read first; its DMA goes out once those fragment reads have returned
+      // (tap 9's were issued after them; DS operations complete in order).  A one-block strip runs half the MFMAs.
+      if (my_sub == 2) {
+        rd(2, 0, xb[0][0], xb[0][1]);
+        TAPS(0, 9, 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (h + 1 < h1) { STAGE_ROWS(h + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        TAPS(9, 27, 2)
+      } else {
+        rd(1, 0, xb[0][0], xb[0][1]);
+        TAPS(0, 9, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (h + 1 < h1) { STAGE_ROWS(h + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        TAPS(9, 27, 1)
+      }
 #undef TAPS
       // epilogue (as conv16_lds_kernel)
       float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
@@ -1114,6 +1152,7 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
         }
       }
     }
+   }
   }
 #undef STAGE_ROWS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2146,8 +2185,16 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         static const bool reg_staged = [] { const char* e = getenv("IDEE_CONV16"); return e && strcmp(e, "regs") == 0; }();
         if (!reg_staged) {
           auto kern = conv16_glds_kernel<MODE>;
-          const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
-          hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
+          // workgroups per weight set: one round of resident workgroups, at least ~8 rows each; IDEE_CONV_HRUN (test knob)
+          // caps the rows per workgroup instead
+          const int nsubw = cdiv(Wframe, 16), lone = nsubw & 1, nfull = nstrip - lone;
+          const long rows = (long)(a.B / a.wsets) * ((a.To & 3) ? a.To * 4L : a.To) / 4 * a.Ho * nstrip;   // per workgroup-slot
+          long g = imax(((long)kCUs * wg_per_cu(kern, 256)) / a.wsets, 1);
+          long cap = imax(rows / 8, 1);
+          if (const char* e = getenv("IDEE_CONV_HRUN")) { const int v = atoi(e); if (v > 0) { cap = cdiv(rows, v); g = cap; } }
+          if (rows * 10 >= (1L << 31)) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv: %ld strip rows exceed the 32-bit work partition", rows);
+          const dim3 grid((unsigned)imax(imin(g, cap), 1), a.wsets);
+          hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, nfull);
           return IDEE_OK;
         }
       }
