@@ -275,7 +275,7 @@ def main():
     for _ in range(a.warmup):
         ts.step(x, *masks)
     timed = ["idee_conv_fwd", "idee_conv_dgrad", "idee_conv_wgrad", "idee_swin_block_fwd", "idee_swin_block_bwd",
-             "idee_lfq_fwd", "idee_lfq_bwd", "idee_patch_embed_ln_fwd", "idee_patch_embed_ln_bwd", "idee_anomaly_l1_fwd",
+             "idee_lfq_fwd", "idee_lfq_bwd", "idee_patch_embed_ln_fwd", "idee_patch_embed_ln_bwd", "idee_anomaly_l1_fwd", "idee_anomaly_l1_signs_fwd", "idee_anomaly_l1_signs_bwd",
              "idee_anomaly_l1_bwd", "idee_adam_step", "idee_ln_relu_res_fwd", "idee_ln_relu_res_bwd"]
     log = _lib.set_event_log(timed)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]

@@ -89,6 +89,9 @@ _SIGS = {
     "idee_anomaly_workspace_floats": (_L, [_L]),
     "idee_anomaly_l1_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
     "idee_anomaly_l1_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "idee_anomaly_signs_workspace_floats": (_L, [_L, _I, _I]),
+    "idee_anomaly_l1_signs_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P]),
+    "idee_anomaly_l1_signs_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P]),
     "idee_lfq_code_vectors": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "idee_loss_combine_fwd": (_I, [_P, _I, _I, _P, _F, _P, _P, _P]),
     "idee_loss_combine_bwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),

@@ -413,7 +413,7 @@ __global__ void lfq_finalize_kernel(const float* __restrict__ partials, int nblo
 }
 
 // backward.  gscal[0] = upstream gradient of the aux loss.  grads accumulate with atomics.
-template <int E, int D>
+template <int E, int D, bool HASG /*a dense d z_q exists*/>
 __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dzq,
                                                       const float* __restrict__ w_in, const float* __restrict__ b_in,
                                                       const float* __restrict__ w_out, const float* __restrict__ stats,
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
     gwi[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gwo[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gbi[i] = 0.f;
   }
   // UN tokens per lane and trip: 2 UN sixteen-byte loads in flight before the first dependent instruction
-  constexpr int UN = 8;
+  constexpr int UN = HASG ? 8 : 16;     // the same number of 16-byte loads in flight per lane either way
   const long total = M * QE, stride = (long)gridDim.x * 256;
   for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += UN * stride) {
    long tokq[UN];
@@ -448,7 +448,8 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
    for (int r = 0; r < UN; ++r) {
      const long u = u0 + r * stride;
      tokq[r] = (u < total ? u : u0) / QE;
-     ziq[r] = ld4(z + tokq[r] * E + 4 * q); goq[r] = ld4(dzq + tokq[r] * E + 4 * q);
+     ziq[r] = ld4(z + tokq[r] * E + 4 * q);
+     goq[r] = HASG ? ld4(dzq + tokq[r] * E + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};   // no dense consumer of z_q: no read
 #pragma unroll
      for (int i = 0; i < D; ++i) dqq[r][i] = dqs ? dqs[tokq[r] * D + i] : 0.f;
    }
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
       const float a = tok_sum<QE>(zi[0] * wi[i][0] + zi[1] * wi[i][1] + zi[2] * wi[i][2] + zi[3] * wi[i][3]) + b_in[i];
       s[i] = a; qv[i] = a > 0.f ? 1.f : -1.f;
       // straight-through: d x_ste = W_out^T dz_q
-      const float d = tok_sum<QE>(go[0] * wo[i][0] + go[1] * wo[i][1] + go[2] * wo[i][2] + go[3] * wo[i][3]);
+      const float d = HASG ? tok_sum<QE>(go[0] * wo[i][0] + go[1] * wo[i][1] + go[2] * wo[i][2] + go[3] * wo[i][3]) : 0.f;
       ds[i] = d + dqq[half][i] + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
     }
     float p[K];
@@ -487,10 +488,10 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
     for (int i = 0; i < D; ++i) {
       o += wi[i] * ds[i];
       gwi[i] += zi * ds[i];
-      gwo[i] += go * qv[i];
+      if (HASG) gwo[i] += go * qv[i];
       if (q == 0) gbi[i] += ds[i];
     }
-    gbo += go;
+    if (HASG) gbo += go;
     st4(dz + tok * E + 4 * q, o);
    }
   }
@@ -701,6 +702,123 @@ __global__ __launch_bounds__(256) void anomaly_bwd_kernel(const float* __restric
       v[uu] = (m == 1.f) ? 0.f : (d > 0.f ? k : (d < 0.f ? -k : 0.f));
     }
     st4(dzq + tok * E + 4 * q, v);
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------
+// The same loss on LFQ's code bits (rank-d form): z_q = b_out + sum_i q_i w_out[:, i] is recomputed per token
+// from its D signs with the operations of lfq_fwd_kernel (so a code-0 token reproduces vq0 bit for bit and contributes an
+// exact zero, as it does through z_q), instead of reading the 64-byte z_q row; the backward returns the gradient of the signs
+// (straight-through input of lfq_bwd) and of project_out directly instead of a dense d z_q.  One thread per token.
+// partials per block, forward: [0] sum |z_q - vq0| * weight  [1] sum weight * E ; backward: E * (D + 1) sums
+// (d w_out[e][i], then d b_out[e]).
+// -------------------------------------------------------------------------------------------
+template <int E, int D>
+__global__ __launch_bounds__(256) void anomaly_signs_fwd_kernel(const float* __restrict__ signs, const float* __restrict__ mask,
+                                                                const float* __restrict__ mvalid, const float* __restrict__ w_out,
+                                                                const float* __restrict__ b_out, const float* __restrict__ vq0,
+                                                                float* __restrict__ partials, int N, int V, int T, long HW) {
+  __shared__ float smem[8];
+  __shared__ float s_w[E * D], s_b[E], s_c[E];
+  for (int i = threadIdx.x; i < E * D; i += 256) s_w[i] = w_out[i];
+  for (int i = threadIdx.x; i < E; i += 256) { s_b[i] = b_out[i]; s_c[i] = vq0[i]; }
+  __syncthreads();
+  float acc[2] = {0.f, 0.f};
+  const long M = (long)N * V * T * HW;
+  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
+    const long hw = tok % HW; long r = tok / HW;
+    const int t = (int)(r % T); r /= T;
+    const int n = (int)(r / V);
+    float m = mask[(long)n * HW + hw];
+    if (mvalid) m = fminf(m + mvalid[((long)n * T + t) * HW + hw], 1.f);
+    const float wgt = 1.f - m;
+    acc[1] += wgt * (float)E;
+    if (m == 1.f) continue;   // target := prediction there (losses.py:162): exactly zero contribution
+    float q[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) q[i] = signs[tok * D + i];
+    float l1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float o = s_b[e];
+#pragma unroll
+      for (int i = 0; i < D; ++i) o += s_w[e * D + i] * q[i];
+      l1 += fabsf(o - s_c[e]);
+    }
+    acc[0] = fmaf(l1, wgt, acc[0]);
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) { partials[(long)blockIdx.x * 2] = acc[0]; partials[(long)blockIdx.x * 2 + 1] = acc[1]; }
+}
+template <int E, int D>
+__global__ __launch_bounds__(256) void anomaly_signs_bwd_kernel(const float* __restrict__ signs, const float* __restrict__ mask,
+                                                                const float* __restrict__ mvalid, const float* __restrict__ w_out,
+                                                                const float* __restrict__ b_out, const float* __restrict__ vq0,
+                                                                const float* __restrict__ gout, const float* __restrict__ denom,
+                                                                float* __restrict__ dsigns, float* __restrict__ partials,
+                                                                int N, int V, int T, long HW) {
+  constexpr int R = E * (D + 1);
+  __shared__ float s_red[4][R];
+  __shared__ float s_w[E * D], s_b[E], s_c[E];
+  for (int i = threadIdx.x; i < E * D; i += 256) s_w[i] = w_out[i];
+  for (int i = threadIdx.x; i < E; i += 256) { s_b[i] = b_out[i]; s_c[i] = vq0[i]; }
+  __syncthreads();
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  const float sc = gout[0] / denom[0];
+  const long M = (long)N * V * T * HW;
+  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
+    const long hw = tok % HW; long r = tok / HW;
+    const int t = (int)(r % T); r /= T;
+    const int n = (int)(r / V);
+    float m = mask[(long)n * HW + hw];
+    if (mvalid) m = fminf(m + mvalid[((long)n * T + t) * HW + hw], 1.f);
+    const float k = sc * (1.f - m);
+    float q[D], dq[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { q[i] = signs[tok * D + i]; dq[i] = 0.f; }
+    if (m != 1.f) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float o = s_b[e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) o += s_w[e * D + i] * q[i];
+        const float d = o - s_c[e];
+        const float g = d > 0.f ? k : (d < 0.f ? -k : 0.f);       // d |.| at 0 is 0 (torch's L1Loss)
+#pragma unroll
+        for (int i = 0; i < D; ++i) { dq[i] = fmaf(g, s_w[e * D + i], dq[i]); acc[e * D + i] = fmaf(g, q[i], acc[e * D + i]); }
+        acc[E * D + e] += g;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) dsigns[tok * D + i] = dq[i];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float v = acc[r];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) s_red[wave][r] = v;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += 256)
+    partials[(long)blockIdx.x * R + r] = (s_red[0][r] + s_red[1][r]) + (s_red[2][r] + s_red[3][r]);
+}
+// out[r] = sum over blocks of partials[b][r], fixed order (one 64-thread workgroup per value)
+__global__ void column_sum_kernel(const float* __restrict__ partials, int nblocks, int R, float* __restrict__ out) {
+  __shared__ double sm[64];
+  const int r = blockIdx.x, t = threadIdx.x;
+  double s = 0.0;
+  for (int b = t; b < nblocks; b += 64) s += (double)partials[(long)b * R + r];
+  sm[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < 64; ++i) tot += sm[i];
+    out[r] = (float)tot;
   }
 }
 
@@ -1446,14 +1564,16 @@ extern "C" int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in,
                             const float* stats, const float* gloss, const float* dsigns, float* dz, float* dw_in, float* db_in,
                             float* dw_out, float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma,
                             float w_commit, idee_stream_t stream) {
-  IDEE_CHECK_ARG(z && dzq && w_in && b_in && w_out && stats && gloss && dz && dw_in && db_in && dw_out && db_out && M > 0,
-                 "lfq_bwd: bad argument");
+  IDEE_CHECK_ARG(z && w_in && b_in && w_out && stats && gloss && dz && dw_in && db_in && dw_out && db_out && M > 0,
+                 "lfq_bwd: bad argument");     // dzq may be null: z_q had no dense consumer (gradients arrive through dsigns)
   const int D = log2i(codebook_size);
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
 #define CALL(E_, D_)                                                                                               \
-  const int nb = imin(cdiv(M * 4, 256), kCUs * wg_per_cu(lfq_bwd_kernel<E_, D_>));                                 \
-  hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in, w_out, \
-                     stats, gloss, dsigns, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
+  const int nb = imin(cdiv(M * 4, 256), kCUs * wg_per_cu(lfq_bwd_kernel<E_, D_, true>));                           \
+  if (dzq) hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in, \
+                     w_out, stats, gloss, dsigns, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit);  \
+  else hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in,    \
+                     w_out, stats, gloss, dsigns, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
   LFQ_DISPATCH(CALL)
 #undef CALL
   IDEE_LAUNCH_CHECK("lfq_bwd");
@@ -1516,6 +1636,61 @@ extern "C" int idee_anomaly_l1_bwd(const float* zq, const float* mask_extreme, c
   else if (E == 32) hipLaunchKernelGGL((anomaly_bwd_kernel<32>), dim3(nb), dim3(256), 0, st, zq, mask_extreme, mask_valid, vq0, gout, denom, dzq, N, V, T, HW);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "anomaly_l1: E=%d not built", E);
   IDEE_LAUNCH_CHECK("anomaly_l1_bwd");
+  return IDEE_OK;
+}
+
+
+// rank-d form of the anomaly loss: reads the LFQ code bits (signs (N,V,T,H,W,D), as idee_lfq_fwd writes them) instead of z_q
+static int anomaly_signs_blocks(long tokens) { return imin(cdiv(tokens, 256), kCUs * 8); }
+extern "C" long idee_anomaly_signs_workspace_floats(long tokens, int E, int codebook_size) {
+  return (long)anomaly_signs_blocks(tokens) * imax(2, E * (log2i(codebook_size) + 1));
+}
+#define ANOM_SIGNS_DISPATCH(CALL)                                                                        \
+  if (E == 16 && D == 1) { CALL(16, 1); } else if (E == 16 && D == 2) { CALL(16, 2); }                   \
+  else if (E == 16 && D == 3) { CALL(16, 3); } else if (E == 32 && D == 1) { CALL(32, 1); }              \
+  else if (E == 32 && D == 2) { CALL(32, 2); }                                                           \
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "anomaly_l1_signs: (dim=%d, codebook_size=%d) not built", E, 1 << D);
+
+extern "C" int idee_anomaly_l1_signs_fwd(const float* signs, const float* mask_extreme, const float* mask_valid,
+                                         const float* w_out, const float* b_out, const float* vq0, float* out /* [loss, denom] */,
+                                         float* workspace, int N, int V, int T, long HW, int E, int codebook_size,
+                                         idee_stream_t stream) {
+  IDEE_CHECK_ARG(signs && mask_extreme && w_out && b_out && vq0 && out && workspace && N > 0 && V > 0 && T > 0 && HW > 0,
+                 "anomaly_l1_signs_fwd: bad argument");
+  const int D = log2i(codebook_size);
+  IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "anomaly_l1_signs: codebook size %d is not a power of two", codebook_size);
+  const long M = (long)N * V * T * HW;
+  const int nb = anomaly_signs_blocks(M);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(E_, D_)                                                                                            \
+  hipLaunchKernelGGL((anomaly_signs_fwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, st, signs, mask_extreme, mask_valid, w_out, \
+                     b_out, vq0, workspace, N, V, T, HW)
+  ANOM_SIGNS_DISPATCH(CALL)
+#undef CALL
+  hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, nb, 1, out);
+  IDEE_LAUNCH_CHECK("anomaly_l1_signs_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_anomaly_l1_signs_bwd(const float* signs, const float* mask_extreme, const float* mask_valid,
+                                         const float* w_out, const float* b_out, const float* vq0, const float* gout,
+                                         const float* denom, float* dsigns, float* dw_out, float* db_out, float* workspace,
+                                         int N, int V, int T, long HW, int E, int codebook_size, idee_stream_t stream) {
+  IDEE_CHECK_ARG(signs && mask_extreme && w_out && b_out && vq0 && gout && denom && dsigns && dw_out && db_out && workspace &&
+                 N > 0 && V > 0 && T > 0 && HW > 0, "anomaly_l1_signs_bwd: bad argument");
+  IDEE_CHECK_ARG(db_out == dw_out + (long)E * log2i(codebook_size), "anomaly_l1_signs_bwd: db_out must follow dw_out (one buffer of E (D + 1) floats)");
+  const int D = log2i(codebook_size);
+  IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "anomaly_l1_signs: codebook size %d is not a power of two", codebook_size);
+  const long M = (long)N * V * T * HW;
+  const int nb = anomaly_signs_blocks(M);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(E_, D_)                                                                                            \
+  hipLaunchKernelGGL((anomaly_signs_bwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, st, signs, mask_extreme, mask_valid, w_out, \
+                     b_out, vq0, gout, denom, dsigns, workspace, N, V, T, HW)
+  ANOM_SIGNS_DISPATCH(CALL)
+#undef CALL
+  hipLaunchKernelGGL(column_sum_kernel, dim3(E * (D + 1)), dim3(64), 0, st, workspace, nb, E * (D + 1), dw_out);
+  IDEE_LAUNCH_CHECK("anomaly_l1_signs_bwd");
   return IDEE_OK;
 }
 

@@ -88,7 +88,9 @@ class VQ_model(nn.Module):
             # with weights folded through project_out (exact refactoring, DESIGN.md "rank-d classifier input")
             z_q, anomaly, loss_z_q, signs = self.vq.quantize_tokens_signs(z)
             zc, y = self.cls.forward_signs(signs, self.vq.project_out)
+            self.last_signs = signs if self.training else None   # the train step's anomaly loss reads the bits too (train.py)
         else:
             z_q, anomaly, loss_z_q = self.vq.quantize_tokens(z)
             zc, y = self.cls.forward_tokens(z_q)
+            self.last_signs = None
         return zc, y, anomaly, z_q.permute(0, 1, 5, 2, 3, 4), loss_z_q.unsqueeze(0)

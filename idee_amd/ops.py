@@ -577,7 +577,7 @@ class LFQQuantize(torch.autograd.Function):
     def backward(ctx, dzq, _didx, dloss, dsigns=None):
         z, w_in, b_in, w_out, stats = ctx.saved_tensors
         M, E, K, w_entropy, gamma, w_commit = ctx.cfg
-        dzq = _f32c(dzq) if dzq is not None else torch.zeros_like(z)
+        dzq = _f32c(dzq) if dzq is not None else None      # None: no dense consumer of z_q (its users read the signs)
         gl = _f32c(dloss).reshape(1) if dloss is not None else torch.zeros(1, device=z.device)
         dz = torch.empty_like(z)
         dw_in, db_in, dw_out = _zeros_like_many(w_in, b_in, w_out)
@@ -658,6 +658,47 @@ class AnomalyL1(torch.autograd.Function):
         L.call("idee_anomaly_l1_bwd", ptr(zq), ptr(mask_extreme), ptr(mask_valid), ptr(vq0), ptr(g), ptr(out[1:]), ptr(dzq), N,
                V, T, H * W, E, L.stream())
         return dzq, None, None, None
+
+
+class AnomalyL1Signs(torch.autograd.Function):
+    """AnomalyL1 read from LFQ's code bits: signs (N,V,T,H,W,D) (LFQQuantize's 4th output), project_out weight (E,D) and bias
+    (E) -> (loss, den).  z_q = project_out(signs) is recomputed per token (rank-d form); the backward returns the
+    gradient of the signs (straight-through into LFQQuantize) and of project_out, so no dense d z_q is written or read."""
+
+    @staticmethod
+    def forward(ctx, signs, w_out, b_out, mask_extreme, mask_valid, codebook_size):
+        signs, w_out, b_out, mask_extreme = _f32c(signs), _f32c(w_out), _f32c(b_out), _f32c(mask_extreme)
+        mask_valid = _f32c(mask_valid) if mask_valid is not None else None
+        N, V, T, H, W, D = signs.shape
+        E = w_out.shape[0]
+        dev = signs.device
+        code0 = torch.zeros(1, dtype=torch.long, device=dev)
+        vq0 = lfq_code_vectors(code0, w_out, b_out, codebook_size).reshape(-1)      # detached target (losses.py:29,141)
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        ws = torch.empty(L.load().idee_anomaly_signs_workspace_floats(N * V * T * H * W, E, codebook_size), device=dev,
+                         dtype=torch.float32)
+        L.call("idee_anomaly_l1_signs_fwd", ptr(signs), ptr(mask_extreme), ptr(mask_valid), ptr(w_out), ptr(b_out), ptr(vq0),
+               ptr(out), ptr(ws), N, V, T, H * W, E, codebook_size, L.stream())
+        ctx.save_for_backward(signs, mask_extreme, mask_valid, w_out, b_out, vq0, out)
+        ctx.codebook_size = codebook_size
+        den = out[1]
+        ctx.mark_non_differentiable(den)
+        return out[0], den
+
+    @staticmethod
+    def backward(ctx, g, _gden):
+        signs, mask_extreme, mask_valid, w_out, b_out, vq0, out = ctx.saved_tensors
+        N, V, T, H, W, D = signs.shape
+        E = w_out.shape[0]
+        g = _f32c(g).reshape(1)
+        dsigns = torch.empty_like(signs)
+        dwb = torch.empty(E * (D + 1), device=signs.device, dtype=torch.float32)
+        ws = torch.empty(L.load().idee_anomaly_signs_workspace_floats(N * V * T * H * W, E, ctx.codebook_size),
+                         device=signs.device, dtype=torch.float32)
+        L.call("idee_anomaly_l1_signs_bwd", ptr(signs), ptr(mask_extreme), ptr(mask_valid), ptr(w_out), ptr(b_out), ptr(vq0),
+               ptr(g), ptr(out[1:]), ptr(dsigns), ptr(dwb), dwb.data_ptr() + 4 * E * D, ptr(ws), N, V, T, H * W, E,
+               ctx.codebook_size, L.stream())
+        return dsigns, dwb[:E * D].view(E, D), dwb[E * D:], None, None, None
 
 
 def lfq_code_vectors(indices, w_out, b_out, codebook_size):

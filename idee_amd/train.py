@@ -55,6 +55,14 @@ class _TrainStep:
 
     def _anomaly_term(self, z_q, mask_loss, mask_valid_t):
         vq = self.model.vq      # indices_to_codes(LongTensor([0])).detach() of train_synthetic.py:193-194 as one tiny kernel
+        signs = getattr(self.model, "last_signs", None)
+        if signs is not None:    # rank-d form: the loss reads the code bits the classifier already reads, not the z_q tensor
+            self.model.last_signs = None
+            l_anom, den = ops.AnomalyL1Signs.apply(signs, vq.project_out.weight, vq.project_out.bias, mask_loss.float(),
+                                                   mask_valid_t.float() if mask_valid_t is not None else None, vq.codebook_size)
+            if parallel.world_size() > 1:
+                l_anom = l_anom * parallel.global_anomaly_scale(den)
+            return l_anom
         vq0 = ops.lfq_code_vectors(self.code0, vq.project_out.weight, vq.project_out.bias, vq.codebook_size)
         zq_tokens = z_q.permute(0, 1, 3, 4, 5, 2)
         l_anom, den = ops.AnomalyL1.apply(zq_tokens if zq_tokens.is_contiguous() else zq_tokens.contiguous(),

@@ -201,7 +201,8 @@ int idee_dropout_mask_(float* x, long n, float p, uint64_t seed, idee_stream_t s
  * ---------------------------------------------------------------------------------------- */
 long idee_lfq_workspace_floats(long M, int codebook_size);
 /* signs (M, D) | NULL: the +-1 code bits per token; dsigns (M, D) | NULL: an additional gradient on them (straight-through),
- * coming from consumers that read the sign field instead of z_q (the rank-d classifier input below). */
+ * coming from consumers that read the sign field instead of z_q (the rank-d classifier input and anomaly loss below).
+ * dzq | NULL: NULL when z_q has no dense consumer (every gradient arrives through dsigns): the 64-byte-per-token read is skipped. */
 int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out, float* zq,
                  int64_t* indices, float* stats, float* workspace, float* signs, long M, int E, int codebook_size,
                  int training, float w_entropy, float gamma, float w_commit, idee_stream_t stream);
@@ -284,6 +285,21 @@ int idee_anomaly_l1_fwd(const float* zq, const float* mask_extreme, const float*
 int idee_anomaly_l1_bwd(const float* zq, const float* mask_extreme, const float* mask_valid, const float* vq0,
                         const float* gout, const float* denom, float* dzq, int N, int V, int T, long HW, int E,
                         idee_stream_t stream);
+/* The same loss read from LFQ's code bits instead of z_q (z_q = b_out + sum_i signs_i w_out[:, i] has rank log2 K per token:
+ * the rank-d form of DESIGN.md 3b; values and gradients equal those through z_q up to f32 summation order).
+ *   signs (N, V, T, HW, D) as idee_lfq_fwd writes them, D = log2(codebook_size); w_out (E, D), b_out (E): LFQ.project_out;
+ *   vq0 (E): the code-0 vector (idee_lfq_code_vectors), a constant of the loss (losses.py detaches it)
+ *   bwd: dsigns (N, V, T, HW, D) is the straight-through gradient idee_lfq_bwd takes as `dsigns`; dw_out (E, D) and db_out (E)
+ *   are ONE buffer of E (D + 1) floats (db_out = dw_out + E D), overwritten; workspace
+ *   idee_anomaly_signs_workspace_floats(N*V*T*HW, E, codebook_size) for either call */
+long idee_anomaly_signs_workspace_floats(long tokens, int E, int codebook_size);
+int idee_anomaly_l1_signs_fwd(const float* signs, const float* mask_extreme, const float* mask_valid, const float* w_out,
+                              const float* b_out, const float* vq0, float* out, float* workspace, int N, int V, int T, long HW,
+                              int E, int codebook_size, idee_stream_t stream);
+int idee_anomaly_l1_signs_bwd(const float* signs, const float* mask_extreme, const float* mask_valid, const float* w_out,
+                              const float* b_out, const float* vq0, const float* gout, const float* denom, float* dsigns,
+                              float* dw_out, float* db_out, float* workspace, int N, int V, int T, long HW, int E,
+                              int codebook_size, idee_stream_t stream);
 
 /* Step glue of the training drivers.
  *   lfq_code_vectors: LFQ.indices_to_codes(indices) with project_out (models/codebook/LFQ.py:152-181; e.g. the code-0 target of

