@@ -125,11 +125,14 @@ def swin_flops(geom, backward):
 
 # which device kernels run inside one launch of a C-ABI entry point (for the PMC traffic lookup)
 FAMILY_KERNELS = {
-    "idee_swin_block_fwd": ("swin_fwd_mfma_kernel",),
-    "idee_swin_block_bwd": ("swin_mlp_bwd_kernel", "swin_attn_bwd_kernel"),
-    "idee_conv_fwd": ("conv16_lds_kernel<0", "conv16_lds_kernel<2", "conv_wide_kernel<0", "conv_wide_kernel<2", "c1_fwd", "conv_kernel<0"),
-    "idee_conv_dgrad": ("conv16_lds_kernel<1", "conv16_lds_kernel<3", "conv_wide_kernel<1", "conv_wide_kernel<3", "c1_dgrad", "conv_kernel<1"),
-    "idee_conv_wgrad": ("wgrad16_strip_kernel", "wgrad_wide_lds_kernel", "c1_wgrad", "wgrad_kernel"),
+    "idee_swin_block_fwd": ("swin_fwd_",),
+    "idee_swin_block_bwd": ("swin_mlp_bwd", "swin_attn_bwd"),
+    "idee_conv_fwd": ("conv16_lds_kernel<0", "conv16_lds_kernel<2", "conv16_glds_kernel<0", "conv16_split_kernel<0", "conv16_split_kernel<2",
+                      "conv_wide_kernel<0", "conv_wide_kernel<2", "conv_wide_split_kernel<2", "c1_fwd", "conv_kernel<0", "conv_kernel<2"),
+    "idee_conv_dgrad": ("conv16_lds_kernel<1", "conv16_lds_kernel<3", "conv16_glds_kernel<1", "conv16_split_kernel<1", "conv16_split_kernel<3",
+                        "conv_wide_kernel<1", "conv_wide_kernel<3", "conv_wide_split_kernel<3", "c1_dgrad", "conv_kernel<1", "conv_kernel<3",
+                        "init_w_edges"),
+    "idee_conv_wgrad": ("wgrad16_strip_kernel", "wgrad16_split_kernel", "wgrad_wide_lds_kernel", "c1_wgrad", "wgrad_kernel"),
 }
 
 
