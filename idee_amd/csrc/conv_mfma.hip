@@ -1160,6 +1160,192 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
 
 
 // ---------------------------------------------------------------------------------------------
+// Data gradient of the (1,3,3) zero-padded convs INTO a 16-channel tensor (the sign-field convs 16 -> 96 / 16 -> 192:
+// dy has Gk 16-channel groups, dx one).  K = 9 taps x 16 Gk channels is deep and the output is one block wide, so the work is
+// split along K: wave g of a workgroup owns channel group g — its 9 weight fragments in registers, its own LDS ring of 3 dy
+// rows (one group = 64 bytes per pixel: every dy byte is fetched once, by LDS-DMA one row ahead as in conv16_glds_kernel) —
+// and the Gk partial 16 x 16 tiles of a row meet in a double-buffered LDS exchange (one workgroup barrier per row); waves 0
+// and 1 sum them and store.  (conv_wide_kernel's one-output-block path re-fetched dy 3x through L2: 54 TFLOP/s.)
+// Rows outside the frame are staged as zeros with ds_write; columns outside it are zeroed once per work unit.
+// Work partition: the cost axis of conv16_glds_kernel, one interval per workgroup (single frames).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) void dgrad_k133_to16_kernel(ConvArgs a, int nstrip, int nfull) {
+  constexpr int MT = 2;
+  constexpr int kRowB = kC16Row * 64;                 // bytes of one staged row
+  extern __shared__ __attribute__((aligned(1024))) float s_dg[];   // [G][3 rows][34 px x 16] then [2][G][2][256]
+  const int G = a.Gk;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  float* s_x = s_dg + (long)wave * 3 * kC16Row * 16;
+  float* s_red = s_dg + (long)G * 3 * kC16Row * 16;
+  const unsigned s_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)s_x);
+  f32x4 wr[9];
+  {
+    const float* wp = a.wp + (long)wset * a.ntaps * G * 256;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) wr[tp] = ld4(wp + ((long)tp * G + wave) * 256 + lane * 4);
+  }
+  const int Wi = a.Wi, Hi = a.Hi;
+  const long i_sH = a.i_sH, i_sW = a.i_sW;
+  const int nsub = (a.Wo + 15) / 16;
+  const int nb = a.B / a.wsets;
+  int lo[3];
+#pragma unroll
+  for (int ow = 0; ow < 3; ++ow) {
+    const int px = j + 2 - ow;                         // staged index of source column p - (ow - 1), staged from p0 - 1
+    lo[ow] = px * 64 + ((kq ^ ((px >> 2) & 3)) * 16);
+  }
+  constexpr unsigned kWF = 10, kWL = 6;
+  const unsigned Ho = (unsigned)a.Ho;
+  const unsigned Rtot = (unsigned)nb * a.To * Ho;
+  const unsigned CF = Rtot * kWF, Cfull = (unsigned)nfull * CF, Ctot = Cfull + (nfull < nstrip ? Rtot * kWL : 0u);
+  const unsigned c_lo = (unsigned)((unsigned long long)Ctot * blockIdx.x / gridDim.x);
+  const unsigned c_hi = (unsigned)((unsigned long long)Ctot * (blockIdx.x + 1) / gridDim.x);
+  int par = 0;                                         // exchange buffer of the next row (alternates over the workgroup's life)
+  for (unsigned cc = c_lo; cc < c_hi;) {
+   const bool in_full = cc < Cfull;
+   int sp = 0;
+   if (in_full) { while (cc >= (unsigned)(sp + 1) * CF) ++sp; } else sp = nfull;
+   const unsigned cbase = in_full ? (unsigned)sp * CF : Cfull;
+   const unsigned cend = in_full ? (cbase + CF < c_hi ? cbase + CF : c_hi) : c_hi;
+   const unsigned r_lo = in_full ? (cc - cbase + kWF - 1) / kWF : (cc - cbase + kWL - 1) / kWL;
+   const unsigned r_hi = in_full ? (cend - cbase + kWF - 1) / kWF : (cend - cbase + kWL - 1) / kWL;
+   cc = cend;
+   for (unsigned rho = r_lo; rho < r_hi;) {
+    const unsigned plane = rho / Ho;
+    const int h0 = (int)(rho - plane * Ho);
+    const int t = (int)(plane % (unsigned)a.To);
+    const int b = (int)(plane / (unsigned)a.To) * a.wsets + wset;
+    const int h1 = (int)(Ho < h0 + (r_hi - rho) ? Ho : h0 + (r_hi - rho));
+    rho += h1 - h0;
+    const int my_sub = min(MT, nsub - sp * MT);
+    const int p0 = sp * MT * 16;
+    const int rowlen = my_sub * 16 + 2;
+    int res0 = -9, res1 = -9, res2 = -9;               // source row held by each ring slot
+    const float* in_bt = a.in + (long)b * a.i_sB + (long)t * a.i_sT + goff(wave, a.i_gpu, a.i_sU, a.i_sG);
+    long src_off0, src_off1, src_off2;
+    bool src_ok0, src_ok1, src_ok2, in_row0, in_row1, in_row2;
+    {
+      auto piece = [&](int k, long& off, bool& ok, bool& inrow) __attribute__((always_inline)) {
+        const int c = lane + 64 * k, px = c >> 2, q4 = (c & 3) ^ ((px >> 2) & 3);
+        const int w = p0 + px - 1;
+        inrow = c < rowlen * 4;
+        ok = inrow && w >= 0 && w < Wi;
+        off = (long)min(max(w, 0), Wi - 1) * i_sW + 4 * q4;
+      };
+      piece(0, src_off0, src_ok0, in_row0); piece(1, src_off1, src_ok1, in_row1); piece(2, src_off2, src_ok2, in_row2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_fence();                                     // the previous unit's reads and DMA are done
+    {                                                 // zero columns outside the frame, all 3 ring rows
+      const bool zk[3] = {in_row0 && !src_ok0, in_row1 && !src_ok1, in_row2 && !src_ok2};
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (zk[k]) {
+#pragma unroll
+          for (int sr = 0; sr < 3; ++sr) st4(s_x + sr * (kC16Row * 16) + (lane + 64 * k) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+    }
+    // DG_STAGE(HS): bring dy row HS into ring slot HS mod 3 unless it is there: DMA for a row of the frame, zeros otherwise
+#define DG_STAGE(HS_)                                                                                          \
+  do {                                                                                                         \
+    const int hs_ = (HS_);                                                                                     \
+    const int slot_ = ((hs_ % 3) + 3) % 3;                                                                     \
+    const int cur_ = slot_ == 0 ? res0 : slot_ == 1 ? res1 : res2;                                             \
+    if (cur_ != hs_) {                                                                                         \
+      if (slot_ == 0) res0 = hs_; else if (slot_ == 1) res1 = hs_; else res2 = hs_;                            \
+      if (hs_ >= 0 && hs_ < Hi) {                                                                              \
+        const float* src_ = in_bt + (long)hs_ * i_sH;                                                          \
+        const unsigned dst_ = s_base + (unsigned)(slot_ * kRowB);                                              \
+        if (src_ok0) glds16(src_ + src_off0, dst_);                                                            \
+        if (src_ok1) glds16(src_ + src_off1, dst_ + 1024);                                                     \
+        if (src_ok2) glds16(src_ + src_off2, dst_ + 2048);                                                     \
+      } else {                                                                                                 \
+        float* dz_ = s_x + slot_ * (kC16Row * 16);                                                             \
+        if (in_row0) st4(dz_ + lane * 4, f32x4{0.f, 0.f, 0.f, 0.f});                                           \
+        if (in_row1) st4(dz_ + (lane + 64) * 4, f32x4{0.f, 0.f, 0.f, 0.f});                                    \
+        if (in_row2) st4(dz_ + (lane + 128) * 4, f32x4{0.f, 0.f, 0.f, 0.f});                                   \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+    DG_STAGE(h0 + 1); DG_STAGE(h0); DG_STAGE(h0 - 1);
+
+    for (int h = h0; h < h1; ++h) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wave_fence();
+      f32x4 acc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // tap (oh, ow) reads source row h - (oh - 1); the next output row replaces row h - 1 (oh = 2): its taps go first
+      const char* rowq[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) rowq[oh] = reinterpret_cast<const char*>(s_x) + (((h - (oh - 1)) % 3 + 3) % 3) * kRowB;
+      f32x4 xb[2][2];
+      auto rd = [&](int nb_, int tp, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
+        const int oh = 2 - tp / 3, ow = tp % 3;
+        const char* rp = rowq[oh] + lo[ow];
+        x0 = *reinterpret_cast<const f32x4*>(rp);
+        if (nb_ == 2) x1 = *reinterpret_cast<const f32x4*>(rp + 1024);
+      };
+#define DG_TAPS(T0_, T1_, NB_)                                                                                 \
+  _Pragma("unroll") for (int tp = (T0_); tp < (T1_); ++tp) {                                                   \
+    if (tp + 1 < 9) rd(NB_, tp + 1, xb[(tp + 1) & 1][0], xb[(tp + 1) & 1][1]);                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    const f32x4 wf = wr[(2 - tp / 3) * 3 + tp % 3];                                                            \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                            \
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][0][s], acc[0], 0, 0, 0);                 \
+      if (NB_ == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xb[tp & 1][1][s], acc[1], 0, 0, 0);   \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+      if (my_sub == 2) {
+        rd(2, 0, xb[0][0], xb[0][1]);
+        DG_TAPS(0, 3, 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (h + 1 < h1) DG_STAGE(h + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        DG_TAPS(3, 9, 2)
+      } else {
+        rd(1, 0, xb[0][0], xb[0][1]);
+        DG_TAPS(0, 3, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (h + 1 < h1) DG_STAGE(h + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        DG_TAPS(3, 9, 1)
+      }
+#undef DG_TAPS
+      // exchange: every wave's partial tiles, then waves 0 / 1 sum block 0 / 1 over the channel groups and store
+      float* red = s_red + (long)par * G * MT * 256;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) st4(red + ((long)wave * MT + m) * 256 + lane * 4, acc[m]);
+      __syncthreads();
+      if (wave < my_sub) {
+        const int m = wave;
+        f32x4 v = ld4(red + (long)m * 256 + lane * 4);
+        for (int g = 1; g < G; ++g) v += ld4(red + ((long)g * MT + m) * 256 + lane * 4);
+        const int p = p0 + m * 16 + j;
+        if (p < a.Wo) {
+          const long o = (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH + (long)p * a.o_sW + 4 * kq;
+          if (a.relu_ref) {
+            const f32x4 rr = ld4(a.relu_ref + o);
+            v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+            v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+          }
+          if (a.addend) v += ld4(a.addend + o);
+          st4(a.out + o, v);
+        }
+      }
+      par ^= 1;
+    }
+#undef DG_STAGE
+   }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // conv16_lds_kernel on split-precision MFMAs (opt-in: IDEE_CONV_MATH=split; reported as its own bench line).
 // Every f32 operand is cut into two 16-bit pieces x = hi + lo (common.h split2): f16 pieces in the FORWARD modes (11 + 11
 // mantissa bits: f32-level, operands are O(1); the weights are pre-scaled by a power of two into f16's normal range and the
@@ -2201,6 +2387,27 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       auto kern = conv16_lds_kernel<MODE>;
       const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
       hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
+      return IDEE_OK;
+    }
+  }
+  if constexpr (MODE == DGRAD_S2) {
+    static const bool old_path = [] { const char* e = getenv("IDEE_DGRAD_TO16"); return e && strcmp(e, "wide") == 0; }();
+    if (!cin1 && !old_path && a.kt == 1 && a.GnTot == 1 && a.cout_real == 16 && a.Gk >= 2 && a.Gk <= 12 && a.o_sW % 4 == 0) {
+      // (1,3,3) data gradient into one 16-channel block: K split over the waves of a workgroup
+      const int nstrip = cdiv(cdiv(a.Wo, 16), 2);
+      const int nsubw = cdiv(a.Wo, 16), lone = nsubw & 1, nfull = nstrip - lone;
+      const size_t lds = (size_t)a.Gk * (3 * kC16Row * 16 + 2 * 2 * 256) * 4;
+      auto kern = dgrad_k133_to16_kernel;
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return idee::fail(IDEE_ERR_LAUNCH, "conv_dgrad: cannot reserve %zu bytes of LDS", lds);
+      int per_cu = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * a.Gk, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+      const long rows = (long)(a.B / a.wsets) * a.To * a.Ho * nstrip;
+      if (rows * 10 >= (1L << 31)) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv_dgrad: %ld strip rows exceed the 32-bit work partition", rows);
+      long g = imax(((long)kCUs * per_cu) / a.wsets, 1);
+      long cap = imax(rows / 8, 1);
+      if (const char* e = getenv("IDEE_CONV_HRUN")) { const int v = atoi(e); if (v > 0) { cap = cdiv(rows, v); g = cap; } }
+      hipLaunchKernelGGL(kern, dim3((unsigned)imax(imin(g, cap), 1), a.wsets), dim3(64 * a.Gk), lds, stream, a, nstrip, nfull);
       return IDEE_OK;
     }
   }

@@ -116,15 +116,20 @@ class tie_relu:
         return False
 
 
-def interval_close(name, got, g0, g1, rtol=1e-3, floor=1e-4):
+def interval_close(name, got, g0, g1, rtol=1e-3, floor=1e-4, exact=None):
     """got within [min(g0,g1) - tol, max(g0,g1) + tol] elementwise, tol = floor * max|g| + rtol * |g|.
-    Returns the number of elements on which g0 and g1 differ by more than tol (the tie-affected ones)."""
+    Returns the number of elements on which g0 and g1 differ by more than tol (the tie-affected ones).
+    exact: the same gradient from the oracle evaluated in float64, where rounding-level ties do not exist — an element also
+    passes within tol of it (the two forced-derivative runs bracket the answer only while tie contributions share a sign; a
+    16-element gradient that sums thousands of near-tie units of mixed sign can fall outside both)."""
     got, g0, g1 = (t.detach().float().cpu() for t in (got, g0, g1))
     assert got.shape == g0.shape == g1.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(g0.shape)}"
     assert torch.isfinite(got).all(), f"{name}: non-finite gradient"
     lo, hi = torch.minimum(g0, g1), torch.maximum(g0, g1)
     tol = max(1e-6, floor * float(hi.abs().max())) + rtol * torch.maximum(lo.abs(), hi.abs())
     bad = (got < lo - tol) | (got > hi + tol)
+    if exact is not None:
+        bad &= (got - exact.detach().float().cpu()).abs() > tol
     if bad.any():
         err = torch.maximum(lo - got, got - hi).clamp_min(0)
         i = int(err.argmax())

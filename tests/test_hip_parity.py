@@ -358,13 +358,15 @@ def test_classifier_vs_oracle(V, H, W, E, monkeypatch):
 
 
 @pytest.mark.parametrize("V,D,H,W", [(3, 1, 7, 72), (6, 1, 5, 40), (1, 1, 3, 3), (5, 2, 4, 20), (8, 2, 3, 19), (6, 1, 6, 200),
-                                     (2, 2, 3, 200)])
-def test_classifier_sign_field_vs_oracle(V, D, H, W):
+                                     (2, 2, 3, 200), (6, 1, 19, 40)])
+def test_classifier_sign_field_vs_oracle(V, D, H, W, monkeypatch):
     """The rank-d input path (ops.ClassifierHeadsSigns: convs on the sign field with folded weights) against
     the oracle's classifier applied to z_q = project_out(signs): outputs and every gradient (strict, tie-free case)."""
     from oracle import idee_oracle as O
     from idee_amd.models.classifier.CNN_3D import CNN_3D
     N, T, E = (1 if W == 200 else 2), 8, 16
+    if H == 19:      # row ranges of at most 8 rows: the K-split data gradient of the sign-field convs starts away from row 0
+        monkeypatch.setenv("IDEE_CONV_HRUN", "8")
 
     torch.manual_seed(V * 100 + W)
     c = CNN_3D(in_var=V, embed_dim=E, dim=16, drop_rate=0.0)
@@ -375,34 +377,43 @@ def test_classifier_sign_field_vs_oracle(V, D, H, W):
     signs = (torch.randint(0, 2, (N, V, T, H, W, D)).float() * 2 - 1)
     rz, ry = torch.randn(N, 1, H, W), torch.randn(V, N, 1, H, W)
     runs = []
-    for mode in (0, 1):
-        sdl = {k: v.clone().requires_grad_() for k, v in sd.items()}
-        so = signs.clone().requires_grad_()
-        wo, bo = po.weight.detach().clone().requires_grad_(), po.bias.detach().clone().requires_grad_()
+    for mode in (0, 1, 2):                   # 2: float64, plain ReLU (this case only: its head 5 has thousands of near-tie units)
+        if mode == 2 and H != 19:
+            continue
+        dt = torch.float64 if mode == 2 else torch.float32
+        sdl = {k: v.clone().to(dt).requires_grad_() for k, v in sd.items()}
+        so = signs.clone().to(dt).requires_grad_()
+        wo, bo = po.weight.detach().clone().to(dt).requires_grad_(), po.bias.detach().clone().to(dt).requires_grad_()
         zq = (so @ wo.t() + bo).permute(0, 1, 5, 2, 3, 4)
-        with tie_relu(mode) as tr:
+        if mode == 2:
             zo, yo = O.classifier(zq, sdl, pre="")
-        ((zo * rz).sum() + sum((yo[v] * ry[v]).sum() for v in range(V))).backward()
+            tr = None
+        else:
+            with tie_relu(mode) as tr:
+                zo, yo = O.classifier(zq, sdl, pre="")
+        ((zo * rz.to(dt)).sum() + sum((yo[v] * ry[v].to(dt)).sum() for v in range(V))).backward()
         runs.append((sdl, so, wo, bo, zo, yo, tr))
-    (sd0, so0, wo0, bo0, zo, yo, tr), (sd1, so1, wo1, bo1, _, _, _) = runs
+    (sd0, so0, wo0, bo0, zo, yo, tr), (sd1, so1, wo1, bo1, _, _, _) = runs[:2]
+    ex = runs[2] if len(runs) > 2 else None
     c, po = c.to(DEV), po.to(DEV)
     sg = signs.to(DEV).requires_grad_()
     z, y = c.forward_signs(sg, po)
     close("z", z, zo, atol=2e-5, rtol=2e-4)
     close("y", torch.stack(y), torch.stack(yo), atol=2e-5, rtol=2e-4)
     ((z * rz.to(DEV)).sum() + sum((y[v] * ry[v].to(DEV)).sum() for v in range(V))).backward()
-    affected = interval_close("dsigns", sg.grad, so0.grad, so1.grad)
-    affected += interval_close("dw_out", po.weight.grad, wo0.grad, wo1.grad)
-    affected += interval_close("db_out", po.bias.grad, bo0.grad, bo1.grad)
+    affected = interval_close("dsigns", sg.grad, so0.grad, so1.grad, exact=ex[1].grad if ex else None)
+    affected += interval_close("dw_out", po.weight.grad, wo0.grad, wo1.grad, exact=ex[2].grad if ex else None)
+    affected += interval_close("db_out", po.bias.grad, bo0.grad, bo1.grad, exact=ex[3].grad if ex else None)
     total = signs.numel() + wo0.numel() + bo0.numel()
     named = dict(c.named_parameters())
     for key, name, idx in c._key_map():
         g = named[name].grad
-        affected += interval_close("d" + key, g if idx is None else g[idx], sd0[key].grad, sd1[key].grad)
+        affected += interval_close("d" + key, g if idx is None else g[idx], sd0[key].grad, sd1[key].grad,
+                                   exact=ex[0][key].grad if ex else None)
         total += sd0[key].numel()
     print(f"[relu ties] sign-field V{V} D{D} {H}x{W}: {tr.n_ties} ties among {tr.n_units} units; gradient elements inside a tie "
           f"interval (all others compared strictly): {affected}/{total}")
-    assert affected <= 0.01 * total
+    assert affected <= (0.5 if ex else 0.01) * total      # with the float64 reference every element is still pinned: by the interval or by it
 
 
 @pytest.mark.parametrize("T,H,W", [(8, 10, 20), (9, 6, 17), (16, 5, 33)])
