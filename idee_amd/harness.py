@@ -185,6 +185,18 @@ def save_model(model, optimizer, epoch, mean_loss_train, mean_loss_val, config, 
     return path
 
 
+def load_model(path, model, optimizer=None, map_location="cpu"):
+    """Resume from a checkpoint written by save_model or by the reference (utils_train.py:562-584): parameters (with or
+    without DataParallel's `module.` prefix, models/build.py:120-125) and, when given, the optimizer's moments, step count and
+    hyper-parameters.  Returns (epoch, mean_loss_train, mean_loss_validation)."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in ck["model_state_dict"].items()}
+    model.load_state_dict(sd, strict=True)
+    if optimizer is not None and "optimizer_state_dict" in ck:
+        optimizer.load_state_dict(ck["optimizer_state_dict"])
+    return ck.get("epoch"), ck.get("mean_loss_train"), ck.get("mean_loss_validation")
+
+
 # ----------------------------------------------------------------------------------------
 # epoch loop (train_synthetic.py:162-233) with deferred metric reads
 # ----------------------------------------------------------------------------------------

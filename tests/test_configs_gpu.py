@@ -229,3 +229,51 @@ def test_config4_era5_train_step_runs():
     assert torch.isfinite(ts.opt.flat_g).all() and float((ts.opt.flat_g != 0).float().mean()) > 0.99
     assert float((ts.opt.flat_p != before).float().mean()) > 0.99
     print(f"[config 4] peak HBM allocated {torch.cuda.max_memory_allocated() / 1e9:.1f} GB")
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """harness.save_model / load_model (the reference's checkpoint file, utils_train.py:562-584): a run interrupted after
+    two steps and resumed in a fresh process state (new model, new optimizer) takes the same next two steps as the
+    uninterrupted run — parameters, Adam moments, step count (bias correction) and learning rate all travel."""
+    from idee_amd import harness
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    from idee_amd.train import SyntheticTrainStep
+    kw = dict(encoder="Swin_3D", in_channels=1, in_channels_dynamic=2, dir_log=str(tmp_path), name="resume")
+    N, T, H, W = 2, 8, 16, 24
+
+    def batch(k):
+        g = torch.Generator().manual_seed(50 + k)
+        x = torch.randn((N, 2, 1, T, H, W), generator=g).clamp_(-10, 10)
+        return [t.to(DEV) for t in (x, (torch.rand((N, H, W), generator=g) < 0.1).float(), (torch.rand((N, H, W), generator=g) < 0.2).float())]
+
+    def make():
+        torch.manual_seed(7)
+        st = SyntheticTrainStep(default_config(**kw), model=VQ_model(default_config(**kw)))
+        with torch.no_grad():
+            st.model.vq.project_in.weight.mul_(20.0)
+        return st
+
+    full = make()
+    for k in range(4):
+        full.step(*batch(k))
+    first = make()
+    for k in range(2):
+        first.step(*batch(k))
+    first.opt.param_groups[0]["lr"] = 7e-4            # a scheduler moved it: must travel too
+    full_lr = make()
+    for k in range(2):
+        full_lr.step(*batch(k))
+    full_lr.opt.param_groups[0]["lr"] = 7e-4
+    for k in range(2, 4):
+        full_lr.step(*batch(k))
+    path = harness.save_model(first.model, first.opt, 1, 0.5, 0.6, first.config, "train")
+    torch.manual_seed(999)
+    resumed = SyntheticTrainStep(default_config(**kw), model=VQ_model(default_config(**kw)))
+    epoch, ltr, lva = harness.load_model(path, resumed.model, resumed.opt)
+    assert (epoch, ltr, lva) == (1, 0.5, 0.6) and resumed.opt.step_count == 2 and resumed.opt.param_groups[0]["lr"] == 7e-4
+    for k in range(2, 4):
+        resumed.step(*batch(k))
+    d = (resumed.opt.flat_p - full_lr.opt.flat_p).abs()
+    assert float(d.max()) <= 2.5e-3 and float((d > 2e-5).float().mean()) < 5e-3, (float(d.max()), float((d > 2e-5).float().mean()))
+    assert float((full.opt.flat_p - full_lr.opt.flat_p).abs().max()) > 1e-5      # the learning-rate change is visible at all
