@@ -44,6 +44,12 @@ struct ConvArgs {
   int i_gpu, o_gpu;                      // 16-channel groups per unit: group g lives at (g / gpu) * sU + (g % gpu) * sG
   int nsub, wtiles, sub_base, sub_rem;   // 16-pixel column blocks per row and their split into wave tiles
   int hgroups, tiles;                    // ceil(Ho/4); To*hgroups*wtiles
+  // 16 -> 16 sub-problems of a wider convolution run on the 16 -> 16 strip kernel (conv16_glds_kernel): where the (tap) fragments
+  // of the sub-block live in the packed buffer, and the epilogue order (0 everywhere = the plain 16 -> 16 layout)
+  int w_tap_stride;                      // floats between consecutive taps (default 256)
+  long w_set_stride;                     // floats between weight sets (default ntaps * 256)
+  int bias_set_stride;                   // floats between the bias vectors of weight sets (default 16)
+  int addend_first;                      // 1: out = relu(acc + addend + bias) (a partial sum), 0: relu(acc + bias) + addend
 };
 
 struct Slot { int src, tap; bool ok; };
@@ -934,8 +940,9 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
   const unsigned s_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)s_x);   // LDS byte address of this wave's ring
   f32x4 wr[27];
   int wkey = -1;
-  const f32x4 bias = a.bias ? ld4(a.bias + (long)wset * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* wp = a.wp + (long)wset * a.ntaps * 256;
+  const f32x4 bias = a.bias ? ld4(a.bias + (long)wset * (a.bias_set_stride ? a.bias_set_stride : 16) + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wp = a.wp + (long)wset * (a.w_set_stride ? a.w_set_stride : (long)a.ntaps * 256);
+  const int wts = a.w_tap_stride ? a.w_tap_stride : 256;
   const int Wi = a.Wi;
   const long i_sT = a.i_sT, i_sH = a.i_sH, i_sW = a.i_sW;
   const int Wframe = FWD ? a.Wo : a.Wo + 2;
@@ -1074,7 +1081,7 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
             for (int oh = 0; oh < 3; ++oh)
 #pragma unroll
               for (int ow = 0; ow < 3; ++ow)
-                wr[(ot * 3 + oh) * 3 + ow] = ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * 256 + lane * 4);
+                wr[(ot * 3 + oh) * 3 + ow] = ld4(wp + (long)((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * wts + lane * 4);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
@@ -1135,9 +1142,11 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
         bool atomic = false;
         if (!FWD) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
         f32x4 v = acc[m];
+        const long o = (long)wdst * a.o_sW + 4 * kq;
+        const bool add_first = FWD && a.addend_first && a.addend;       // forward partial sums: the ReLU acts on the total
+        if (add_first) v += ld4(a.addend + (out_r - a.out) + o);
         v += bias;
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const long o = (long)wdst * a.o_sW + 4 * kq;
         if (ref_r) {
           const f32x4 rr = ld4(ref_r + o);
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
@@ -1147,7 +1156,7 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
           atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
           atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
         } else {
-          if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
+          if (a.addend && !add_first) v += ld4(a.addend + (out_r - a.out) + o);
           st4(out_r + o, v);
         }
       }
@@ -2349,6 +2358,36 @@ bool conv_split_math() {
 
 template <int MODE>
 int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
+  if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
+    // 32 -> 32 replicate convolutions (config #4's width) as 2 x 2 sub-problems on the 16 -> 16 strip kernel: output block n =
+    // sum over input blocks g, the second pass adding to the first in place (the generic kernel ran them at 73-78 TFLOP/s)
+    static const bool no_split = [] { const char* e = getenv("IDEE_CONV32"); return e && strcmp(e, "generic") == 0; }();
+    static const bool reg16 = [] { const char* e = getenv("IDEE_CONV16"); return e && strcmp(e, "regs") == 0; }();
+    if (!cin1 && !no_split && !reg16 && !conv_split_math() && a.Gk == 2 && a.GnTot == 2 && a.cout_real == 32 && !a.w_tap_stride &&
+        !(a.addend && a.relu)) {
+      const int GA = a.Gk, GB = a.GnTot;        // fwd: input, output blocks ; dgrad: dy, dx blocks (packed [tap][GA][GB])
+      for (int n = 0; n < GB; ++n)
+        for (int g = 0; g < GA; ++g) {
+          ConvArgs sub = a;
+          sub.Gk = 1; sub.GnTot = 1; sub.cout_real = 16;
+          sub.in = a.in + (long)(g / a.i_gpu) * a.i_sU + (long)(g % a.i_gpu) * a.i_sG;
+          const long og = (long)(n / a.o_gpu) * a.o_sU + (long)(n % a.o_gpu) * a.o_sG;
+          sub.out = a.out + og;
+          sub.wp = a.wp + ((long)g * GB + n) * 256;
+          sub.w_tap_stride = GA * GB * 256;
+          sub.w_set_stride = (long)a.ntaps * GA * GB * 256;
+          sub.bias = (g == 0 && a.bias) ? a.bias + n * 16 : nullptr;
+          sub.bias_set_stride = GB * 16;
+          sub.relu = (g == GA - 1) ? a.relu : 0;
+          sub.relu_ref = a.relu_ref ? a.relu_ref + og : nullptr;
+          sub.addend = g == 0 ? (a.addend ? a.addend + og : nullptr) : sub.out;
+          sub.addend_first = g > 0;
+          split_tiles(sub, MODE == DGRAD_REP ? sub.Wo + 2 : sub.Wo);
+          if (int rc = launch_conv<MODE>(sub, false, stream)) return rc;
+        }
+      return IDEE_OK;
+    }
+  }
   const int NT = pick_nt(a.GnTot);
   const bool wlds = (a.GnTot == 1 && a.Gk == 1 && !cin1);
   const int gz = a.GnTot / NT;
