@@ -1708,6 +1708,162 @@ __global__ __launch_bounds__(256, 2) void wgrad16_strip_kernel(WgradArgs a, int 
 
 
 // ---------------------------------------------------------------------------------------------
+// wgrad16_strip_kernel<FWD_REP, 3, 1> (the 3x3x3 replicate 16 -> 16 weight gradient) with the x-row staging of
+// conv16_glds_kernel: the next row's three new source rows arrive by LDS-DMA (no staging registers; the image is the same
+// pixel-major [pixel][4 chunks] the register path writes, which is lane-linear) after the 9 taps that read the ring slot being
+// replaced; the registers that frees pay for the cost-axis work partition.  One (input block, output block) pair per grid.z slice.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad16_glds_kernel(WgradArgs a, int nstrip, int nfull, int wl_arg) {
+  constexpr int TSL = 3, NTAPS = 27;
+  constexpr int kRowB = kC16Row * 64;
+  __shared__ __attribute__((aligned(1024))) float s_xw[4][TSL * 3 * kC16Row * 16];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  float* s_x = s_xw[wave];
+  const unsigned s_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)s_x);
+  const int ngb = a.CoutPad / 16;
+  const int ga = blockIdx.z / ngb, gb0 = blockIdx.z % ngb;
+  f32x4 acc[NTAPS];
+  float bsum = 0.f;
+#pragma unroll
+  for (int tp = 0; tp < NTAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsub = (a.W + 15) / 16;
+  const int nb = a.B / a.wsets;
+  const int Wd = a.W;
+  const long x_sT = a.x_sT, x_sH = a.x_sH, x_sW = a.x_sW;
+  // work partition: the cost axis of conv16_glds_kernel (frame groups of 4 when To allows it)
+  constexpr unsigned kWF = 10;
+  const unsigned kWL = (unsigned)wl_arg;
+  const bool grouped = (a.To & 3) == 0;
+  const int TG = grouped ? a.To / 4 : a.To;
+  const unsigned Ho = (unsigned)a.H;
+  const unsigned Rtot = (unsigned)nb * TG * Ho;
+  const unsigned CF = Rtot * kWF, Cfull = (unsigned)nfull * CF, Ctot = Cfull + (nfull < nstrip ? Rtot * kWL : 0u);
+  const unsigned part = grouped ? blockIdx.x : blockIdx.x * 4 + wave, nparts = grouped ? gridDim.x : gridDim.x * 4;
+  const unsigned c_lo = (unsigned)((unsigned long long)Ctot * part / nparts);
+  const unsigned c_hi = (unsigned)((unsigned long long)Ctot * (part + 1) / nparts);
+  for (unsigned cc = c_lo; cc < c_hi;) {
+   const bool in_full = cc < Cfull;
+   int sp = 0;
+   if (in_full) { while (cc >= (unsigned)(sp + 1) * CF) ++sp; } else sp = nfull;
+   const unsigned cbase = in_full ? (unsigned)sp * CF : Cfull;
+   const unsigned cend = in_full ? (cbase + CF < c_hi ? cbase + CF : c_hi) : c_hi;
+   const unsigned r_lo = in_full ? (cc - cbase + kWF - 1) / kWF : (cc - cbase + kWL - 1) / kWL;
+   const unsigned r_hi = in_full ? (cend - cbase + kWF - 1) / kWF : (cend - cbase + kWL - 1) / kWL;
+   cc = cend;
+   for (unsigned rho = r_lo; rho < r_hi;) {
+    const unsigned plane = rho / Ho;
+    const int h0 = (int)(rho - plane * Ho);
+    const int tg = (int)(plane % (unsigned)TG);
+    const int b = (int)(plane / (unsigned)TG) * a.wsets + wset;
+    const int h1 = (int)(Ho < h0 + (r_hi - rho) ? Ho : h0 + (r_hi - rho));
+    rho += h1 - h0;
+    const int t = grouped ? tg * 4 + wave : tg;
+    const int my_sub = min(2, nsub - sp * 2);
+    const int p0 = sp * 32;
+    const int rowlen = my_sub * 16 + 2;
+    int res0 = -1, res1 = -1, res2 = -1;
+    const float* x_b = a.x + (long)b * a.x_sB + goff(ga, a.x_gpu, a.x_sU, a.x_sG);
+    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT + goff(gb0, a.y_gpu, a.y_sU, a.y_sG) + r16;
+    int tsrc[TSL];
+#pragma unroll
+    for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = min(max(t + ot - 1, 0), a.T - 1);
+    // per-lane source of the three DMA pieces of a row: chunk c = lane + 64 k -> pixel c >> 2, 16-byte piece c & 3
+    long src_off0, src_off1, src_off2;
+    bool src_ok0, src_ok1, src_ok2;
+    {
+      auto piece = [&](int k, long& off, bool& ok) __attribute__((always_inline)) {
+        const int c = lane + 64 * k, px = c >> 2;
+        ok = c < rowlen * 4;
+        off = (long)min(max(p0 + px - 1, 0), Wd - 1) * x_sW + 4 * (c & 3);
+      };
+      piece(0, src_off0, src_ok0); piece(1, src_off1, src_ok1); piece(2, src_off2, src_ok2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_fence();
+    if (my_sub < 2) {      // pixels past a one-block strip: zeros (they meet zero dy fragments; stale LDS could hold NaN patterns)
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        const int c = lane + 64 * kz;
+        if (c >= rowlen * 4 && c < kC16Row * 4) {
+#pragma unroll
+          for (int sr = 0; sr < TSL * 3; ++sr) st4(s_x + sr * (kC16Row * 16) + c * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+      }
+    }
+#define WG_STAGE(H_)                                                                                           \
+  _Pragma("unroll") for (int oh_ = 0; oh_ < 3; ++oh_) {                                                        \
+    const int hs_ = min(max((H_) + oh_ - 1, 0), a.H - 1);                                                      \
+    const int slot_ = hs_ % 3;                                                                                 \
+    const int cur_ = slot_ == 0 ? res0 : slot_ == 1 ? res1 : res2;                                             \
+    if (cur_ != hs_ + 1) {                                                                                     \
+      if (slot_ == 0) res0 = hs_ + 1; else if (slot_ == 1) res1 = hs_ + 1; else res2 = hs_ + 1;                \
+      _Pragma("unroll") for (int ot_ = 0; ot_ < TSL; ++ot_) {                                                  \
+        const float* src_ = x_b + (long)tsrc[ot_] * x_sT + (long)hs_ * x_sH;                                   \
+        const unsigned dst_ = s_base + (unsigned)((ot_ * 3 + slot_) * kRowB);                                  \
+        if (src_ok0) glds16(src_ + src_off0, dst_);                                                            \
+        if (src_ok1) glds16(src_ + src_off1, dst_ + 1024);                                                     \
+        if (src_ok2) glds16(src_ + src_off2, dst_ + 2048);                                                     \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+    WG_STAGE(h0)
+
+    for (int h = h0; h < h1; ++h) {
+      // dy fragments of this row: lane (cout = r16, pixel 4 kb + kq); pixels past the row end contribute zero.  (Ordinary
+      // loads, younger than the row's DMA: the compiler's counted waits for them also retire the DMA.)
+      float bf[8];
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const int p = p0 + 4 * kb + kq;
+        bf[kb] = (kb < 4 * my_sub && p < Wd) ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW] : 0.f;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wave_fence();
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) bsum += bf[kb];
+      const float* rowq[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) rowq[oh] = s_x + ((long)(min(max(h + oh - 1, 0), a.H - 1) % 3) * kC16Row + kq) * 16 + r16;
+      // taps of the source row the next output row replaces (oh = 0) first; then its DMA; then the rest
+#define WG_TAPS(OH0_, OH1_)                                                                                    \
+  _Pragma("unroll") for (int oh = (OH0_); oh < (OH1_); ++oh)                                                   \
+    _Pragma("unroll") for (int ot = 0; ot < TSL; ++ot)                                                         \
+      _Pragma("unroll") for (int ow = 0; ow < 3; ++ow) {                                                       \
+        const float* ap = rowq[oh] + (ot * 3 * kC16Row + ow) * 16;                                             \
+        const int tp = (ot * 3 + oh) * 3 + ow;                                                                 \
+        _Pragma("unroll") for (int kb = 0; kb < 8; ++kb)                                                       \
+          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kb * 64], bf[kb], acc[tp], 0, 0, 0);               \
+      }
+      // (a one-block last strip multiplies its absent pixels by zero dy fragments: skipping them — a second code path, or a
+      // branch around the second half of the K-chunks — cost more in registers / scheduling than the 12 % of MFMAs it saves)
+      WG_TAPS(0, 1)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (h + 1 < h1) { WG_STAGE(h + 1) }
+      WG_TAPS(1, 3)
+#undef WG_TAPS
+    }
+#undef WG_STAGE
+   }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float* dw = a.dwp + ((long)wset * NTAPS * a.Cin + ga * 16) * a.CoutPad;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * a.Cin + r0 + r) * a.CoutPad + gb0 * 16 + col, acc[tp][r]);
+  if (a.dbias && ga == 0) {
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + gb0 * 16 + lane, v);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // wgrad16_strip_kernel on split-precision MFMAs (opt-in, IDEE_CONV_MATH=split): bf16 pieces (gradients have no a-priori
 // scale), three piece products per tap, K = the strip's 32 pixels in ONE v_mfma_f32_16x16x32_bf16: 81 MFMAs of 16 cycles
 // per output row instead of 216 f32 MFMAs of 32 cycles.  The x rows are staged as token-major piece images
@@ -2664,6 +2820,19 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const bool split = conv_split_math() && Gb == 1 && Ga == 1;
     if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSTRIP((wgrad16_split_kernel<FWD_S2, 2>));
+    else if (rep && !getenv("IDEE_WGRAD16_REGS")) {
+      // LDS-DMA staged kernel, cost-axis partition (see conv16_glds_kernel); a one-block last strip's rows weigh by their K-chunks
+      auto kern = wgrad16_glds_kernel;
+      const int nsubw = cdiv(d->W, 16), lone = nsubw & 1, nfull = nstrip - lone;
+      const int kbn_l = imin(8, (imin(d->W - (nstrip - 1) * 32, 16) + 3) / 4);
+      const int wl = 10; (void)kbn_l; (void)lone;     // (a one-block strip still runs all 8 K-chunks: see the kernel)
+      const long rows_s = (long)(d->B / d->wsets) * ((a.To & 3) ? a.To * 4L : a.To) / 4 * d->H * nstrip;
+      if (rows_s * 10 >= (1L << 31)) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv_wgrad: %ld strip rows exceed the 32-bit work partition", rows_s);
+      long g = imax(((long)kCUs * wg_per_cu(kern, 256)) / ((long)d->wsets * gz), 1);
+      long cap = imax(rows_s / 8, 1);
+      if (const char* e = getenv("IDEE_CONV_HRUN")) { const int v = atoi(e); if (v > 0) { cap = cdiv(rows_s, v); g = cap; } }
+      hipLaunchKernelGGL(kern, dim3((unsigned)imax(imin(g, cap), 1), d->wsets, gz), dim3(256), 0, st, a, nstrip, nfull, wl);
+    }
     else if (rep) LSTRIP((wgrad16_strip_kernel<FWD_REP, 3, 1>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO) LSTRIP((wgrad16_strip_kernel<FWD_S2, 2, 1>));
     else if (Gb == 1) LSTRIP((wgrad16_strip_kernel<FWD_S2, 1, 1>));
