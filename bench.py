@@ -277,7 +277,7 @@ def main():
 
     for _ in range(a.warmup):
         ts.step(x, *masks)
-    timed = ["idee_conv_fwd", "idee_conv_dgrad", "idee_conv_wgrad", "idee_swin_block_fwd", "idee_swin_block_bwd",
+    timed = ["idee_conv_fwd", "idee_conv_dgrad", "idee_conv_dgrad_add", "idee_conv_wgrad", "idee_swin_block_fwd", "idee_swin_block_bwd",
              "idee_lfq_fwd", "idee_lfq_bwd", "idee_patch_embed_ln_fwd", "idee_patch_embed_ln_bwd", "idee_anomaly_l1_fwd", "idee_anomaly_l1_signs_fwd", "idee_anomaly_l1_signs_bwd",
              "idee_anomaly_l1_bwd", "idee_adam_step", "idee_ln_relu_res_fwd", "idee_ln_relu_res_bwd"]
     log = _lib.set_event_log(timed)
@@ -301,6 +301,7 @@ def main():
     import ctypes
     per, fam = {}, {}
     for name, evs in log.items():
+        name = "idee_conv_dgrad" if name == "idee_conv_dgrad_add" else name      # the same kernels, out = dgrad + addend
         for e0, e1, args in evs:
             ms = e0.elapsed_time(e1)
             key, flops = name, 0.0
