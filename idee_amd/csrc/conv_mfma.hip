@@ -2214,6 +2214,7 @@ struct C1Args {
   long x_sB, x_sT, x_sH, x_sW, x_sG, x_sU;
   int x_gpu;
   int accumulate;
+  int To;              // output frames: frame `to` of item b reads input frames 2 to, 2 to + 1 (x has 2 To frames, y / dy has To)
 };
 // weight of (tap, cin) for cout 0 in the packed buffers
 __device__ __forceinline__ f32x4 c1_w4_fwd(const float* wp, int Gi, int tap, int c4 /* cin = 4*c4 .. +3 */) {
@@ -2233,7 +2234,7 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
   const int QC = a.C / 4, Gi = a.C / 16;
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, GPB = 256 / LPP;
   const int WG = (a.W + PXT - 1) / PXT;
-  const long ngrp = (long)a.B * a.H * WG;
+  const long ngrp = (long)a.B * a.To * a.H * WG;       // (item, output frame) pairs walk like a batch of a.B * a.To items
   // this lane's 4 channels of all 18 taps stay in registers (re-read when the weight set changes: per-variable heads)
   f32x4 wr[18];
   int wcur = -1;
@@ -2245,15 +2246,15 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
     int b = 0, h = 0, w0 = 0;
     if (g < ngrp && q < QC) {
       w0 = (int)(g % WG) * PXT; h = (int)((g / WG) % a.H);
-      b = (int)(g / ((long)WG * a.H));
-      const int wset = b % a.wsets;
+      b = (int)(g / ((long)WG * a.H));           // (item, frame) pair index; item = b / To
+      const int wset = (b / a.To) % a.wsets;
       if (wset != wcur) {
         wcur = wset;
         const float* wp = a.w + (long)wset * 18 * Gi * 256;
 #pragma unroll
         for (int tap = 0; tap < 18; ++tap) wr[tap] = c1_w4_fwd(wp, Gi, tap, q);
       }
-      const float* xb = a.x + (long)b * a.x_sB + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
+      const float* xb = a.x + (long)(b / a.To) * a.x_sB + (long)(b % a.To) * 2 * a.x_sT + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -2282,7 +2283,7 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
 #pragma unroll
       for (int sft = 1; sft < LPP; sft <<= 1) acc += __shfl_xor(acc, sft, 64);
       if (g < ngrp && q == 0 && w0 + o < a.W)
-        a.y[((long)b * a.H + h) * a.W + w0 + o] = acc + (a.bias ? a.bias[b % a.wsets] : 0.f);
+        a.y[((long)b * a.H + h) * a.W + w0 + o] = acc + (a.bias ? a.bias[(b / a.To) % a.wsets] : 0.f);
     }
   }
 }
@@ -2291,7 +2292,7 @@ template <int LPP>
 __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
   const int QC = a.C / 4, Gi = a.C / 16;
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
-  const long npix = (long)a.B * 2 * a.H * a.W;       // input pixels (b, kt, h, w)
+  const long npix = (long)a.B * a.To * 2 * a.H * a.W;       // input pixels (b, to, kt, h, w)
   // this lane's 4 channels of all 18 taps, once (requires one weight set per launch column: blockIdx.y = wset)
   const int wset = blockIdx.y;
   f32x4 wr[18];
@@ -2303,14 +2304,16 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
       for (int u = 0; u < 4; ++u) wr[tap][u] = c1_w_dgrad(wp, Gi, tap, 4 * q + u);
   }
   const int nb = a.B / a.wsets;
-  const long npw = (long)nb * 2 * a.H * a.W;
+  const long npw = (long)nb * a.To * 2 * a.H * a.W;
   (void)npix;
   for (long p0 = (long)blockIdx.x * PPB; p0 < npw; p0 += (long)gridDim.x * PPB) {
     const long p = p0 + pl;
     if (p >= npw || q >= QC) continue;
     const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H), kt = (int)((p / ((long)a.W * a.H)) % 2);
-    const int b = (int)(p / ((long)a.W * a.H * 2)) * a.wsets + wset;
-    const float* dyb = a.dy + (long)b * a.H * a.W;
+    const long bt = p / ((long)a.W * a.H * 2);                           // (item of this weight set, output frame)
+    const int to = (int)(bt % a.To);
+    const int b = (int)(bt / a.To) * a.wsets + wset;
+    const float* dyb = a.dy + ((long)b * a.To + to) * a.H * a.W;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int oh = 0; oh < 3; ++oh) {
@@ -2323,7 +2326,7 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
         acc += (kt == 0 ? wr[oh * 3 + ow] : wr[9 + oh * 3 + ow]) * g;
       }
     }
-    const long off = (long)b * a.x_sB + (long)kt * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
+    const long off = (long)b * a.x_sB + (long)(2 * to + kt) * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
     if (a.relu_ref) {
       const f32x4 rr = ld4(a.relu_ref + off);
 #pragma unroll
@@ -2342,7 +2345,7 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
   const int wset = blockIdx.y;
   const int nb = a.B / a.wsets;
-  const long npix = (long)nb * a.H * a.W;            // source pixels per kt for this weight set
+  const long npix = (long)nb * a.To * a.H * a.W;     // source pixels per kt for this weight set
   f32x4 acc[2][9];
   float bsum = 0.f;
 #pragma unroll
@@ -2362,8 +2365,10 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
       on[r] = p < npix && q < QC;
       const long pc = on[r] ? p : 0;
       const int ws = (int)(pc % a.W), hs = (int)((pc / a.W) % a.H);
-      const int b = (int)(pc / ((long)a.W * a.H)) * a.wsets + wset;
-      const float* dyb = a.dy + (long)b * a.H * a.W;
+      const long bt = pc / ((long)a.W * a.H);
+      const int to = (int)(bt % a.To);
+      const int b = (int)(bt / a.To) * a.wsets + wset;
+      const float* dyb = a.dy + ((long)b * a.To + to) * a.H * a.W;
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh)
 #pragma unroll
@@ -2371,7 +2376,7 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
           const int h = hs - (oh - 1), w = ws - (ow - 1);      // output pixel this source feeds through tap (oh, ow)
           gq[r][oh * 3 + ow] = (on[r] && h >= 0 && h < a.H && w >= 0 && w < a.W) ? dyb[(long)h * a.W + w] : 0.f;
         }
-      const float* xb = a.x + (long)b * a.x_sB + (long)hs * a.x_sH + (long)ws * a.x_sW + goff((on[r] ? q : 0) / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * ((on[r] ? q : 0) % 4);
+      const float* xb = a.x + (long)b * a.x_sB + (long)(2 * to) * a.x_sT + (long)hs * a.x_sH + (long)ws * a.x_sW + goff((on[r] ? q : 0) / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * ((on[r] ? q : 0) % 4);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) xq[r][kt] = ld4(xb + (long)kt * a.x_sT);
     }
@@ -2423,7 +2428,7 @@ int launch_c1(int which, C1Args& a, hipStream_t st) {
   if (QC > 64) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): Cin %d > 256 is not built", a.C);
   const int PPB = 256 / LPP;
   const long nbw = a.B / a.wsets;
-  const long npix = which == 1 ? nbw * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * ((a.W + 3) / 4) : nbw * a.H * a.W);
+  const long npix = (which == 1 ? nbw * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * ((a.W + 3) / 4) : nbw * a.H * a.W)) * a.To;
   const int per = which == 0 ? 1 : a.wsets;                       // dgrad / wgrad: one weight set per grid column
   const int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : 8), per));
   const dim3 grid(gx < 1 ? 1 : gx, per);
@@ -2434,10 +2439,15 @@ int launch_c1(int which, C1Args& a, hipStream_t st) {
 #undef C1
   return IDEE_OK;
 }
-bool is_c1(const idee_conv_desc* d) { return d->Cout == 1 && d->mode == IDEE_CONV_K233_S2_ZERO && d->T == 2; }
+// Cout = 1 (2,3,3) stride-2 convs: streaming kernels, any even frame count (T = 2: the reference's last classifier conv at T = 8;
+// T = 4: the same conv at T = 16), y / dy a contiguous (B, T / 2, H, W)
+bool is_c1(const idee_conv_desc* d) {
+  return d->Cout == 1 && d->mode == IDEE_CONV_K233_S2_ZERO && d->T >= 2 && d->T % 2 == 0 && d->y_sW == 1 && d->y_sH == d->W &&
+         d->y_sB == (long)(d->T / 2) * d->H * d->W && (d->T == 2 || d->y_sT == (long)d->H * d->W);
+}
 void fill_c1(C1Args& a, const idee_conv_desc* d) {
   memset(&a, 0, sizeof(a));
-  a.B = d->B; a.wsets = d->wsets; a.H = d->H; a.W = d->W; a.C = d->Cin;
+  a.B = d->B; a.wsets = d->wsets; a.H = d->H; a.W = d->W; a.C = d->Cin; a.To = d->T / 2;
   a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;
   a.x_sU = d->x_sU; a.x_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30);
 }
@@ -2698,7 +2708,7 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const float* x, const floa
                              idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   IDEE_CHECK_ARG(x && w_packed && y, "conv_fwd: null argument");
-  if (is_c1(d) && d->y_sW == 1 && d->y_sH == d->W && d->y_sB == (long)d->H * d->W) {
+  if (is_c1(d)) {
     C1Args c; fill_c1(c, d);
     c.x = x; c.w = w_packed; c.bias = bias; c.y = y;
     if (int rc = launch_c1(0, c, (hipStream_t)stream)) return rc;
@@ -2731,7 +2741,7 @@ extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const float* dy, con
                                    const float* addend, float* dx, idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   IDEE_CHECK_ARG(dy && w_packed_dgrad && dx, "conv_dgrad: null argument");
-  if (is_c1(d) && d->y_sW == 1 && d->y_sH == d->W && d->y_sB == (long)d->H * d->W) {
+  if (is_c1(d) && d->T == 2) {      // (at T = 4 the padded MFMA path is faster for the data gradient: 0.35 vs 0.53 ms at config #4)
     IDEE_CHECK_ARG(!addend || addend == dx, "conv_dgrad (Cout = 1): a separate addend is not built");
     const int accumulate = addend != nullptr;
     C1Args c; fill_c1(c, d);
@@ -2773,7 +2783,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
                                idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   IDEE_CHECK_ARG(x && dy && dw_packed, "conv_wgrad: null argument");
-  if (is_c1(d) && d->y_sW == 1 && d->y_sH == d->W && d->y_sB == (long)d->H * d->W) {
+  if (is_c1(d)) {
     C1Args c; fill_c1(c, d);
     c.x = x; c.dy = dy; c.dwp = dw_packed; c.dbias = dbias;
     if (int rc = launch_c1(2, c, (hipStream_t)stream)) return rc;

@@ -313,7 +313,7 @@ def test_classifier_golden():
 
 
 @pytest.mark.parametrize("V,H,W,E", [(3, 7, 72, 16), (6, 5, 40, 16), (1, 3, 3, 16), (5, 4, 20, 16), (6, 6, 200, 16), (2, 3, 200, 16),
-                                     (6, 4, 24, 32), (3, 3, 20, 32), (2, 19, 40, 16)])
+                                     (6, 4, 24, 32), (3, 3, 20, 32), (2, 19, 40, 16), (3, 5, 24, 16)])
 def test_classifier_vs_oracle(V, H, W, E, monkeypatch):
     """Plain path (convolutions on z_q).  W = 200: the frame-wide row-wrapping column-block numbering of conv_wide,
     its zero borders, the wide weight-gradient kernel and the heads' strip kernels at both frame edges.  E = 32 (config #4's
@@ -321,15 +321,16 @@ def test_classifier_vs_oracle(V, H, W, E, monkeypatch):
     weight gradient over (input block, output block) pairs)."""
     from oracle import idee_oracle as O
     from idee_amd.models.classifier.CNN_3D import CNN_3D
-    N, T = (1 if W == 200 else 2), 8
-    if H == 19:      # the heads' strip kernels in runs of 8, 8, 3 rows (run starts away from row 0)
+    N, T = (1 if W == 200 else 2), (16 if (H, W, E) == (5, 24, 16) else 8)     # T = 16 (config #4): two output frames, the
+    if H == 19:      # the heads' strip kernels in runs of 8, 8, 3 rows (run starts away from row 0)      # Cout = 1 convs read 4
         monkeypatch.setenv("IDEE_CONV_HRUN", "8")
 
     torch.manual_seed(V * 100 + W)
     c = CNN_3D(in_var=V, embed_dim=E, dim=E, drop_rate=0.0)
     sd = {k: v.clone() for k, v in c.state_dict().items()}
     x = torch.randn(N, V, E, T, H, W)
-    rz, ry = torch.randn(N, 1, H, W), torch.randn(V, N, 1, H, W)
+    oshape = (N, 1, H, W) if T == 8 else (N, 1, T // 8, H, W)
+    rz, ry = torch.randn(oshape), torch.randn((V,) + oshape)
     runs = []
     for mode in (0, 1):                      # oracle backward with the ReLU derivative at tie units forced to 0 / to 1
         sdl = {k: v.clone().requires_grad_() for k, v in sd.items()}
