@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 CONFIGS = {
     # id: (encoder, H, W, T, C_in, per-GPU batch, model overrides, step kind, label)
@@ -56,8 +56,9 @@ def parse():
     ap.add_argument("--hw", type=int, default=None, help="override grid height = width")
     ap.add_argument("--encoder", default=None, help="override the config's encoder")
     ap.add_argument("--math", default="f32", choices=["f32", "split"],
-                    help="f32 (default): convolutions on the exact-f32 MFMA.  split: the opt-in split-precision 16->16 "
-                         "convolution kernels (IDEE_CONV_MATH=split) — a separately labelled line, never the headline")
+                    help="f32 (default): every GEMM-shaped kernel on the exact-f32 MFMA (the reference's arithmetic).  split: the "
+                         "opt-in two-piece split-precision kernels, convolutions (IDEE_CONV_MATH=split) AND Swin linear layers "
+                         "(IDEE_SWIN_MATH=split) — a separately labelled line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-eval", action="store_true", help="skip the eval-mode forward timing (profiling runs: every launch then belongs to a train step)")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-entry-point / per-shape time table (stderr)")
@@ -67,30 +68,68 @@ def parse():
 # ---------------------------------------------------------------------------------------------
 # multi-rank launch (no GPU call may precede this in the parent)
 # ---------------------------------------------------------------------------------------------
-def launch_ranks(a):
-    """Start a.gpus child ranks of this script (one per GPU), wait, propagate their status."""
+def visible_gpus():
+    """GPUs this process may use, WITHOUT opening the HIP runtime in the launcher: the KFD topology in sysfs (a node with
+    simd_count > 0 is a GPU), narrowed by HIP_/ROCR_/CUDA_VISIBLE_DEVICES.  None when sysfs is unreadable (then every
+    child validates its own device index and the launcher only polices their exit codes)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:  # noqa: BLE001
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
+def launch_ranks(a, argv=None, poll_s=0.2):
+    """Start a.gpus child ranks of this script (one fresh process per GPU; this launcher never touches HIP), poll them, and
+    on the FIRST non-zero exit terminate the siblings (a rank that dies before the first collective would otherwise leave
+    them blocked in the rendezvous until the driver's limit) and return that status."""
     import socket
-    import torch   # importing torch and counting devices does not initialise the GPU on this image
     forced = "IDEE_FORCE_DEVICE" in os.environ
-    have = torch.cuda.device_count()
-    if have < a.gpus and not forced:
+    have = visible_gpus()
+    if have is not None and have < a.gpus and not forced:
         sys.stderr.write(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible; refusing to report a smaller run\n")
         return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    cmd = argv if argv is not None else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                    IDEE_BENCH_CHILD="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc, live = 0, list(procs)
+    while live and rc == 0:
+        time.sleep(poll_s)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = r
+                break
     if rc:
-        sys.stderr.write(f"bench.py: a rank exited with status {rc}\n")
+        sys.stderr.write(f"bench.py: rank process {procs.index(p)} exited with status {rc}; stopping the other ranks\n")
+        for q in live:
+            q.terminate()                      # exact PIDs this launcher started
+        deadline = time.time() + 10
+        for q in live:
+            try:
+                q.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
     return rc
 
 
@@ -153,6 +192,23 @@ def pmc_traffic(family, launches_per_step, headline):
     if tot <= 0 or not launches_per_step:
         return None, None
     return round(tot / launches_per_step), f"profiles/{os.path.basename(PMC_SUMMARY)} @ {doc.get('source_commit', '?')}"
+
+
+def math_label(math, cfg):
+    """What arithmetic the GEMM-shaped kernels of THIS run used (the library switches are pinned in main())."""
+    swin = cfg.encoder == "Swin_3D"
+    if math == "f32":
+        d = dict(conv="exact f32 MFMA (v_mfma_f32_16x16x4_f32)", everything_else="f32")
+        if swin:
+            d["swin_gemm"] = "exact f32 MFMA (v_mfma_f32_16x16x4_f32) for every linear layer, the attention scores and P.V, at every width"
+        return d
+    d = dict(conv="16->16 convs (all three passes) and the forward / data gradient of the 96-wide convs: two 16-bit pieces per operand, "
+                  "3 piece products (f16 fwd: 2^-22 operand rounding, bf16 bwd: 2^-18); every other conv kernel exact f32 MFMA",
+             everything_else="f32")
+    if swin:
+        d["swin_gemm"] = ("C = 16 and C = 32: two 16-bit pieces per operand, all 4 piece products, f32 accumulate (f16 pieces fwd: 2^-22 "
+                          "operand rounding; bf16 pieces bwd: 2^-18); attention scores on the f32 MFMA")
+    return d
 
 
 def host_cores():
@@ -236,8 +292,10 @@ def cpu_baseline(cfg, kind, model, T, H, W):
 
 def main():
     a = parse()
-    if a.math == "split":
-        os.environ["IDEE_CONV_MATH"] = "split"          # read by the library at every convolution launch; inherited by ranks
+    # the library reads these at every launch; child ranks inherit them.  The headline (--math f32) pins BOTH to the exact-f32
+    # kernels whatever the caller's environment holds, so the printed `dtype` / `math` always describe what ran.
+    os.environ["IDEE_CONV_MATH"] = "split" if a.math == "split" else "f32"
+    os.environ["IDEE_SWIN_MATH"] = "split" if a.math == "split" else "f32"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
     import torch
@@ -332,7 +390,11 @@ def main():
     if mfma_fams:
         k, (ms, n, fl) = mfma_fams[0]          # the entry point (all its shapes) with the largest total time in the timed region
         traffic, src = pmc_traffic(k, n // a.steps, headline)
-        roof = dict(kernel=k + " (all launches of this entry point in the step)", bound="mfma", achieved=round(fl / ms / 1e9, 3),
+        # what actually limits the family (profiles/r03_sq_counters.txt): the convolution kernels are paced by the f32 MFMA pipe
+        # (MFMA-busy ~80 %); the fused Swin kernels by VALU issue (LayerNorm / softmax / GELU share the issue slots with the f32
+        # MFMA, which does not co-execute with VALU work on gfx950) — their peak is the same 157.3 TFLOP/s f32 vector rate
+        bound = "valu" if k.startswith("idee_swin") else "mfma"
+        roof = dict(kernel=k + " (all launches of this entry point in the step)", bound=bound, achieved=round(fl / ms / 1e9, 3),
                     peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                     traffic_source=src, avg_launch_ms=round(ms / n, 4), flops_per_launch=fl / n, launches_per_step=n // a.steps,
                     share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
@@ -357,13 +419,9 @@ def main():
     out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * batch * a.steps / dt, 3),
                unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
                ms_per_step_median=round(statistics.median(step_ms), 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f32" if a.math == "f32" else "f32 storage/accumulate, 16->16 and 96-wide 3x3 convolutions (fwd, data gradient; 16->16 weight gradient) on f16x3 (fwd) / bf16x3 (bwd) split MFMAs",
-               math=dict(conv="exact f32 MFMA (v_mfma_f32_16x16x4_f32)" if a.math == "f32" else
-                              "16->16 convs and the forward / data gradient of the 96-wide convs: two 16-bit pieces per operand, 3 piece products (f16 fwd, bf16 bwd); every other conv kernel exact f32 MFMA",
-                         swin_gemm=("exact f32 MFMA" if os.environ.get("IDEE_SWIN_MATH") == "f32" or cfg.en_embed_dim[0] != 16 else
-                                    "two 16-bit pieces per operand, all 4 piece products, f32 accumulate (f16 pieces fwd: 2^-22 operand "
-                                    "rounding; bf16 pieces bwd: 2^-18); attention scores on the f32 MFMA"),
-                         everything_else="f32"),
+               dtype="f32" if a.math == "f32" else
+                     "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs",
+               math=math_label(a.math, cfg),
                data="synthetic",
                config=dict(workload=f"#{a.config}: {label}, V={cfg.in_channels_dynamic}, batch {batch}/GPU" +
                                     (f", grid overridden to {H}x{W}" if a.hw else ""), global_batch=world * batch,

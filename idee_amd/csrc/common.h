@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/idee_hip.h"
@@ -29,6 +30,13 @@ int fail(int code, const char* fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int imin(long a, long b) { return (int)(a < b ? a : b); }
 static inline int imax(long a, long b) { return (int)(a > b ? a : b); }
+
+// Kernel-selection switches (IDEE_*) are read from the environment at EVERY launch (no cached statics), so a test can toggle
+// them between calls of one process.
+static inline bool env_is(const char* name, const char* value) {
+  const char* e = getenv(name);
+  return e && strcmp(e, value) == 0;
+}
 
 // number of workgroups that fills the chip a few times over (256 CUs)
 constexpr int kCUs = 256;

@@ -2517,18 +2517,14 @@ void split_tiles(ConvArgs& a, int Wframe) {
 }
 
 // IDEE_CONV_MATH=split selects the split-precision 16 -> 16 kernels (default: exact f32 MFMA)
-bool conv_split_math() {
-  const char* e = getenv("IDEE_CONV_MATH");
-  return e && strcmp(e, "split") == 0;
-}
+bool conv_split_math() { return env_is("IDEE_CONV_MATH", "split"); }
 
 template <int MODE>
 int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
   if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
     // 32 -> 32 replicate convolutions (config #4's width) as 2 x 2 sub-problems on the 16 -> 16 strip kernel: output block n =
     // sum over input blocks g, the second pass adding to the first in place (the generic kernel ran them at 73-78 TFLOP/s)
-    static const bool no_split = [] { const char* e = getenv("IDEE_CONV32"); return e && strcmp(e, "generic") == 0; }();
-    static const bool reg16 = [] { const char* e = getenv("IDEE_CONV16"); return e && strcmp(e, "regs") == 0; }();
+    const bool no_split = env_is("IDEE_CONV32", "generic"), reg16 = env_is("IDEE_CONV16", "regs");   // read at every launch
     if (!cin1 && !no_split && !reg16 && !conv_split_math() && a.Gk == 2 && a.GnTot == 2 && a.cout_real == 32 && !a.w_tap_stride &&
         !(a.addend && a.relu)) {
       const int GA = a.Gk, GB = a.GnTot;        // fwd: input, output blocks ; dgrad: dy, dx blocks (packed [tap][GA][GB])
@@ -2573,7 +2569,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         return IDEE_OK;
       }
       if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
-        static const bool reg_staged = [] { const char* e = getenv("IDEE_CONV16"); return e && strcmp(e, "regs") == 0; }();
+        const bool reg_staged = env_is("IDEE_CONV16", "regs");
         if (!reg_staged) {
           auto kern = conv16_glds_kernel<MODE>;
           // workgroups per weight set: one round of resident workgroups, at least ~8 rows each; IDEE_CONV_HRUN (test knob)
@@ -2596,7 +2592,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
     }
   }
   if constexpr (MODE == DGRAD_S2) {
-    static const bool old_path = [] { const char* e = getenv("IDEE_DGRAD_TO16"); return e && strcmp(e, "wide") == 0; }();
+    const bool old_path = env_is("IDEE_DGRAD_TO16", "wide");
     if (!cin1 && !old_path && a.kt == 1 && a.GnTot == 1 && a.cout_real == 16 && a.Gk >= 2 && a.Gk <= 12 && a.o_sW % 4 == 0) {
       // (1,3,3) data gradient into one 16-channel block: K split over the waves of a workgroup
       const int nstrip = cdiv(cdiv(a.Wo, 16), 2);
@@ -2830,7 +2826,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const fl
     const bool split = conv_split_math() && Gb == 1 && Ga == 1;
     if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSTRIP((wgrad16_split_kernel<FWD_S2, 2>));
-    else if (rep && !getenv("IDEE_WGRAD16_REGS")) {
+    else if (rep && !env_is("IDEE_WGRAD16_REGS", "1")) {
       // LDS-DMA staged kernel, cost-axis partition (see conv16_glds_kernel); a one-block last strip's rows weigh by their K-chunks
       auto kern = wgrad16_glds_kernel;
       const int nsubw = cdiv(d->W, 16), lone = nsubw & 1, nfull = nstrip - lone;

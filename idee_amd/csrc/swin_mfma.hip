@@ -2020,11 +2020,10 @@ int make_geom(const idee_swin_geom* s, Geom& g, int& NW) {
   return IDEE_OK;
 }
 
-// IDEE_SWIN_MATH=f32 selects the exact-f32 MFMA kernels; default: the split-bf16 GEMM kernels where they exist (C = 16)
-bool split_math() {
-  const char* e = getenv("IDEE_SWIN_MATH");
-  return !(e && strcmp(e, "f32") == 0);
-}
+// Default: the exact-f32 MFMA kernels (the reference's arithmetic: fp32 nn.Linear, Swin_3D.py:145-178, 264-265).
+// IDEE_SWIN_MATH=split opts into the two-piece split-precision GEMM kernels (f16 pieces forward, bf16 pieces backward:
+// operand rounding 2^-22 / 2^-18) — a separately labelled bench line (bench.py --math split), never the headline.
+bool split_math() { return env_is("IDEE_SWIN_MATH", "split"); }
 
 // One round of resident workgroups: gx * B <= CUs * (workgroups per CU), so that no CU is left with a
 // lone straggler round (work items are uniform; every workgroup loops over its share).

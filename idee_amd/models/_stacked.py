@@ -43,3 +43,28 @@ class StackedModule(nn.Module):
             for k in state_dict:
                 if k.startswith(prefix) and k not in expected and not k.startswith(own_children):
                     unexpected_keys.append(k)
+
+
+def reference_param_slices(model):
+    """[(reference key, stacked Parameter, index | None, reference shape)] in the order of the REFERENCE model's `model.parameters()` — the
+    index space of torch.optim.Adam's state dict in a reference checkpoint (utils_train.py:562-584).  The reference registers
+    one small parameter per variable where this code base keeps one V-stacked parameter; entry i is the slice
+    `parameter[index]` (or the whole parameter) that the reference's i-th parameter corresponds to.  Walks the module tree in
+    registration order (= the reference's, verified against the golden state-dict key order); buffers are skipped."""
+    out = []
+    for prefix, mod in model.named_modules():
+        pre = prefix + "." if prefix else ""
+        if isinstance(mod, StackedModule):
+            for key, name, idx in mod._key_map():
+                p = mod._parameters.get(name)
+                if p is None and name.endswith("_w5"):        # "<x>_w5": the (…,1,1,1) state-dict view of parameter "<x>_w"
+                    p = mod._parameters.get(name[:-1])
+                if p is None:
+                    continue                                   # a buffer (relative_position_index)
+                t = getattr(mod, name)                        # the state-dict-shaped view (e.g. (V, C, Cin, 1, 1, 1))
+                out.append((pre + key, p, idx, tuple((t if idx is None else t[idx]).shape)))
+        else:
+            for name, p in mod._parameters.items():
+                if p is not None:
+                    out.append((pre + name, p, None, tuple(p.shape)))
+    return out

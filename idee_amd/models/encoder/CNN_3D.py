@@ -75,6 +75,7 @@ class CNN_3D(_stacked.StackedModule):
                           (f"{base}norm{u}.bias", f"l{l}_norm{u}_b", v)]
                 if has_ds:
                     m.append((base + "downsample.proj.weight", f"l{l}_ds_w5", v))
+        for v in range(self.in_vars):        # the reference registers layers_var (all variables) before proj_var: its key order
             m += [(f"proj_var.{v}.0.weight", "pv_w1", v), (f"proj_var.{v}.0.bias", "pv_b1", v),
                   (f"proj_var.{v}.2.weight", "pv_w2", v), (f"proj_var.{v}.2.bias", "pv_b2", v)]
         return m

@@ -147,6 +147,7 @@ class Swin_3D(_stacked.StackedModule):
                           (k + "mlp.fc2.weight", p + "fc2_w", v), (k + "mlp.fc2.bias", p + "fc2_b", v)]
                 if has_ds:
                     m += [(base + "downsample.proj.weight", f"s{s}_ds_w5", v), (base + "downsample.proj.bias", f"s{s}_ds_b", v)]
+        for v in range(self.in_vars):        # the reference registers layers_var (all variables) before proj_var: its key order
             m += [(f"proj_var.{v}.0.weight", "pv_w1", v), (f"proj_var.{v}.0.bias", "pv_b1", v),
                   (f"proj_var.{v}.2.weight", "pv_w2", v), (f"proj_var.{v}.2.bias", "pv_b2", v)]
         return m

@@ -8,6 +8,7 @@ call into libidee_hip.so.  Internal activation layout is channels-last tokens
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 
@@ -21,22 +22,42 @@ class ZeroArena:
     requested sizes; every later step takes ONE torch.zeros of the total and hands out 16-byte-aligned slices in the same
     order (256-byte aligned: float atomics of different buffers must not share a memory line).  A request that does not match the recorded sequence falls back to its own torch.zeros (and the arena re-records
     on the next step), so a change of shapes or of control flow is safe.  Used as `with arena:` around forward + backward
-    (idee_amd/train.py); without an active arena `_zeros` is plain torch.zeros."""
-    active = None
+    (idee_amd/train.py); without an active arena `_zeros` is plain torch.zeros.
+
+    Re-entrancy: the active arena is looked up BY HIP STREAM (autograd runs a backward node on the stream of its forward), so
+    two host threads stepping concurrently on their own streams each see their own arena: a slice is only ever handed to a
+    caller whose current stream is the one the buffer was zero-filled on, and `take` is serialised by a lock."""
+    _active = {}                      # stream handle -> arena
+    _lock = threading.Lock()
 
     def __init__(self):
         self.plan, self.recording, self.buf, self.pos, self.off, self.ok = None, [], None, 0, 0, True
+        self.stream = None
+
+    @staticmethod
+    def _stream_key():
+        return torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+
+    @classmethod
+    def current(cls):
+        if not cls._active:
+            return None
+        return cls._active.get(cls._stream_key())
 
     def __enter__(self):
         self.recording, self.pos, self.off, self.ok = [], 0, 0, True
         self.buf = None
         if self.plan is not None:
-            self.buf = torch.zeros(self.plan[1], device=self.plan[2], dtype=torch.float32)
-        ZeroArena.active = self
+            self.buf = torch.zeros(self.plan[1], device=self.plan[2], dtype=torch.float32)     # filled on the current stream
+        self.stream = self._stream_key()
+        with ZeroArena._lock:
+            ZeroArena._active[self.stream] = self
         return self
 
     def __exit__(self, *exc):
-        ZeroArena.active = None
+        with ZeroArena._lock:
+            if ZeroArena._active.get(self.stream) is self:
+                del ZeroArena._active[self.stream]
         if self.buf is None or not self.ok or self.pos != len(self.plan[0]):
             total = sum(n for n, _ in self.recording)
             dev = self.recording[0][1] if self.recording else None
@@ -46,23 +67,24 @@ class ZeroArena:
 
     def take(self, numel, device):
         n = (numel + 63) // 64 * 64        # 256-byte slots: small accumulate-into buffers on separate lines
-        self.recording.append((n, device))
-        if self.buf is not None and self.ok and self.pos < len(self.plan[0]) and self.plan[0][self.pos] == n and device == self.plan[2]:
-            out = self.buf[self.off:self.off + numel]
-            self.pos += 1
-            self.off += n
-            return out
-        self.ok = False
+        with ZeroArena._lock:
+            self.recording.append((n, device))
+            if self.buf is not None and self.ok and self.pos < len(self.plan[0]) and self.plan[0][self.pos] == n and device == self.plan[2]:
+                out = self.buf[self.off:self.off + numel]
+                self.pos += 1
+                self.off += n
+                return out
+            self.ok = False
         return torch.zeros(numel, device=device, dtype=torch.float32)
 
 
 def _zeros(shape, device):
-    """Zero-filled f32 tensor: a slice of the step's ZeroArena when one is active, else torch.zeros."""
+    """Zero-filled f32 tensor: a slice of the ZeroArena active on the CURRENT stream when there is one, else torch.zeros."""
     shape = tuple(shape) if not isinstance(shape, int) else (shape,)
     numel = 1
     for d in shape:
         numel *= int(d)
-    a = ZeroArena.active
+    a = ZeroArena.current()
     if a is None or numel == 0:
         return torch.zeros(shape, device=device, dtype=torch.float32)
     return a.take(numel, torch.device(device)).view(shape)

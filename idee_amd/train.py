@@ -18,6 +18,7 @@ import torch
 
 from . import ops, optim, parallel
 from .models.build import VQ_model
+from .models._stacked import reference_param_slices
 
 
 class _TrainStep:
@@ -25,8 +26,9 @@ class _TrainStep:
         self.config = config
         self.model = (model if model is not None else VQ_model(config)).to(device)
         self.model.train()
+        # state_dict() / load_state_dict() of this optimizer index the REFERENCE model's ~240 per-variable parameters
         self.opt = optim.Adam(self.model.parameters(), lr=config.lr, weight_decay=config.weight_decay,
-                              betas=(config.beta1, config.beta2))
+                              betas=(config.beta1, config.beta2), reference_slices=reference_param_slices(self.model))
         parallel.broadcast_parameters(self.opt.flat_p)
         self.code0 = torch.zeros(1, dtype=torch.long, device=device)
         self.arena = ops.ZeroArena()

@@ -30,6 +30,39 @@ def golden():
 
 
 # ---------------------------------------------------------------------------------------------
+# Kernel variants.  libidee_hip.so reads its IDEE_* kernel-selection switches from the environment at EVERY launch, so the
+# `-m gpu` suite runs the parity tests once per variant that ships: every kernel in the library is reached by a driver-run
+# test id (e.g. test_swin_block_golden[swin_split-w244_shift]), not by scratch logs.
+# ---------------------------------------------------------------------------------------------
+KERNEL_VARIANTS = {
+    "default": {},                                                   # exact-f32 MFMA everywhere (the headline arithmetic)
+    "swin_split": {"IDEE_SWIN_MATH": "split"},                       # two-piece split GEMMs in the Swin block (opt-in)
+    "conv_split": {"IDEE_CONV_MATH": "split"},                       # split-precision convolutions (opt-in)
+    "all_split": {"IDEE_SWIN_MATH": "split", "IDEE_CONV_MATH": "split"},
+    "conv16_regs": {"IDEE_CONV16": "regs"},                          # register-staged 16->16 strip kernel
+    "wgrad16_regs": {"IDEE_WGRAD16_REGS": "1"},                      # register-staged 3^3 weight gradient
+    "conv32_generic": {"IDEE_CONV32": "generic"},                    # 32->32 on the generic kernel
+    "dgrad_to16_wide": {"IDEE_DGRAD_TO16": "wide"},                  # (1,3,3) data gradient on conv_wide_kernel
+}
+
+
+def variants(*names):
+    """Decorator: run the test once per named kernel variant (the `kernel_variant` fixture sets the switches)."""
+    assert all(n in KERNEL_VARIANTS for n in names)
+    return pytest.mark.parametrize("kernel_variant", names, indirect=True)
+
+
+@pytest.fixture
+def kernel_variant(request, monkeypatch):
+    name = getattr(request, "param", "default")
+    for k in ("IDEE_SWIN_MATH", "IDEE_CONV_MATH", "IDEE_CONV16", "IDEE_WGRAD16_REGS", "IDEE_CONV32", "IDEE_DGRAD_TO16"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in KERNEL_VARIANTS[name].items():
+        monkeypatch.setenv(k, v)
+    return name
+
+
+# ---------------------------------------------------------------------------------------------
 # ReLU ties.  A ReLU unit whose pre-activation lies within f32 summation-order rounding of zero may
 # legitimately get the other mask bit on the GPU, which changes gradients discretely.  Instead of a
 # blanket outlier budget the gradient tests LIST such units: the oracle's pre-activations are recorded,

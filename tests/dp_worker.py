@@ -28,8 +28,57 @@ def global_batch(kind, cfg, N, T, H, W):
     return x, (me, ml)
 
 
+def vq_ema_main(out):
+    """VQ(ema_update, kmeans_init, threshold_ema_dead_code) under data parallelism (reference: VQ.py:164-202 sync'd k-means,
+    :233-244 all-reduced bins / sums, :528-539 all-reduced cluster sizes and per-code sums, expiry replacements from rank 0):
+    three training steps on this rank's shard of a seeded global batch; what the replicas hold afterwards."""
+    from idee_amd import parallel
+    from idee_amd.models.codebook.VQ import VQ
+    rank, world, local = parallel.init_from_env()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(3)
+    q = VQ(dim=16, codebook_size=8, codebook_dim=16, ema_update=True, learnable_codebook=False, decay=0.8, kmeans_init=True,
+           kmeans_iters=4, threshold_ema_dead_code=2)
+    q.sample_indices = lambda n, num, device: torch.arange(num, device=device)      # deterministic stand-in for randperm
+    q = q.to(dev).train()
+    g = torch.Generator().manual_seed(11)
+    steps = []
+    for step in range(3):
+        # a few tight clusters + two far outliers per step: some codes die (cluster size < 2) and get replaced
+        centres = torch.randn((5, 16), generator=g) * 3
+        x = centres[torch.randint(0, 5, (4, 60), generator=g)] + 0.1 * torch.randn((4, 60, 16), generator=g)
+        x[0, 0] += 50.0          # lone far tokens among the first K samples: they seed singleton codes (cluster size 1 < 2)
+        x[0, 1] -= 50.0
+        lo, hi = parallel.shard_batch(4, rank, world)
+        zq, idx, loss = q(x[lo:hi].to(dev))
+        idx_all = idx
+        if world > 1:
+            parts = [torch.empty_like(idx) for _ in range(world)]
+            torch.distributed.all_gather(parts, idx.contiguous())
+            idx_all = torch.cat(parts, 0)
+        sd = {k: v.detach().cpu().clone() for k, v in q.state_dict().items()}
+        equal = True
+        if world > 1:
+            for k in ("_codebook.embed", "_codebook.cluster_size", "_codebook.embed_avg"):
+                mine = q.state_dict()[k].clone()
+                ref = mine.clone()
+                torch.distributed.broadcast(ref, src=0)
+                flags = [None] * world
+                torch.distributed.all_gather_object(flags, bool(torch.equal(mine, ref)))
+                equal = equal and all(flags)
+        steps.append(dict(sd=sd, idx=idx_all.cpu(), replicas_equal=equal, zq0=zq[0].detach().cpu()))
+    if rank == 0:
+        torch.save(dict(world=world, steps=steps), out)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     kind, out = sys.argv[1], sys.argv[2]
+    if kind == "vq_ema":
+        return vq_ema_main(out)
     from idee_amd import parallel
     from idee_amd.config import default_config
     from idee_amd.train import SyntheticTrainStep, ERA5TrainStep
@@ -60,8 +109,15 @@ def main():
     ts.opt.step()
     p1 = ts.opt.flat_p.clone()
     total2, _, _ = ts.step(x, *masks)
+    # with world > 1 a rank reports its rescaled SHARE of every loss term: their mean over the ranks is the global-batch loss
+    names = sorted(parts)
+    vec = torch.stack([total.detach().reshape(()), total2.detach().reshape(())] + [parts[k].detach().reshape(()) for k in names]).double()
+    if world > 1:
+        torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM)
+        vec /= world
     res = dict(world=world, p0=p0.cpu(), grad=grad.cpu(), p1=p1.cpu(), p2=ts.opt.flat_p.cpu(),
-               parts={k: float(v) for k, v in parts.items()}, total2=float(total2))
+               parts={k: float(v) for k, v in zip(names, vec[2:])}, total1=float(vec[0]), total2=float(vec[1]),
+               weight_decay=float(cfg.weight_decay), lr=float(cfg.lr))
     if world > 1:
         # every rank must hold identical parameters after the steps
         mine = ts.opt.flat_p.clone()

@@ -9,6 +9,8 @@ import math
 import pytest
 import torch
 
+from conftest import variants
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -49,7 +51,8 @@ CROPS = {
 
 @pytest.mark.parametrize("crop", list(CROPS))
 @pytest.mark.parametrize("encoder", ["Swin_3D", "CNN_3D"])
-def test_fullsize_forward_matches_oracle_on_crop(encoder, crop):
+@variants('default', 'all_split')
+def test_fullsize_forward_matches_oracle_on_crop(encoder, crop, kernel_variant):
     """Full-size (V=6, T=8, 200x200) forward vs the ORACLE on a crop, element by element, no conditional skips:
     the continuous encoder output everywhere in the region; `anomaly` and z_q at every token that is not an LFQ
     boundary token (|s| < 1e-5: listed and counted); z and y at every pixel whose 3-pixel classifier neighbourhood
@@ -100,7 +103,8 @@ def test_fullsize_forward_matches_oracle_on_crop(encoder, crop):
     torch.testing.assert_close(R(torch.stack(y))[yk], torch.stack(yo)[..., rs, cs][yk], atol=5e-5, rtol=5e-4)
 
 
-def test_fullsize_width_swin_block_gradients_vs_oracle():
+@variants('default', 'swin_split')
+def test_fullsize_width_swin_block_gradients_vs_oracle(kernel_variant):
     """Shifted (2,4,4) Swin block and the (8,1,1) temporal block at the frame width W = 200 (H = 8): outputs and every
     gradient against the oracle (no ReLU in the block: strict tolerance as is)."""
     from oracle import idee_oracle as O
@@ -137,7 +141,8 @@ def test_fullsize_width_swin_block_gradients_vs_oracle():
             gclose("d" + n, p_.grad, torch.stack([sds[v][n].grad for v in range(V)]))
 
 
-def test_fullsize_conv_linearity_and_wgrad_identity():
+@variants('default', 'conv_split', 'conv16_regs', 'wgrad16_regs')
+def test_fullsize_conv_linearity_and_wgrad_identity(kernel_variant):
     """conv(a x1 + b x2) = a conv(x1) + b conv(x2) (bias off) for the 3^3 replicate conv at full size, and
     <conv(x), r> = <x, conv^T(r)> = <w, wgrad(x, r)> (adjoint identities tie fwd, dgrad and wgrad together)."""
     from idee_amd import ops

@@ -14,7 +14,7 @@ import os
 import pytest
 import torch
 
-from conftest import load_golden, relu_record, tie_free_case, tie_relu, interval_close
+from conftest import load_golden, relu_record, tie_free_case, tie_relu, interval_close, variants
 
 pytestmark = pytest.mark.gpu
 
@@ -97,7 +97,8 @@ def test_patch_merging_golden(tag):
 
 @pytest.mark.parametrize("tag", ["w244_noshift", "w244_shift", "w244_shift_pad", "w244_noshift_pad", "w811",
                                  "w811_T16_shift", "w244_c32"])
-def test_swin_block_golden(tag):
+@variants('default', 'swin_split')
+def test_swin_block_golden(tag, kernel_variant):
     ops = _ops()
     a, sd, grads = load_golden("swin_block_" + tag)
     params, names = _swin_params(sd)
@@ -111,7 +112,8 @@ def test_swin_block_golden(tag):
         gclose("d" + n, p.grad[0], grads[n])
 
 
-def test_swin_block_two_variables_vs_oracle():
+@variants('default', 'swin_split')
+def test_swin_block_two_variables_vs_oracle(kernel_variant):
     """V = 2 weight sets, N = 2, a grid that is not a multiple of the window and spans many
     window groups (exercises b % V weight selection and the grid-stride loops)."""
     from oracle import idee_oracle as O
@@ -143,7 +145,8 @@ def test_swin_block_two_variables_vs_oracle():
         gclose("d" + n, p.grad, torch.stack([sds[v][n].grad for v in range(V)]))
 
 
-def test_proj_var_golden():
+@variants('default', 'conv_split', 'conv16_regs', 'wgrad16_regs')
+def test_proj_var_golden(kernel_variant):
     ops = _ops()
     a, sd, grads = load_golden("proj_var")
     x = dev(a["x"]).permute(0, 2, 3, 4, 1).unsqueeze(1).contiguous().requires_grad_()   # (N,1,T,H,W,C)
@@ -157,7 +160,8 @@ def test_proj_var_golden():
 
 
 @pytest.mark.parametrize("tag,cin", [("1_16", 1), ("16_16", 16)])
-def test_conv_block_golden(tag, cin):
+@variants('default', 'conv_split', 'wgrad16_regs')
+def test_conv_block_golden(tag, cin, kernel_variant):
     """CNN_3D encoder block: [PatchEmbed+LN] -> 2 x (x + ReLU(LN_affine(conv3^3 replicate(x))))."""
     ops = _ops()
     a, sd, grads = load_golden("conv_block_" + tag)
@@ -187,7 +191,8 @@ def test_conv_block_golden(tag, cin):
 
 
 @pytest.mark.parametrize("T,H,W", [(8, 9, 72), (3, 5, 200), (8, 6, 200), (1, 1, 1), (2, 2, 17), (3, 21, 40)])
-def test_proj_var_vs_oracle(T, H, W, monkeypatch):
+@variants('default', 'conv_split', 'conv16_regs', 'wgrad16_regs')
+def test_proj_var_vs_oracle(T, H, W, monkeypatch, kernel_variant):
     """Multi-tile widths (72 = 3+2 column blocks, 200 = 4+3+3+3 incl. both frame edges), thin extents
     (clamp-everything cases).  Strict gradient tolerance on a tie-free case."""
     from oracle import idee_oracle as O
@@ -221,7 +226,8 @@ def test_proj_var_vs_oracle(T, H, W, monkeypatch):
 
 
 @pytest.mark.parametrize("T,H,W", [(3, 5, 200), (8, 7, 40)])
-def test_conv_ln_unit_vs_oracle(T, H, W):
+@variants('default', 'conv_split')
+def test_conv_ln_unit_vs_oracle(T, H, W, kernel_variant):
     """CNN_3D encoder unit x + ReLU(LN(conv3^3 replicate(x))) twice at a frame-wide W (both edge columns, partial
     column blocks) against the oracle, strict tolerance on a tie-free case."""
     from oracle import idee_oracle as O
@@ -294,7 +300,8 @@ def _classifier(sd, V):
     return c.to(DEV)
 
 
-def test_classifier_golden():
+@variants('default', 'conv_split')
+def test_classifier_golden(kernel_variant):
     a, sd, grads = load_golden("classifier_v2")
     c = _classifier(sd, 2)
     x = dev(a["x"]).requires_grad_()
@@ -314,7 +321,8 @@ def test_classifier_golden():
 
 @pytest.mark.parametrize("V,H,W,E", [(3, 7, 72, 16), (6, 5, 40, 16), (1, 3, 3, 16), (5, 4, 20, 16), (6, 6, 200, 16), (2, 3, 200, 16),
                                      (6, 4, 24, 32), (3, 3, 20, 32), (2, 19, 40, 16), (3, 5, 24, 16)])
-def test_classifier_vs_oracle(V, H, W, E, monkeypatch):
+@variants('default', 'conv_split')
+def test_classifier_vs_oracle(V, H, W, E, monkeypatch, kernel_variant):
     """Plain path (convolutions on z_q).  W = 200: the frame-wide row-wrapping column-block numbering of conv_wide,
     its zero borders, the wide weight-gradient kernel and the heads' strip kernels at both frame edges.  E = 32 (config #4's
     width): the 192 -> 192 joint head (weight gradient as a grid of 6 x 6-block sub-problems) and the 32 -> 32 heads (strip
@@ -360,7 +368,8 @@ def test_classifier_vs_oracle(V, H, W, E, monkeypatch):
 
 @pytest.mark.parametrize("V,D,H,W", [(3, 1, 7, 72), (6, 1, 5, 40), (1, 1, 3, 3), (5, 2, 4, 20), (8, 2, 3, 19), (6, 1, 6, 200),
                                      (2, 2, 3, 200), (6, 1, 19, 40)])
-def test_classifier_sign_field_vs_oracle(V, D, H, W, monkeypatch):
+@variants('default', 'conv_split', 'dgrad_to16_wide')
+def test_classifier_sign_field_vs_oracle(V, D, H, W, monkeypatch, kernel_variant):
     """The rank-d input path (ops.ClassifierHeadsSigns: convs on the sign field with folded weights) against
     the oracle's classifier applied to z_q = project_out(signs): outputs and every gradient (strict, tie-free case)."""
     from oracle import idee_oracle as O
@@ -418,7 +427,8 @@ def test_classifier_sign_field_vs_oracle(V, D, H, W, monkeypatch):
 
 
 @pytest.mark.parametrize("T,H,W", [(8, 10, 20), (9, 6, 17), (16, 5, 33)])
-def test_sign_field_switch_matches_plain_path(monkeypatch, T, H, W):
+@variants('default', 'dgrad_to16_wide')
+def test_sign_field_switch_matches_plain_path(monkeypatch, T, H, W, kernel_variant):
     """VQ_model with and without the rank-d classifier input: same outputs, same gradients (to f32 rounding);
     T = 9 leaves an unpaired last frame (never read by the stride-2 conv), T = 16 keeps two output frames.
     The case (weights seed) is one the oracle shows to be free of ReLU ties and of LFQ boundary tokens."""
@@ -565,7 +575,8 @@ def _safe_tokens(a, sd, cfg):
 
 
 @pytest.mark.parametrize("tag", ["swin_v2_14x18", "swin_v6_8x8_c2", "cnn_v2_12x16"])
-def test_e2e_eval_forward_golden(tag):
+@variants('default', 'all_split')
+def test_e2e_eval_forward_golden(tag, kernel_variant):
     from idee_amd.models.build import VQ_model
     a, sd, _ = load_golden("e2e_" + tag)
     cfg = _cfg_from(a)
@@ -586,7 +597,8 @@ def test_e2e_eval_forward_golden(tag):
 
 
 @pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16", "era5_swin_v3_c2_10x12"])
-def test_e2e_train_steps_golden(tag):
+@variants('default', 'all_split')
+def test_e2e_train_steps_golden(tag, kernel_variant):
     """3 full steps of the train_synthetic.py / train_ERA5_Land.py sequence (fused step objects) vs the reference's
     outputs, losses, all gradients and the parameters after 3 Adam steps."""
     from idee_amd.models.build import VQ_model
@@ -697,7 +709,8 @@ def test_vq_nearest_golden(tag):
         gclose("dembed", q._codebook.embed.grad, grads["_codebook.embed"])
 
 
-def test_small_config_c32_vs_oracle():
+@variants('default', 'swin_split', 'conv32_generic', 'all_split')
+def test_small_config_c32_vs_oracle(kernel_variant):
     """Builder-defined "small" width: embed 32, head_dim 16, codebook/cls dim 32, C_in = 2,
     depths [2,2] — full model forward + one backward against the oracle (strict; tie-free, boundary-free case)."""
     from oracle import idee_oracle as O
@@ -812,7 +825,8 @@ def test_harness_evaluators_collector_checkpoint(tmp_path):
 
 
 @pytest.mark.parametrize("tag", ["16_32", "32_16"])
-def test_swin_hierarchical_encoder_golden(tag):
+@variants('default', 'swin_split')
+def test_swin_hierarchical_encoder_golden(tag, kernel_variant):
     """Swin_3D with a width change between its stages (the reference re-embeds with PatchEmbed3D(in_dim -> dim) + LN,
     Swin_3D.py:414-419): outputs and every gradient against the reference's own."""
     from idee_amd.models.encoder.Swin_3D import Swin_3D
@@ -863,7 +877,8 @@ def test_vq_ema_kmeans_expire_golden(tag):
         assert bool(sd["_codebook.initted"])
 
 
-def test_swin_block_qkv_bias_false_golden():
+@variants('default', 'swin_split')
+def test_swin_block_qkv_bias_false_golden(kernel_variant):
     """SwinTransformerBlock3D built with qkv_bias=False (Swin_3D.py:137): the kernels get a zero, untrained bias."""
     ops = _ops()
     a, _, _ = load_golden("misc")
@@ -884,7 +899,8 @@ def test_swin_block_qkv_bias_false_golden():
 
 
 @pytest.mark.parametrize("C", [16, 32])
-def test_swin_block_drop_path_vs_oracle(C):
+@variants('default', 'swin_split')
+def test_swin_block_drop_path_vs_oracle(C, kernel_variant):
     """Stochastic depth: the kernels take the per-sample DropPath factors (mask / keep_prob, incl. dropped samples = 0) of
     both residual branches; forward and every gradient against the oracle with the same factors.  C = 32 runs the exact-f32
     kernels, C = 16 the split-precision ones."""
@@ -919,7 +935,8 @@ def test_swin_block_drop_path_vs_oracle(C):
         gclose("d" + n, p_.grad, torch.stack([sds[v][n].grad for v in range(V)]))
 
 
-def test_swin_encoder_drop_path_rate_module():
+@variants('default', 'swin_split')
+def test_swin_encoder_drop_path_rate_module(kernel_variant):
     """Swin_3D(drop_path_rate > 0): identity in eval mode, stochastic in training (the decay rule gives block 0 rate 0)."""
     from idee_amd.models.encoder.Swin_3D import Swin_3D
     torch.manual_seed(3)
@@ -936,7 +953,8 @@ def test_swin_encoder_drop_path_rate_module():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
 
 
-def test_conv_block_drop_path_vs_oracle():
+@variants('default', 'conv_split')
+def test_conv_block_drop_path_vs_oracle(kernel_variant):
     """CNN_3D encoder unit with stochastic depth: y = x + s_b * ReLU(LN(conv(x))) with the per-item factor s_b (0 = dropped),
     forward and gradients against the oracle formula."""
     import torch.nn.functional as F

@@ -47,19 +47,46 @@ def test_two_ranks_product_step_equals_one_rank(kind, tmp_path):
     g2, g1 = two["grad"], one["grad"]
     tol = 2e-4 * float(g1.abs().max())
     assert float((g2 - g1).abs().max()) <= tol, f"flat gradient: max err {float((g2 - g1).abs().max()):.3e} > {tol:.3e}"
-    # Adam's first step moves every element by lr * g / (|g| + eps): an element whose gradient is at the eps = 1e-8 level is
-    # sensitive to rounding-level gradient differences; bound those few (<= 2 % of lr), everything else tight
+    # Parameters after Adam are compared where the comparison means something: on every element whose effective gradient
+    # (g + weight_decay * p) exceeds a stated noise floor, 1e-3 of the largest — there Adam's update lr * m_hat / (sqrt(v_hat) +
+    # eps) is insensitive to the rounding-level differences between a 2-shard and a 1-shard summation, and the replicas must
+    # agree tightly (1 % of one lr step after the first update, 2 % after the second).  Below the floor the update's SIGN is
+    # decided by rounding noise (|step| = lr whatever |g| is), so those elements only get the trivial bound of 2 lr.
+    lr, wd = one["lr"], one["weight_decay"]
+    geff = g1 + wd * one["p0"]
+    firm = geff.abs() > 1e-3 * float(geff.abs().max())
+    print(f"[dp {kind}] elements above the gradient noise floor: {int(firm.sum())}/{firm.numel()}")
+    assert float(firm.float().mean()) > 0.5
     d1 = (two["p1"] - one["p1"]).abs()
-    loose1 = d1 > 2e-6 + 1e-4 * one["p1"].abs()
-    assert float(d1.max()) <= 2e-5 and float(loose1.float().mean()) <= 1e-3, (float(d1.max()), float(loose1.float().mean()))
-    # second step: Adam divides by sqrt(v) ~ |g|, so an element whose gradient is at rounding-noise level moves by up to ~lr
-    # in a direction the noise decides; bound those (<= 2 lr over the two steps, <= 0.5 % of the elements), everything else tight
-    d = (two["p2"] - one["p2"]).abs()
-    loose = d > 5e-6 + 2e-4 * one["p2"].abs()
-    assert float(d.max()) <= 2.2e-3 and float(loose.float().mean()) <= 5e-3, (float(d.max()), float(loose.float().mean()))
-    for k in ("extreme", "var"):          # global class counts -> identical weighting; means over equal shards
-        assert two["parts"][k] == pytest.approx(one["parts"][k], rel=0.5) or kind == "era5"
-    assert two["total2"] == pytest.approx(two["total2"])
+    assert float(d1[firm].max()) <= 0.01 * lr, f"p1 on firm elements: {float(d1[firm].max()):.3e}"
+    assert float(d1.max()) <= 2.0 * lr + 1e-7
+    d2 = (two["p2"] - one["p2"]).abs()
+    assert float(d2[firm].max()) <= 0.02 * lr, f"p2 on firm elements: {float(d2[firm].max()):.3e}"
+    assert float(d2.max()) <= 4.0 * lr + 1e-7
+    # losses: the mean over ranks of the per-rank (rescaled) shares is the global-batch loss of the one-rank run
+    for k in one["parts"]:
+        assert two["parts"][k] == pytest.approx(one["parts"][k], rel=1e-4, abs=1e-6), (k, two["parts"][k], one["parts"][k])
+    assert two["total1"] == pytest.approx(one["total1"], rel=1e-4)
+    assert two["total2"] == pytest.approx(one["total2"], rel=1e-4)
+
+
+def test_two_ranks_vq_ema_kmeans_expiry_equals_one_rank(tmp_path):
+    """VQ(ema_update=True, kmeans_init=True, threshold_ema_dead_code=2) on two ranks (2 clips each) against one rank on the
+    4 clips: k-means seeds broadcast from rank 0, bins / sums / cluster sizes all-reduced, expiry replacements broadcast —
+    replicas identical after every step and equal to the one-rank codebook; code indices equal token for token.
+    Reference: models/codebook/VQ.py:164-202, 233-244, 528-539."""
+    two = _run_world("vq_ema", 2, str(tmp_path / "vq2.pt"))
+    one = _run_world("vq_ema", 1, str(tmp_path / "vq1.pt"))
+    assert two["world"] == 2 and one["world"] == 1
+    for step, (a, b) in enumerate(zip(two["steps"], one["steps"])):
+        assert a["replicas_equal"], f"step {step}: replicas differ"
+        assert torch.equal(a["idx"], b["idx"]), f"step {step}: code indices differ"
+        torch.testing.assert_close(a["zq0"], b["zq0"], atol=1e-6, rtol=1e-5)
+        for k in ("_codebook.embed", "_codebook.cluster_size", "_codebook.embed_avg"):
+            torch.testing.assert_close(a["sd"][k], b["sd"][k], atol=2e-5, rtol=1e-5, msg=lambda m: f"step {step} {k}: {m}")
+        assert bool(a["sd"]["_codebook.initted"])
+    # the scenario must actually exercise expiry: some code of the one-rank run was replaced (cluster size reset to 2)
+    assert any(float((s["sd"]["_codebook.cluster_size"] == 2.0).sum()) > 0 for s in one["steps"])
 
 
 def test_two_host_threads_step_concurrently_on_their_own_streams():
