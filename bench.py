@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_SUMMARY_BF16 = os.path.join(ROOT, "profiles", "r03_pmc_traffic_config4_bf16.json")
 
 CONFIGS = {
     # id: (encoder, H, W, T, C_in, per-GPU batch, model overrides, step kind, label)
@@ -59,6 +60,13 @@ def parse():
                     help="f32 (default): every GEMM-shaped kernel on the exact-f32 MFMA (the reference's arithmetic).  split: the "
                          "opt-in two-piece split-precision kernels, convolutions (IDEE_CONV_MATH=split) AND Swin linear layers "
                          "(IDEE_SWIN_MATH=split) — a separately labelled line, never the headline")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="activation storage between the fused units.  f32 (default): the reference's arithmetic.  bf16: BASELINE "
+                         "config #4's precision — bf16 tokens, bf16 MFMA GEMMs / convolutions with f32 accumulate, f32 LFQ, losses, "
+                         "master weights and optimizer (Swin_3D encoder)")
+    ap.add_argument("--codebook", default="LFQ", choices=["LFQ", "VQ"],
+                    help="LFQ: what the reference's build.py wires.  VQ: the nearest-neighbour codebook of models/codebook/VQ.py in its "
+                         "place (BASELINE config #4's '+ VQ codebook' variant line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-eval", action="store_true", help="skip the eval-mode forward timing (profiling runs: every launch then belongs to a train step)")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-entry-point / per-shape time table (stderr)")
@@ -154,6 +162,23 @@ def conv_flops(desc):
     return 2.0 * desc.B * To * desc.H * desc.W * taps * desc.Cin * desc.Cout
 
 
+def conv_bytes(desc):
+    """Algorithmic HBM bytes of one launch of any pass of the convolution (a fused unit reads its input once
+    and writes its output once): the input tensor + the output tensor (forward: x in, y out; data gradient: dy in, dx out;
+    weight gradient: x and dy in).  Weights, bias and the ReLU reference are not counted."""
+    es = 2 if desc.act_dtype == 1 else 4
+    To = (desc.T - 2) // 2 + 1 if desc.mode == 1 else desc.T
+    return float(desc.B * desc.T * desc.H * desc.W * desc.Cin * es + desc.B * To * desc.H * desc.W * desc.Cout * (4 if desc.Cout == 1 else es))
+
+
+def swin_bytes(geom, backward):
+    """Algorithmic HBM bytes of a Swin block launch: forward x in, y and the saved pre-MLP state out (3 token tensors in a train
+    step); backward x, saved state, dy in and dx out (4 token tensors; the dh hand-off between its two kernels is traffic, not
+    algorithm)."""
+    tok = float(geom.N * geom.V * geom.D * geom.H * geom.W * geom.C) * (2 if geom.act_dtype == 1 else 4)
+    return (4 if backward else 3) * tok
+
+
 def swin_flops(geom, backward):
     """Per token: qkv 6C^2 + attention 4*Nw*C + proj 2C^2 + MLP 16C^2; backward = 2x."""
     nw = geom.wd * geom.wh * geom.ww
@@ -166,23 +191,24 @@ def swin_flops(geom, backward):
 FAMILY_KERNELS = {
     "idee_swin_block_fwd": ("swin_fwd_",),
     "idee_swin_block_bwd": ("swin_mlp_bwd", "swin_attn_bwd"),
-    "idee_conv_fwd": ("conv16_lds_kernel<0", "conv16_lds_kernel<2", "conv16_glds_kernel<0", "conv16_split_kernel<0", "conv16_split_kernel<2",
+    "idee_conv_fwd": ("conv_bf16_kernel<0", "conv_bf16_kernel<2", "conv16_lds_kernel<0", "conv16_lds_kernel<2", "conv16_glds_kernel<0", "conv16_split_kernel<0", "conv16_split_kernel<2",
                       "conv_wide_kernel<0", "conv_wide_kernel<2", "conv_wide_split_kernel<2", "c1_fwd", "conv_kernel<0", "conv_kernel<2"),
-    "idee_conv_dgrad": ("conv16_lds_kernel<1", "conv16_lds_kernel<3", "conv16_glds_kernel<1", "conv16_split_kernel<1", "conv16_split_kernel<3",
+    "idee_conv_dgrad": ("conv_bf16_kernel<1", "conv_bf16_kernel<3", "conv16_lds_kernel<1", "conv16_lds_kernel<3", "conv16_glds_kernel<1", "conv16_split_kernel<1", "conv16_split_kernel<3",
                         "conv_wide_kernel<1", "conv_wide_kernel<3", "conv_wide_split_kernel<3", "c1_dgrad", "conv_kernel<1", "conv_kernel<3",
                         "init_w_edges"),
-    "idee_conv_wgrad": ("wgrad16_strip_kernel", "wgrad16_split_kernel", "wgrad_wide_lds_kernel", "c1_wgrad", "wgrad_kernel"),
+    "idee_conv_wgrad": ("wgrad_bf16_kernel", "wgrad16_strip_kernel", "wgrad16_split_kernel", "wgrad_wide_lds_kernel", "c1_wgrad", "wgrad_kernel"),
 }
 
 
-def pmc_traffic(family, launches_per_step, headline):
+def pmc_traffic(family, launches_per_step, headline, summary=None):
     """Average HBM bytes per launch of the family from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes of this same command, corrected as MI355X_MICROARCH.md prescribes; profiles/collect_pmc.py) — or None
     when the summary is absent, was taken at another workload, or lists no kernel of the family.  -> (bytes, source)."""
-    if not headline or not os.path.exists(PMC_SUMMARY) or family not in FAMILY_KERNELS:
+    summary = summary or PMC_SUMMARY
+    if not headline or not os.path.exists(summary) or family not in FAMILY_KERNELS:
         return None, None
     try:
-        doc = json.load(open(PMC_SUMMARY))
+        doc = json.load(open(summary))
         tot = 0.0
         for r in doc["kernels"]:
             if any(r["kernel"].startswith(p) for p in FAMILY_KERNELS[family]):
@@ -191,12 +217,19 @@ def pmc_traffic(family, launches_per_step, headline):
         return None, None
     if tot <= 0 or not launches_per_step:
         return None, None
-    return round(tot / launches_per_step), f"profiles/{os.path.basename(PMC_SUMMARY)} @ {doc.get('source_commit', '?')}"
+    return round(tot / launches_per_step), f"profiles/{os.path.basename(summary)} @ {doc.get('source_commit', '?')}"
 
 
-def math_label(math, cfg):
+def math_label(math, cfg, dtype="f32"):
     """What arithmetic the GEMM-shaped kernels of THIS run used (the library switches are pinned in main())."""
     swin = cfg.encoder == "Swin_3D"
+    if dtype == "bf16":
+        return dict(storage="bf16 tokens between the fused units (patch embedding -> Swin blocks -> 3^3 convs -> classifier) and their "
+                            "gradients; f32 parameters, parameter gradients, Adam moments, LFQ projection / code bits, logits, losses",
+                    conv="v_mfma_f32_16x16x32_bf16, f32 accumulate (weights rounded to bf16 once per step); the Cout = 1 logit convs "
+                         "are f32 streaming dot products on bf16 inputs",
+                    swin_gemm="linear layers, P.V and the token-reduction weight-gradient GEMMs on v_mfma_f32_16x16x32_bf16 with "
+                              "one-piece bf16 operands, f32 accumulate; LayerNorm, softmax, GELU and the attention scores in f32")
     if math == "f32":
         d = dict(conv="exact f32 MFMA (v_mfma_f32_16x16x4_f32)", everything_else="f32")
         if swin:
@@ -314,7 +347,7 @@ def main():
     batch = a.batch or batch
     if a.hw:
         H = W = a.hw
-    cfg = default_config(encoder=enc, in_channels=Cin, **over)
+    cfg = default_config(encoder=enc, in_channels=Cin, act_dtype=a.dtype, codebook_impl=a.codebook, **over)
     headline = (a.config == "2" and a.hw is None and batch == 4 and enc == "Swin_3D")
     torch.manual_seed(0)
     ts = (ERA5TrainStep if kind == "era5" else SyntheticTrainStep)(cfg, device=dev)
@@ -362,33 +395,44 @@ def main():
         name = "idee_conv_dgrad" if name == "idee_conv_dgrad_add" else name      # the same kernels, out = dgrad + addend
         for e0, e1, args in evs:
             ms = e0.elapsed_time(e1)
-            key, flops = name, 0.0
+            key, flops, nbytes = name, 0.0, 0.0
             if name.startswith("idee_conv_"):
                 d = ctypes.cast(args[0], ctypes.POINTER(_lib.ConvDesc)).contents
                 key = f"{name}[{('k333', 'k233', 'k133')[d.mode]} {d.Cin}->{d.Cout} B{d.B} T{d.T}]"
-                flops = conv_flops(d)
+                flops, nbytes = conv_flops(d), conv_bytes(d)
             elif name.startswith("idee_swin_block_"):
                 g = ctypes.cast(args[-2], ctypes.POINTER(_lib.SwinGeom)).contents
                 key = f"{name}[w{g.wd}{g.wh}{g.ww} s{g.sd}{g.sh}{g.sw} C{g.C}]"
-                flops = swin_flops(g, name.endswith("bwd"))
-            r = per.setdefault(key, [0.0, 0, 0.0])
-            r[0] += ms; r[1] += 1; r[2] = flops
-            f = fam.setdefault(name, [0.0, 0, 0.0])
-            f[0] += ms; f[1] += 1; f[2] += flops
+                flops, nbytes = swin_flops(g, name.endswith("bwd")), swin_bytes(g, name.endswith("bwd"))
+            r = per.setdefault(key, [0.0, 0, 0.0, 0.0])
+            r[0] += ms; r[1] += 1; r[2] = flops; r[3] = nbytes
+            f = fam.setdefault(name, [0.0, 0, 0.0, 0.0])
+            f[0] += ms; f[1] += 1; f[2] += flops; f[3] += nbytes
     rows = sorted(per.items(), key=lambda kv: -kv[1][0])
     if a.breakdown and rank == 0:
         tot = sum(v[0] for v in per.values())
-        sys.stderr.write(f"{'entry point':66s} {'ms/step':>9s} {'calls':>6s} {'avg ms':>8s} {'TFLOP/s':>8s}\n")
-        for k, (ms, n, fl) in rows:
-            sys.stderr.write(f"{k:66s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / (ms / n) / 1e9 if fl else 0:8.2f}\n")
+        sys.stderr.write(f"{'entry point':66s} {'ms/step':>9s} {'calls':>6s} {'avg ms':>8s} {'TFLOP/s':>8s} {'alg GB/s':>9s}\n")
+        for k, (ms, n, fl, by) in rows:
+            sys.stderr.write(f"{k:66s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / (ms / n) / 1e9 if fl else 0:8.2f} "
+                             f"{by / (ms / n) / 1e6 if by else 0:9.1f}\n")
         sys.stderr.write("-- families --\n")
-        for k, (ms, n, fl) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
-            sys.stderr.write(f"{k:66s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / ms / 1e9 if fl else 0:8.2f}\n")
+        for k, (ms, n, fl, by) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+            sys.stderr.write(f"{k:66s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / ms / 1e9 if fl else 0:8.2f} "
+                             f"{by / ms / 1e6 if by else 0:9.1f}\n")
         sys.stderr.write(f"sum of bracketed entry points {tot / a.steps:.3f} ms/step; wall {dt / a.steps * 1e3:.3f} ms/step\n")
     roof = None
     mfma_fams = sorted(((k, v) for k, v in fam.items() if v[2] > 0), key=lambda kv: -kv[1][0])
-    if mfma_fams:
-        k, (ms, n, fl) = mfma_fams[0]          # the entry point (all its shapes) with the largest total time in the timed region
+    if mfma_fams and a.dtype == "bf16":
+        # bf16 activations: 16 x the MFMA rate of the f32 path at half the bytes — the path is HBM-bound; the
+        # dominant family is priced in algorithmic bytes (conv_bytes / swin_bytes) per second against the HBM peak
+        k, (ms, n, fl, by) = mfma_fams[0]
+        traffic, src = pmc_traffic(k, n // a.steps, a.config == "4" and a.hw is None and a.batch is None, PMC_SUMMARY_BF16)
+        roof = dict(kernel=k + " (all launches of this entry point in the step)", bound="hbm", achieved=round(by / ms / 1e6, 1),
+                    peak=PEAK_HBM_GBS, unit="GB/s", frac=round(by / ms / 1e6 / PEAK_HBM_GBS, 4), traffic=traffic, traffic_source=src,
+                    avg_launch_ms=round(ms / n, 4), bytes_per_launch=by / n, flops_per_launch=fl / n, tflops=round(fl / ms / 1e9, 2),
+                    launches_per_step=n // a.steps, share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
+    elif mfma_fams:
+        k, (ms, n, fl, by) = mfma_fams[0]      # the entry point (all its shapes) with the largest total time in the timed region
         traffic, src = pmc_traffic(k, n // a.steps, headline)
         # what actually limits the family (profiles/r03_sq_counters.txt): the convolution kernels are paced by the f32 MFMA pipe
         # (MFMA-busy ~80 %); the fused Swin kernels by VALU issue (LayerNorm / softmax / GELU share the issue slots with the f32
@@ -419,9 +463,10 @@ def main():
     out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * batch * a.steps / dt, 3),
                unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
                ms_per_step_median=round(statistics.median(step_ms), 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f32" if a.math == "f32" else
-                     "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs",
-               math=math_label(a.math, cfg),
+               dtype=("bf16" if a.dtype == "bf16" else "f32" if a.math == "f32" else
+                      "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs"),
+               math=math_label(a.math, cfg, a.dtype),
+               codebook=a.codebook,
                data="synthetic",
                config=dict(workload=f"#{a.config}: {label}, V={cfg.in_channels_dynamic}, batch {batch}/GPU" +
                                     (f", grid overridden to {H}x{W}" if a.hw else ""), global_batch=world * batch,
@@ -430,7 +475,10 @@ def main():
     if world > 1:
         out["backend"] = torch.distributed.get_backend()
         out["ranks"] = ranks_report
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.codebook == "VQ":
+        out["cpu_baseline"] = dict(value=None, unit="samples/s", cores=host_cores(), kind="port",
+                                   sample="not timed: the oracle's model forward wires LFQ as the reference's build.py does; see the LFQ line")
+    elif world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, kind, ts.model, T, H, W)
         except Exception as e:  # noqa: BLE001  (the GPU measurement above must still be reported)

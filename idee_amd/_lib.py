@@ -20,7 +20,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 class SwinGeom(C.Structure):
     _fields_ = [(n, _I) for n in ("N", "V", "D", "H", "W", "C", "heads", "hidden", "wd", "wh", "ww", "sd", "sh", "sw")] + [
-        ("scale", _F)]
+        ("scale", _F), ("act_dtype", _I)]
 
 
 _SWIN_PTRS = ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "rel_bias")
@@ -37,7 +37,19 @@ class SwinGrads(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = ([("mode", _I), ("B", _I), ("wsets", _I), ("T", _I), ("H", _I), ("W", _I), ("Cin", _I), ("Cout", _I)]
                 + [(n, _L) for n in ("x_sB", "x_sT", "x_sH", "x_sW", "x_sG", "y_sB", "y_sT", "y_sH", "y_sW", "y_sG")]
-                + [("relu", _I), ("x_gpu", _I), ("y_gpu", _I), ("x_sU", _L), ("y_sU", _L)])
+                + [("relu", _I), ("x_gpu", _I), ("y_gpu", _I), ("x_sU", _L), ("y_sU", _L), ("act_dtype", _I)])
+
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+
+def act_dtype(t):
+    """IDEE_DTYPE_* of an activation tensor (f32 or bf16 storage)."""
+    if t.dtype == torch.bfloat16:
+        return DTYPE_BF16
+    if t.dtype == torch.float32:
+        return DTYPE_F32
+    raise IdeeHipError(f"activation tensors must be float32 or bfloat16, got {t.dtype}")
 
 
 CONV_K333_REPLICATE, CONV_K233_S2_ZERO, CONV_K133_ZERO = 0, 1, 2
@@ -47,8 +59,8 @@ _SIGS = {
     "idee_version": (C.c_char_p, []),
     "idee_last_error": (C.c_char_p, []),
     "idee_check_device": (_I, [_I]),
-    "idee_patch_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
-    "idee_patch_embed_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "idee_patch_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P]),
+    "idee_patch_embed_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P]),
     "idee_stage_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
     "idee_stage_embed_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
     "idee_swin_block_fwd": (_I, [_P, _P, _P, C.POINTER(SwinParams), C.POINTER(SwinGeom), _P]),
@@ -65,14 +77,14 @@ _SIGS = {
     "idee_conv_unpack_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P]),
     "idee_ln_relu_res_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
     "idee_ln_relu_res_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
-    "idee_dropout_mask_": (_I, [_P, _L, _F, C.c_uint64, _P]),
+    "idee_dropout_mask_": (_I, [_P, _L, _F, C.c_uint64, _I, _P]),
     "idee_lfq_workspace_floats": (_L, [_L, _I]),
-    "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P]),
-    "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _P]),
+    "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _I, _P]),
+    "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _I, _P]),
     "idee_patch_merging_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "idee_patch_merging_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "idee_lfq_sign_field_fwd": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _P]),
-    "idee_lfq_sign_field_bwd": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _P]),
+    "idee_lfq_sign_field_fwd": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _I, _P]),
+    "idee_lfq_sign_field_bwd": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _I, _P]),
     "idee_lfq_fold_weights_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "idee_lfq_fold_weights_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "idee_vq_workspace_floats": (_L, [_L]),
@@ -139,7 +151,7 @@ def check(rc: int, what: str):
 
 
 def ptr(t):
-    """Device pointer of a contiguous f32/int64 CUDA tensor (None -> NULL)."""
+    """Device pointer of a contiguous f32/bf16/int64 CUDA tensor (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:

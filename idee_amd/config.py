@@ -59,13 +59,18 @@ def read_arguments(train=True, print=True, save=True, argv=None):
     return config
 
 
+# attributes models/build.py reads with getattr() that are NOT flags of the reference's config.py (its flag surface stays equal
+# to the reference's): act_dtype "f32" | "bf16" (activation storage), codebook_impl "LFQ" | "VQ" (BASELINE config #4's variants)
+EXTENSION_FIELDS = ("act_dtype", "codebook_impl")
+
+
 def default_config(**overrides):
     """Defaults of the flag table with overrides; `encoder` defaults to the reference's 'Mamba',
     which this build rejects — pass encoder='Swin_3D' or 'CNN_3D' (and in_channels=1 for
     synthetic data), as every reference run must too."""
     config = add_all_arguments(argparse.ArgumentParser()).parse_args([])
     for k, v in overrides.items():
-        if not hasattr(config, k):
+        if not hasattr(config, k) and k not in EXTENSION_FIELDS:
             raise AttributeError(f"unknown config field {k}")
         setattr(config, k, v)
     return config

@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.environ.get("IDEE_BUILD_OUT") or os.path.join(PKG, "libidee_hip.so")
-SRCS = ["api.cpp", "swin_mfma.hip", "conv_mfma.hip", "pointwise.hip"]
-DEPS = ["common.h", os.path.join("..", "..", "include", "idee_hip.h")]
+SRCS = ["api.cpp", "swin_mfma.hip", "conv_mfma.hip", "conv_bf16.hip", "pointwise.hip"]
+DEPS = ["common.h", "conv_common.h", os.path.join("..", "..", "include", "idee_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
 

@@ -68,9 +68,14 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 //       absolute floor of 2^-25 below; used by the FORWARD kernel, whose operands (LayerNorm outputs, weights, softmax,
 //       GELU) are O(1) by construction.
 // An operand fragment is 4 registers = 8 pieces; fragments travel as u32x4 and are bit-cast at the MFMA.
-template <bool F16>
+// Piece mode PM of the split kernels (the former `bool F16` slot: false -> 0, true -> 1 keep their meaning):
+//   PM_BF16X2 = 0  two bf16 pieces     PM_F16X2 = 1  two f16 pieces     PM_BF16X1 = 2  ONE bf16 piece (plain bf16 GEMM operands:
+//   the bf16 activation path, act_dtype == IDEE_DTYPE_BF16; the lo piece does not exist and its MFMAs / LDS traffic are
+//   compiled out)
+enum { PM_BF16X2 = 0, PM_F16X2 = 1, PM_BF16X1 = 2 };
+template <int F16>
 __device__ __forceinline__ f32x4 mfma_s(u32x4 a, u32x4 b, f32x4 c) {
-  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  if (F16 == PM_F16X2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: low half = a, high half = b
@@ -79,11 +84,38 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_p
 __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {    // v_cvt_pk_f16_f32 (RNE)
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, h16x2));
 }
+// ---- bf16 ACTIVATION STORAGE (idee_*_geom / idee_conv_desc .act_dtype == IDEE_DTYPE_BF16): tokens travel between the fused
+// units as bf16, every kernel converts on load, accumulates in f32 and rounds to nearest-even on store ----
+typedef __bf16 bf16_t;
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+// 4 consecutive channels of one token
+template <typename T> __device__ __forceinline__ f32x4 ldx4(const T* p);
+template <> __device__ __forceinline__ f32x4 ldx4<float>(const float* p) { return ld4(p); }
+template <> __device__ __forceinline__ f32x4 ldx4<bf16_t>(const bf16_t* p) {
+  const u32x2s v = *reinterpret_cast<const u32x2s*>(p);
+  return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+               __uint_as_float(v[1] & 0xffff0000u)};
+}
+template <typename T> __device__ __forceinline__ void stx4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void stx4<float>(float* p, f32x4 v) { st4(p, v); }
+template <> __device__ __forceinline__ void stx4<bf16_t>(bf16_t* p, f32x4 v) {
+  *reinterpret_cast<u32x2s*>(p) = u32x2s{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+}
+template <typename T> __device__ __forceinline__ float ldx1(const T* p);
+template <> __device__ __forceinline__ float ldx1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldx1<bf16_t>(const bf16_t* p) {
+  return __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short*>(p)) << 16);
+}
+
 struct Split { unsigned h01, h23, l01, l23; };
-template <bool F16>
+template <int F16>
 __device__ __forceinline__ Split split2(f32x4 x) {
   Split p;
-  if (F16) {
+  if (F16 == PM_BF16X1) {
+    p.h01 = cvt_pk_bf16(x[0], x[1]);
+    p.h23 = cvt_pk_bf16(x[2], x[3]);
+    p.l01 = 0u; p.l23 = 0u;
+  } else if (F16 == PM_F16X2) {
     p.h01 = cvt_pk_f16(x[0], x[1]);
     p.h23 = cvt_pk_f16(x[2], x[3]);
     // residual x - float(hi), exact, one v_fma_mix_f32 per element (the f16 half is read in place: no conversion back)

@@ -1,0 +1,425 @@
+// Implicit-GEMM 3-D convolutions on bf16 tensors with v_mfma_f32_16x16x32_bf16 (f32 accumulate) for gfx950 — the
+// convolutions of the bf16 activation path (idee_conv_desc.act_dtype == IDEE_DTYPE_BF16; BASELINE config #4:
+// "bf16 activations/GEMMs with fp32 accumulate").  Same modes, layouts and epilogues as conv_mfma.hip:
+//   K333_REPLICATE (proj_var, Swin_3D.py:586-592), K233_S2_ZERO / K133_ZERO (classifier, classifier/CNN_3D.py:38-40,83-85),
+// forward, data gradient, weight gradient; x / y / dy / dx / relu_ref / addend are bf16, bias and the weight-gradient
+// accumulators f32, weights packed once per step as bf16 fragments.
+//
+// K of one MFMA = 32 = TWO "k-items" of 16 input channels each ((tap, channel block) pairs): lane (i = lane & 15,
+// g = lane >> 4) supplies k-slots 8g..8g+7, i.e. 8 consecutive channels 8(g & 1).. of item (g >> 1) — one 16-byte load of
+// its pixel for the B operand (activations) and one 16-byte load of its output-channel row for the A operand (weights).
+// D^T orientation as everywhere in this library: rows = output channels, columns = pixels, so a lane ends with 4
+// consecutive channels of one pixel = one 8-byte bf16 store.
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+using namespace idee;
+using namespace idee_conv;
+
+typedef const bf16_t* bfp;
+
+__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 ld16(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: reference layout (wsets, Cout, Cin, taps) f32 -> item-major bf16 blocks
+//   fwd   P[wset][tap][cin block][cout block][i = cout % 16][k = cin % 16]
+//   dgrad P[wset][tap][cout block][cin block][i = cin % 16][k = cout % 16]
+// (256 elements per (tap, K block, N block); the same element count as the f32 fragment buffers)
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ pf, bf16_t* __restrict__ pd, int wsets,
+                                 int Cout, int Cin, int ntaps) {
+  const int Gi = Cin / 16, Go = (Cout + 15) / 16;
+  const long total = (long)wsets * ntaps * Gi * Go * 256;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e & 15), i = (int)((e >> 4) & 15);
+    long r = e >> 8;
+    const int ws = (int)(r / ((long)ntaps * Gi * Go));
+    r %= (long)ntaps * Gi * Go;
+    const int tap = (int)(r / (Gi * Go));
+    const int rem = (int)(r % (Gi * Go));
+    if (pf) {
+      const int gin = rem / Go, gout = rem % Go;
+      const int co = gout * 16 + i, ci = gin * 16 + k;
+      pf[e] = (bf16_t)(co < Cout ? w[(((long)ws * Cout + co) * Cin + ci) * ntaps + tap] : 0.f);
+    }
+    if (pd) {
+      const int gk = rem / Gi, gn = rem % Gi;
+      const int co = gk * 16 + k, ci = gn * 16 + i;
+      pd[e] = (bf16_t)(co < Cout ? w[(((long)ws * Cout + co) * Cin + ci) * ntaps + tap] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / data gradient.  Every WAVE owns an output tile of 64 pixels of one row (4 MFMA column blocks) x NT output
+// channel blocks and walks the (T tap, H tap) combinations that exist for its row; inside a combination the k-items
+// (W tap, channel block) are consumed two per MFMA.  Operands come straight from global memory (the activations' 3 x 3 x 3
+// re-use is served by L1 / L2; the bf16 MFMA is so much faster than the f32 one that these kernels are load-issue and
+// address-arithmetic bound, not MFMA bound).  No LDS, no barriers, no atomics:
+//   * replicate padding (FWD_REP) is a clamp of the source coordinates;
+//   * its data gradient (DGRAD_REP) folds the out-of-frame taps back onto the border: in T and H by the (source row, tap)
+//     pair lists of slot_t / slot_h, in W by two extra k-item kinds that exist only in tiles touching a frame edge —
+//     dx[0] += w[.,.,0] dy[0] and dx[W-1] += w[.,.,2] dy[W-1] (the output pixel that the clamp sends a second time to the
+//     border column) — so no padded frame and no float atomics are needed.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int NT>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a) {
+  constexpr int MT = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g4 = lane >> 4, hlf = g4 >> 1, ko = 8 * (g4 & 1);
+  const int b = blockIdx.y, ntg = blockIdx.z;
+  const int wset = b % a.wsets;
+  bfp in = reinterpret_cast<bfp>(a.in);
+  bfp wp = reinterpret_cast<bfp>(a.wp) + (long)wset * a.ntaps * a.Gk * a.GnTot * 256 + (long)ntg * NT * 256 + j * 16 + ko;
+  bfp ref = reinterpret_cast<bfp>(a.relu_ref);
+  bfp addend = reinterpret_cast<bfp>(a.addend);
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+  const int Gk = a.Gk;
+  const long wtiles = (a.Wo + 63) / 64;
+  const long tiles = (long)a.To * a.Ho * wtiles;
+
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+    const int wt = (int)(tile % wtiles);
+    const long r = tile / wtiles;
+    const int h = (int)(r % a.Ho), t = (int)(r / a.Ho);
+    const int w0 = wt * 64;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool edgeL = MODE == DGRAD_REP && w0 == 0, edgeR = MODE == DGRAD_REP && w0 + 64 >= a.Wo;
+    const int nkind = 3 + (edgeL ? 1 : 0) + (edgeR ? 1 : 0);
+    const int nitems = nkind * Gk, npairs = (nitems + 1) >> 1;
+    bfp in_b = in + (long)b * a.i_sB;
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot) {
+      const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
+      if (!st.ok) continue;
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const Slot sh = slot_h<MODE>(oh, h, a.Hi);
+        if (!sh.ok) continue;
+        bfp rowp = in_b + (long)st.src * a.i_sT + (long)sh.src * a.i_sH + ko;
+        const int tapbase = (st.tap * 3 + sh.tap) * 3;
+        for (int q = 0; q < npairs; ++q) {
+          // this lane's k-item of the pair
+          const int e = 2 * q + hlf;
+          const bool item_ok = e < nitems;
+          const int ki = (e >= Gk) + (e >= 2 * Gk) + (e >= 3 * Gk) + (e >= 4 * Gk);      // item kind index (e / Gk)
+          const int cb = e - ki * Gk;                                                    // channel block of `in`
+          const int kind = ki < 3 ? ki : (ki == 3 && edgeL ? 3 : 4);                     // 3: left fold, 4: right fold
+          const int ow = kind < 3 ? kind : (kind == 3 ? 0 : 2);                          // W tap whose weights apply
+          u32x4 A[NT];
+          {
+            bfp wq = wp + ((long)(tapbase + ow) * Gk + cb) * a.GnTot * 256;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) A[n] = item_ok ? ld16(wq + n * 256) : u32x4{0u, 0u, 0u, 0u};
+          }
+          bfp colp = rowp + goff(cb, a.i_gpu, a.i_sU, a.i_sG);
+          u32x4 Bv[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int p = w0 + 16 * m + j;
+            int qs;
+            bool ok;
+            if (MODE == FWD_REP) { qs = min(max(p + ow - 1, 0), a.Wi - 1); ok = true; }
+            else if (MODE == DGRAD_REP) {
+              if (kind < 3) { qs = p - (ow - 1); ok = qs >= 0 && qs < a.Wi; }
+              else { qs = p; ok = kind == 3 ? p == 0 : p == a.Wi - 1; }
+            } else if (MODE == FWD_S2) { qs = p + ow - 1; ok = qs >= 0 && qs < a.Wi; }
+            else { qs = p - (ow - 1); ok = qs >= 0 && qs < a.Wi; }
+            ok = ok && item_ok && p < a.Wo;
+            Bv[m] = ok ? ld16(colp + (long)qs * a.i_sW) : u32x4{0u, 0u, 0u, 0u};
+          }
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf(A[n], Bv[m], acc[m][n]);
+        }
+      }
+    }
+    // ---- epilogue: lane holds channels 4 g4 .. 4 g4 + 3 of block n for pixel column j ----
+    const long row_o = (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int p = w0 + 16 * m + j;
+      if (p >= a.Wo) continue;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int cg = ntg * NT + n;
+        f32x4 v = acc[m][n];
+        if (a.bias) v += ld4(a.bias + (long)wset * a.GnTot * 16 + cg * 16 + 4 * g4);
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const long o = row_o + (long)p * a.o_sW + goff(cg, a.o_gpu, a.o_sU, a.o_sG) + 4 * g4;
+        if (ref) {
+          const f32x4 rr = ldx4<bf16_t>(ref + o);
+          v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+          v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+        }
+        if (addend) v += ldx4<bf16_t>(addend + o);
+        stx4<bf16_t>(out + o, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: dWp[wset][tap][cin][coutPad] += sum_pixels x[src(pixel, tap)][cin] dy[pixel][cout], K = pixels, 32 per
+// MFMA.  The structure of wgrad16_split_kernel (conv_mfma.hip): every WAVE owns a strip of 32 pixels of one
+// (input block ga, output block group) pair and walks a run of rows of one (batch item, t), with a wave-private LDS ring of
+// 3 source rows x TSL T-slots staged pixel-major [pixel][16 channels bf16]; the K = pixels operand of x comes out of the
+// transposing LDS read (ds_read_b64_tr_b16: lane (channel i, group g) receives pixels 8g..8g+7 of channel i, shifted by the
+// W tap); dy is read from global memory, one bf16 per (pixel, channel).  All TSL * 9 * NB accumulator tiles stay in registers
+// for the wave's whole share and are flushed once with float atomics.  Any Cin, Cout multiples of 16 (blockIdx.z = pair).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowPx = 34;                 // staged pixels per row: 32 + halo
+constexpr int kRowW = kRowPx * 8;          // 32-bit words per staged row (16 bf16 channels per pixel)
+
+template <int MODE /*FWD_REP | FWD_S2*/, int TSL, int NB>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
+  constexpr int NTAPS = TSL * 9;
+  static_assert(NTAPS * NB <= 36, "accumulator tiles must fit the register file");
+  __shared__ __attribute__((aligned(16))) unsigned s_xw[4][TSL * 3 * kRowW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  unsigned* s_x = s_xw[wave];
+  const int ngb = (a.CoutPad / 16) / NB;
+  const int ga = blockIdx.z / ngb;
+  const int gb0 = (blockIdx.z % ngb) * NB;
+  bfp x = reinterpret_cast<bfp>(a.x);
+  bfp dy = reinterpret_cast<bfp>(a.dy);
+  f32x4 acc[NTAPS][NB];
+  float bsum[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    bsum[n] = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < NTAPS; ++tp) acc[tp][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nsub = (a.W + 15) / 16;
+  const int nb = a.B / a.wsets;
+  const long nunits = (long)nb * a.To * nhrun * nstrip;
+  // transposed-read address of this lane inside a staged row, pixel shift 0: lane 4q + c of group g supplies pixel
+  // 8g + q (+ 4 for the second read), channels 4c .. 4c + 3
+  const int tr_off = (8 * kq + (r16 >> 2)) * 8 + 2 * (r16 & 3);
+  auto tr = [&](const unsigned* p) __attribute__((always_inline)) {
+    const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(unsigned long long, t);
+  };
+
+  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+    long r = un;      // t fastest: the users of a source row run together
+    const int t = (int)(r % a.To); r /= a.To;
+    const int sp = (int)(r % nstrip); r /= nstrip;
+    const int hr = (int)(r % nhrun);
+    const int b = (int)(r / nhrun) * a.wsets + wset;
+    const int my_sub = min(2, nsub - sp * 2);
+    const int p0 = sp * 32;
+    const int rowlen = my_sub * 16 + 2;
+    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;
+    bfp x_b = x + (long)b * a.x_sB + goff(ga, a.x_gpu, a.x_sU, a.x_sG);
+    bfp dy_b = dy + (long)b * a.y_sB + (long)t * a.y_sT;
+    int tsrc[TSL];
+#pragma unroll
+    for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : a.kt * t + ot;
+
+    for (int h = h0; h < h1; ++h) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // dy of this row: lane (cout = r16, pixels p0 + 8 kq + {0..7}); pixels past the row end contribute zero
+      u32x4 Bv[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        unsigned short hv[8];
+        const int co = (gb0 + n) * 16 + r16;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int p = p0 + 8 * kq + jj;
+          const bool on = 8 * kq + jj < 16 * my_sub && p < a.W && co < a.cout_real;
+          hv[jj] = on ? *reinterpret_cast<const unsigned short*>(dy_b + (long)h * a.y_sH + (long)p * a.y_sW +
+                                                                 goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16)
+                      : (unsigned short)0;
+          bsum[n] += __uint_as_float((unsigned)hv[jj] << 16);
+        }
+        Bv[n] = u32x4{(unsigned)hv[0] | ((unsigned)hv[1] << 16), (unsigned)hv[2] | ((unsigned)hv[3] << 16),
+                      (unsigned)hv[4] | ((unsigned)hv[5] << 16), (unsigned)hv[6] | ((unsigned)hv[7] << 16)};
+      }
+      int slot_of[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const int hs = MODE == FWD_REP ? min(max(h + oh - 1, 0), a.H - 1) : h + oh - 1;
+        const bool inside = hs >= 0 && hs < a.H;
+        const int slot = (hs + 3) % 3;
+        slot_of[oh] = slot;
+        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+        if (cur == hs + 1) continue;
+        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
+        u32x2s stg[TSL][3];
+#pragma unroll
+        for (int ot = 0; ot < TSL; ++ot) {
+          bfp src = x_b + (long)tsrc[ot] * a.x_sT + (long)hs * a.x_sH;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            u32x2s v = {0u, 0u};
+            if (u < rowlen * 4 && inside) {
+              const int w = p0 + (u >> 2) - 1;
+              if (MODE == FWD_REP) v = *reinterpret_cast<const u32x2s*>(src + (long)min(max(w, 0), a.W - 1) * a.x_sW + 4 * (u & 3));
+              else if (w >= 0 && w < a.W) v = *reinterpret_cast<const u32x2s*>(src + (long)w * a.x_sW + 4 * (u & 3));
+            }
+            stg[ot][k] = v;
+          }
+        }
+#pragma unroll
+        for (int ot = 0; ot < TSL; ++ot) {
+          unsigned* dst = s_x + (ot * 3 + slot) * kRowW;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int u = lane + 64 * k;
+            if (u < kRowPx * 4) *reinterpret_cast<u32x2s*>(dst + (u >> 2) * 8 + (u & 3) * 2) = stg[ot][k];   // past a one-block strip: zeros
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // acc[tap][cin][cout] += sum over the strip's 32 pixels of x[pixel + tap offset][cin] dy[pixel][cout]
+#pragma unroll
+      for (int ot = 0; ot < TSL; ++ot)
+#pragma unroll
+        for (int oh = 0; oh < 3; ++oh)
+#pragma unroll
+          for (int ow = 0; ow < 3; ++ow) {
+            const unsigned* ap = s_x + (ot * 3 + slot_of[oh]) * kRowW + ow * 8 + tr_off;
+            const unsigned long long a0 = tr(ap), a1 = tr(ap + 4 * 8);
+            const u32x4 Av = {(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)};
+            const int tp = (ot * 3 + oh) * 3 + ow;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[tp][n] = mfma_bf(Av, Bv[n], acc[tp][n]);
+          }
+    }
+  }
+  float* dw = a.dwp + ((long)wset * NTAPS * a.Cin + ga * 16) * a.CoutPad;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) atomicAdd(dw + ((long)tp * a.Cin + r0 + rr) * a.CoutPad + (gb0 + n) * 16 + col, acc[tp][n][rr]);
+  if (a.dbias && ga == 0) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      float v = bsum[n];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + (gb0 + n) * 16 + lane, v);
+    }
+  }
+}
+
+inline int pick_nt(int G) { return G % 6 == 0 ? 6 : G % 3 == 0 ? 3 : G % 2 == 0 ? 2 : 1; }
+
+template <int MODE>
+int launch_conv_bf16(ConvArgs& a, hipStream_t stream) {
+  const int NT = pick_nt(a.GnTot);
+  const int gz = a.GnTot / NT;
+  const long tiles = (long)a.To * a.Ho * ((a.Wo + 63) / 64);
+  long gx = ((long)kCUs * 8) / ((long)a.B * gz);        // ~8 workgroups per CU in total: every wave loops over its tiles
+  if (gx < 1) gx = 1;
+  if (gx > (tiles + 3) / 4) gx = (tiles + 3) / 4;
+  const dim3 grid((unsigned)gx, a.B, gz);
+#define LCB(NT_) hipLaunchKernelGGL((conv_bf16_kernel<MODE, NT_>), grid, dim3(256), 0, stream, a)
+  if (NT == 6) LCB(6); else if (NT == 3) LCB(3); else if (NT == 2) LCB(2); else LCB(1);
+#undef LCB
+  return IDEE_OK;
+}
+
+inline int out_T(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K233_S2_ZERO ? (d->T - 2) / 2 + 1 : d->T; }
+inline int n_taps(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REPLICATE ? 27 : d->mode == IDEE_CONV_K233_S2_ZERO ? 18 : 9; }
+inline int mode_kt(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K133_ZERO ? 1 : 2; }
+
+}  // namespace
+
+namespace idee_conv {
+
+int bf16_pack(const idee_conv_desc* d, const float* w, void* packed_fwd, void* packed_dgrad, hipStream_t stream) {
+  const long total = (long)d->wsets * n_taps(d) * (d->Cin / 16) * ((d->Cout + 15) / 16) * 256;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, stream, w, (bf16_t*)packed_fwd,
+                     (bf16_t*)packed_dgrad, d->wsets, d->Cout, d->Cin, n_taps(d));
+  return IDEE_OK;
+}
+
+int bf16_fwd(const idee_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y, hipStream_t stream) {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = (const float*)x; a.wp = (const float*)w_packed; a.bias = bias; a.out = (float*)y;
+  a.B = d->B; a.wsets = d->wsets;
+  a.Ti = d->T; a.Hi = d->H; a.Wi = d->W;
+  a.To = out_T(d); a.Ho = d->H; a.Wo = d->W;
+  a.Gk = d->Cin / 16; a.GnTot = d->Cout / 16; a.cout_real = d->Cout; a.relu = d->relu; a.ntaps = n_taps(d); a.kt = mode_kt(d);
+  a.i_sB = d->x_sB; a.i_sT = d->x_sT; a.i_sH = d->x_sH; a.i_sW = d->x_sW; a.i_sG = d->x_sG;
+  a.o_sB = d->y_sB; a.o_sT = d->y_sT; a.o_sH = d->y_sH; a.o_sW = d->y_sW; a.o_sG = d->y_sG;
+  a.i_sU = d->x_sU; a.i_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30); a.o_sU = d->y_sU; a.o_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30);
+  if (d->mode == IDEE_CONV_K333_REPLICATE) return launch_conv_bf16<FWD_REP>(a, stream);
+  return launch_conv_bf16<FWD_S2>(a, stream);
+}
+
+int bf16_dgrad(const idee_conv_desc* d, const void* dy, const void* w_packed_dgrad, const void* relu_ref, const void* addend,
+               void* dx, hipStream_t stream) {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = (const float*)dy; a.wp = (const float*)w_packed_dgrad; a.relu_ref = (const float*)relu_ref; a.out = (float*)dx;
+  a.addend = (const float*)addend;
+  a.B = d->B; a.wsets = d->wsets;
+  a.Ti = out_T(d); a.Hi = d->H; a.Wi = d->W;
+  a.To = d->T; a.Ho = d->H; a.Wo = d->W;
+  a.Gk = d->Cout / 16; a.GnTot = d->Cin / 16; a.cout_real = d->Cin; a.ntaps = n_taps(d); a.kt = mode_kt(d);
+  a.i_sB = d->y_sB; a.i_sT = d->y_sT; a.i_sH = d->y_sH; a.i_sW = d->y_sW; a.i_sG = d->y_sG;
+  a.o_sB = d->x_sB; a.o_sT = d->x_sT; a.o_sH = d->x_sH; a.o_sW = d->x_sW; a.o_sG = d->x_sG;
+  a.i_sU = d->y_sU; a.i_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30); a.o_sU = d->x_sU; a.o_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30);
+  if (d->mode == IDEE_CONV_K333_REPLICATE) return launch_conv_bf16<DGRAD_REP>(a, stream);
+  return launch_conv_bf16<DGRAD_S2>(a, stream);
+}
+
+int bf16_wgrad(const idee_conv_desc* d, const void* x, const void* dy, float* dw_packed, float* dbias, hipStream_t st) {
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const float*)x; a.dy = (const float*)dy; a.dwp = dw_packed; a.dbias = dbias;
+  a.B = d->B; a.wsets = d->wsets; a.T = d->T; a.H = d->H; a.W = d->W; a.To = out_T(d);
+  a.Cin = d->Cin; a.CoutPad = ((d->Cout + 15) / 16) * 16; a.cout_real = d->Cout; a.ntaps = n_taps(d); a.kt = mode_kt(d);
+  a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;
+  a.y_sB = d->y_sB; a.y_sT = d->y_sT; a.y_sH = d->y_sH; a.y_sW = d->y_sW; a.y_sG = d->y_sG;
+  a.x_sU = d->x_sU; a.x_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30); a.y_sU = d->y_sU; a.y_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30);
+  a.rows = a.To * d->H;
+  const int Ga = d->Cin / 16, Gb = a.CoutPad / 16;
+  const int nstrip = cdiv(cdiv(d->W, 16), 2);
+  const long btr = (long)(d->B / d->wsets) * a.To;
+  // rows per work unit: enough units to fill the chip twice over, runs of at least 8 rows
+  auto launch = [&](auto kern, int NB) {
+    const int gz = Ga * (Gb / NB);
+    int hrun = d->H;
+    while (hrun > 8 && btr * cdiv(d->H, hrun) * nstrip * d->wsets * gz < 2L * kCUs * 8) hrun = (hrun + 1) / 2;
+    const int nhrun = cdiv(d->H, hrun);
+    const long nunits = btr * nhrun * nstrip;
+    long gx = ((long)kCUs * 2) / ((long)d->wsets * gz);
+    if (gx < 1) gx = 1;
+    if (gx > (nunits + 3) / 4) gx = (nunits + 3) / 4;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, d->wsets, gz), dim3(256), 0, st, a, nstrip, hrun, nhrun);
+  };
+  if (d->mode == IDEE_CONV_K333_REPLICATE) launch(wgrad_bf16_kernel<FWD_REP, 3, 1>, 1);
+  else if (d->mode == IDEE_CONV_K233_S2_ZERO) launch(wgrad_bf16_kernel<FWD_S2, 2, 1>, 1);      // (NB = 2: 144 accumulator registers, spills)
+  else { if (Gb % 2 == 0) launch(wgrad_bf16_kernel<FWD_S2, 1, 2>, 2); else launch(wgrad_bf16_kernel<FWD_S2, 1, 1>, 1); }
+  return IDEE_OK;
+}
+
+}  // namespace idee_conv

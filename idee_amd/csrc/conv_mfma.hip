@@ -16,81 +16,12 @@
 // gradient uses the exact (q, tap) pair lists in T and H (tile-uniform) and a padded frame with
 // float atomics on the two edge columns in W.
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
 
 using namespace idee;
-
-enum { FWD_REP = 0, DGRAD_REP = 1, FWD_S2 = 2, DGRAD_S2 = 3 };
-
-struct ConvArgs {
-  const float* in;
-  const float* wp;        // packed fragments
-  const float* bias;      // fwd: (wsets, CoutPad) or null
-  const float* relu_ref;  // dgrad: multiply by (relu_ref > 0), same layout as out, or null
-  float* out;
-  int B, wsets;
-  int Ti, Hi, Wi;         // extent of `in`
-  int To, Ho, Wo;         // extent of `out`
-  int Gk;                 // K groups (16 channels each) of `in`
-  int GnTot;              // output channel groups in total
-  int cout_real;          // real output channels (1 => scalar store)
-  int relu;
-  const float* addend;    // out = result + addend (same layout as out; may BE out) or null
-  int ntaps;
-  int kt;                 // temporal taps of the (kt,3,3) zero-padded modes: 2 (stride 2 in T) or 1 (stride 1)
-  long i_sB, i_sT, i_sH, i_sW, i_sG, i_sU;
-  long o_sB, o_sT, o_sH, o_sW, o_sG, o_sU;
-  int i_gpu, o_gpu;                      // 16-channel groups per unit: group g lives at (g / gpu) * sU + (g % gpu) * sG
-  int nsub, wtiles, sub_base, sub_rem;   // 16-pixel column blocks per row and their split into wave tiles
-  int hgroups, tiles;                    // ceil(Ho/4); To*hgroups*wtiles
-  // 16 -> 16 sub-problems of a wider convolution run on the 16 -> 16 strip kernel (conv16_glds_kernel): where the (tap) fragments
-  // of the sub-block live in the packed buffer, and the epilogue order (0 everywhere = the plain 16 -> 16 layout)
-  int w_tap_stride;                      // floats between consecutive taps (default 256)
-  long w_set_stride;                     // floats between weight sets (default ntaps * 256)
-  int bias_set_stride;                   // floats between the bias vectors of weight sets (default 16)
-  int addend_first;                      // 1: out = relu(acc + addend + bias) (a partial sum), 0: relu(acc + bias) + addend
-};
-
-struct Slot { int src, tap; bool ok; };
-
-// offset of 16-channel group g: units of `gpu` groups (e.g. the V slices of z_q), sU apart; groups sG apart inside a unit
-__device__ __forceinline__ long goff(int g, int gpu, long sU, long sG) { return (long)(g / gpu) * sU + (long)(g % gpu) * sG; }
-
-template <int MODE>
-__device__ __forceinline__ Slot slot_t(int o, int t, int Ti, int kt) {
-  Slot s;
-  if (MODE == FWD_REP) { s.src = min(max(t + o - 1, 0), Ti - 1); s.tap = o; s.ok = true; }
-  else if (MODE == DGRAD_REP) {
-    const int q = t - (o - 1);
-    const bool in = q >= 0 && q < Ti;
-    s.src = min(max(q, 0), Ti - 1); s.tap = in ? o : 2 - o; s.ok = true;
-  } else if (MODE == FWD_S2) { s.src = kt * t + o; s.tap = o; s.ok = (o < kt) && (s.src < Ti); }
-  else { s.src = kt == 2 ? t >> 1 : t; s.tap = kt == 2 ? t & 1 : 0; s.ok = (o == 0) && (s.src < Ti); }
-  return s;
-}
-template <int MODE>
-__device__ __forceinline__ Slot slot_h(int o, int h, int Hi) {
-  Slot s;
-  if (MODE == FWD_REP) { s.src = min(max(h + o - 1, 0), Hi - 1); s.tap = o; s.ok = true; }
-  else if (MODE == DGRAD_REP) {
-    const int q = h - (o - 1);
-    const bool in = q >= 0 && q < Hi;
-    s.src = min(max(q, 0), Hi - 1); s.tap = in ? o : 2 - o; s.ok = true;
-  } else if (MODE == FWD_S2) { s.src = h + o - 1; s.tap = o; s.ok = s.src >= 0 && s.src < Hi; }
-  else { s.src = h - (o - 1); s.tap = o; s.ok = s.src >= 0 && s.src < Hi; }
-  return s;
-}
-// per-lane source column for output column index p (p counts the padded frame in DGRAD_REP)
-template <int MODE>
-__device__ __forceinline__ int src_w(int o, int p, int Wi, bool& ok) {
-  int q;
-  if (MODE == FWD_REP) { q = min(max(p + o - 1, 0), Wi - 1); ok = true; }
-  else if (MODE == DGRAD_REP) { q = (p - 1) - (o - 1); ok = q >= 0 && q < Wi; }
-  else if (MODE == FWD_S2) { q = p + o - 1; ok = q >= 0 && q < Wi; }
-  else { q = p - (o - 1); ok = q >= 0 && q < Wi; }
-  return q;
-}
+using namespace idee_conv;
 
 template <int MODE, int NT, bool WLDS, bool CIN1>
 __global__ __launch_bounds__(256, NT >= 6 ? 2 : 1) void conv_kernel(ConvArgs a) {
@@ -221,26 +152,6 @@ __global__ __launch_bounds__(256, NT >= 6 ? 2 : 1) void conv_kernel(ConvArgs a) 
 // One wave owns TPW taps x NTA input-channel blocks x NTB output-channel blocks and a share of
 // the (b, t, h) pixel rows; K runs over pixels, 4 per MFMA.
 // ---------------------------------------------------------------------------------------------
-struct WgradArgs {
-  const float* x;
-  const float* dy;
-  float* dwp;     // (wsets, ntaps, Cin, CoutPad)
-  float* dbias;   // (wsets, CoutPad) or null
-  int B, wsets;
-  int T, H, W;    // x extent
-  int To;         // dy extent in T (H, W equal)
-  int Cin, CoutPad, cout_real;
-  int ntaps;
-  int kt;         // temporal taps (= temporal stride) of the zero-padded modes: 2 or 1
-  long x_sB, x_sT, x_sH, x_sW, x_sG, x_sU;
-  long y_sB, y_sT, y_sH, y_sW, y_sG, y_sU;
-  int x_gpu, y_gpu;
-  int rows;       // To * H  (pixel rows per batch item)
-  int row_chunks; // gridDim.x
-  int tap_groups; // ntaps / TPW
-  int ga_groups;  // (Cin/16) / NTA
-};
-
 template <int MODE /*FWD_REP or FWD_S2*/, int TPW, int NTA, int NTB>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2201,13 +2112,13 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 // of a pixel own 4 channels each (16-byte accesses), weights read from the packed fragment buffers.
 // ---------------------------------------------------------------------------------------------
 struct C1Args {
-  const float* x;      // (B, 2, H, W, C) by strides
+  const void* x;       // (B, 2, H, W, C) by strides; XT = float | bf16_t (act_dtype)
   const float* w;      // packed fragments (fwd or dgrad order)
   const float* bias;   // (wsets) or null
   const float* dy;     // (B, H, W)
-  const float* relu_ref;
+  const void* relu_ref;   // XT, like x
   float* y;            // fwd: (B, H, W)
-  float* dx;           // dgrad: like x
+  void* dx;            // dgrad: like x (XT)
   float* dwp;          // wgrad: (wsets, 18, C, 16)
   float* dbias;        // (wsets, 16) or null
   int B, wsets, H, W, C;
@@ -2226,7 +2137,7 @@ __device__ __forceinline__ float c1_w_dgrad(const float* wp, int Gi, int tap, in
 }
 
 // LPP lanes per pixel (power of two >= C/4); lanes q >= C/4 idle
-template <int LPP>
+template <int LPP, typename XT>
 __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
   // LPP lanes (4 channels each) own FOUR consecutive output pixels of a row: per (kt, kh) they load the 6 source pixels
   // once (9 loads per output instead of 18) and keep f32x4 partial products, summed over channels only at the end
@@ -2254,19 +2165,19 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
 #pragma unroll
         for (int tap = 0; tap < 18; ++tap) wr[tap] = c1_w4_fwd(wp, Gi, tap, q);
       }
-      const float* xb = a.x + (long)(b / a.To) * a.x_sB + (long)(b % a.To) * 2 * a.x_sT + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
+      const XT* xb = reinterpret_cast<const XT*>(a.x) + (long)(b / a.To) * a.x_sB + (long)(b % a.To) * 2 * a.x_sT + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int oh = 0; oh < 3; ++oh) {
           const int hs = h + oh - 1;
           const bool rok = hs >= 0 && hs < a.H;
-          const float* row = xb + (long)kt * a.x_sT + (long)min(max(hs, 0), a.H - 1) * a.x_sH;
+          const XT* row = xb + (long)kt * a.x_sT + (long)min(max(hs, 0), a.H - 1) * a.x_sH;
           f32x4 xv[PXT + 2];
 #pragma unroll
           for (int i = 0; i < PXT + 2; ++i) {            // source pixels w0-1 .. w0+PXT: clamped address, zeroed outside the frame
             const int ws = w0 - 1 + i;
-            xv[i] = ld4(row + (long)min(max(ws, 0), a.W - 1) * a.x_sW);
+            xv[i] = ldx4<XT>(row + (long)min(max(ws, 0), a.W - 1) * a.x_sW);
             if (!(rok && ws >= 0 && ws < a.W)) xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
@@ -2288,7 +2199,7 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
   }
 }
 
-template <int LPP>
+template <int LPP, typename XT>
 __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
   const int QC = a.C / 4, Gi = a.C / 16;
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
@@ -2328,17 +2239,17 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
     }
     const long off = (long)b * a.x_sB + (long)(2 * to + kt) * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
     if (a.relu_ref) {
-      const f32x4 rr = ld4(a.relu_ref + off);
+      const f32x4 rr = ldx4<XT>(reinterpret_cast<const XT*>(a.relu_ref) + off);
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[u] = rr[u] > 0.f ? acc[u] : 0.f;
     }
-    if (a.accumulate) acc += ld4(a.dx + off);
-    st4(a.dx + off, acc);
+    if (a.accumulate) acc += ldx4<XT>(reinterpret_cast<const XT*>(a.dx) + off);
+    stx4<XT>(reinterpret_cast<XT*>(a.dx) + off, acc);
   }
 }
 
 // dW[tap][c] = sum_{b,h,w} x[b][kt][h+oh-1][w+ow-1][c] dy[b][h][w]: every x value is read once and spread over its 9 taps
-template <int LPP>
+template <int LPP, typename XT>
 __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
   __shared__ float s_red[256 / LPP][LPP][4];
   const int QC = a.C / 4;
@@ -2376,9 +2287,9 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
           const int h = hs - (oh - 1), w = ws - (ow - 1);      // output pixel this source feeds through tap (oh, ow)
           gq[r][oh * 3 + ow] = (on[r] && h >= 0 && h < a.H && w >= 0 && w < a.W) ? dyb[(long)h * a.W + w] : 0.f;
         }
-      const float* xb = a.x + (long)b * a.x_sB + (long)(2 * to) * a.x_sT + (long)hs * a.x_sH + (long)ws * a.x_sW + goff((on[r] ? q : 0) / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * ((on[r] ? q : 0) % 4);
+      const XT* xb = reinterpret_cast<const XT*>(a.x) + (long)b * a.x_sB + (long)(2 * to) * a.x_sT + (long)hs * a.x_sH + (long)ws * a.x_sW + goff((on[r] ? q : 0) / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * ((on[r] ? q : 0) % 4);
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) xq[r][kt] = ld4(xb + (long)kt * a.x_sT);
+      for (int kt = 0; kt < 2; ++kt) xq[r][kt] = ldx4<XT>(xb + (long)kt * a.x_sT);
     }
 #pragma unroll
     for (int r = 0; r < UN; ++r) {
@@ -2422,7 +2333,8 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
   }
 }
 
-int launch_c1(int which, C1Args& a, hipStream_t st) {
+template <typename XT>
+int launch_c1_t(int which, C1Args& a, hipStream_t st) {
   const int QC = a.C / 4;
   const int LPP = QC <= 4 ? 4 : QC <= 8 ? 8 : QC <= 16 ? 16 : QC <= 32 ? 32 : 64;
   if (QC > 64) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): Cin %d > 256 is not built", a.C);
@@ -2432,12 +2344,15 @@ int launch_c1(int which, C1Args& a, hipStream_t st) {
   const int per = which == 0 ? 1 : a.wsets;                       // dgrad / wgrad: one weight set per grid column
   const int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : 8), per));
   const dim3 grid(gx < 1 ? 1 : gx, per);
-#define C1(K) do { if (LPP == 4) hipLaunchKernelGGL((K<4>), grid, dim3(256), 0, st, a); else if (LPP == 8) hipLaunchKernelGGL((K<8>), grid, dim3(256), 0, st, a); \
-  else if (LPP == 16) hipLaunchKernelGGL((K<16>), grid, dim3(256), 0, st, a); else if (LPP == 32) hipLaunchKernelGGL((K<32>), grid, dim3(256), 0, st, a); \
-  else hipLaunchKernelGGL((K<64>), grid, dim3(256), 0, st, a); } while (0)
+#define C1(K) do { if (LPP == 4) hipLaunchKernelGGL((K<4, XT>), grid, dim3(256), 0, st, a); else if (LPP == 8) hipLaunchKernelGGL((K<8, XT>), grid, dim3(256), 0, st, a); \
+  else if (LPP == 16) hipLaunchKernelGGL((K<16, XT>), grid, dim3(256), 0, st, a); else if (LPP == 32) hipLaunchKernelGGL((K<32, XT>), grid, dim3(256), 0, st, a); \
+  else hipLaunchKernelGGL((K<64, XT>), grid, dim3(256), 0, st, a); } while (0)
   if (which == 0) C1(c1_fwd_kernel); else if (which == 1) C1(c1_dgrad_kernel); else C1(c1_wgrad_kernel);
 #undef C1
   return IDEE_OK;
+}
+int launch_c1(int which, C1Args& a, bool bf16, hipStream_t st) {
+  return bf16 ? launch_c1_t<bf16_t>(which, a, st) : launch_c1_t<float>(which, a, st);
 }
 // Cout = 1 (2,3,3) stride-2 convs: streaming kernels, any even frame count (T = 2: the reference's last classifier conv at T = 8;
 // T = 4: the same conv at T = 16), y / dy a contiguous (B, T / 2, H, W)
@@ -2461,6 +2376,13 @@ int check_desc(const idee_conv_desc* d) {
   IDEE_CHECK_ARG(d->Cin > 0 && d->Cin % 16 == 0, "conv: Cin %d must be a multiple of 16", d->Cin);
   IDEE_CHECK_ARG(d->Cout == 1 || (d->Cout > 0 && d->Cout % 16 == 0), "conv: Cout %d must be 1 or a multiple of 16", d->Cout);
   if (d->mode == IDEE_CONV_K233_S2_ZERO) IDEE_CHECK_ARG(d->T >= 2, "conv (2,3,3): T %d < kernel 2", d->T);
+  return IDEE_OK;
+}
+// act_dtype == IDEE_DTYPE_BF16 outside the streaming Cout == 1 case: what conv_bf16.hip is built for
+int check_bf16(const idee_conv_desc* d) {
+  IDEE_CHECK_ARG(d->Cout % 16 == 0, "conv (bf16): Cout %d must be a multiple of 16 (or the (2,3,3) Cout = 1 logit conv)", d->Cout);
+  IDEE_CHECK_ARG(d->x_sW % 8 == 0 && d->y_sW % 8 == 0 && d->x_sG % 8 == 0 && d->y_sG % 8 == 0 && d->x_sU % 8 == 0 && d->y_sU % 8 == 0,
+                 "conv (bf16): pixel / group strides must keep 16-byte alignment");
   return IDEE_OK;
 }
 inline int out_T(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K233_S2_ZERO ? (d->T - 2) / 2 + 1 : d->T; }
@@ -2679,10 +2601,17 @@ extern "C" long idee_conv_wgrad_floats(const idee_conv_desc* d) {
   return (long)d->wsets * n_taps(d) * d->Cin * (((d->Cout + 15) / 16) * 16);
 }
 
-extern "C" int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, float* packed_fwd, float* packed_dgrad,
+extern "C" int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, void* packed_fwd_, void* packed_dgrad_,
                                       idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
-  IDEE_CHECK_ARG(w && (packed_fwd || packed_dgrad), "conv_pack_weights: null argument");
+  IDEE_CHECK_ARG(w && (packed_fwd_ || packed_dgrad_), "conv_pack_weights: null argument");
+  if (d->act_dtype == IDEE_DTYPE_BF16 && d->Cout != 1) {      // (Cout == 1: the streaming kernels read the f32 fragments)
+    bf16_pack(d, w, packed_fwd_, packed_dgrad_, (hipStream_t)stream);
+    IDEE_LAUNCH_CHECK("conv_pack_weights");
+    return IDEE_OK;
+  }
+  float* packed_fwd = (float*)packed_fwd_;
+  float* packed_dgrad = (float*)packed_dgrad_;
   const long total = idee_conv_packed_floats(d);
   hipLaunchKernelGGL(pack_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, w, packed_fwd,
                      packed_dgrad, d->wsets, d->Cout, d->Cin, n_taps(d));
@@ -2700,14 +2629,22 @@ extern "C" int idee_conv_unpack_wgrad(const idee_conv_desc* d, const float* dw_p
   return IDEE_OK;
 }
 
-extern "C" int idee_conv_fwd(const idee_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+extern "C" int idee_conv_fwd(const idee_conv_desc* d, const void* x_, const void* w_packed_, const float* bias, void* y_,
                              idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
-  IDEE_CHECK_ARG(x && w_packed && y, "conv_fwd: null argument");
+  IDEE_CHECK_ARG(x_ && w_packed_ && y_, "conv_fwd: null argument");
+  const bool bf = d->act_dtype == IDEE_DTYPE_BF16;
+  const float* x = (const float*)x_; const float* w_packed = (const float*)w_packed_; float* y = (float*)y_;
   if (is_c1(d)) {
     C1Args c; fill_c1(c, d);
-    c.x = x; c.w = w_packed; c.bias = bias; c.y = y;
-    if (int rc = launch_c1(0, c, (hipStream_t)stream)) return rc;
+    c.x = x_; c.w = w_packed; c.bias = bias; c.y = y;
+    if (int rc = launch_c1(0, c, bf, (hipStream_t)stream)) return rc;
+    IDEE_LAUNCH_CHECK("conv_fwd");
+    return IDEE_OK;
+  }
+  if (bf) {
+    if (int rc = check_bf16(d)) return rc;
+    bf16_fwd(d, x_, w_packed_, bias, y_, (hipStream_t)stream);
     IDEE_LAUNCH_CHECK("conv_fwd");
     return IDEE_OK;
   }
@@ -2728,21 +2665,30 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const float* x, const floa
   return IDEE_OK;
 }
 
-extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
-                               float* dx, int accumulate, idee_stream_t stream) {
+extern "C" int idee_conv_dgrad(const idee_conv_desc* d, const void* dy, const void* w_packed_dgrad, const void* relu_ref,
+                               void* dx, int accumulate, idee_stream_t stream) {
   return idee_conv_dgrad_add(d, dy, w_packed_dgrad, relu_ref, accumulate ? dx : nullptr, dx, stream);
 }
 
-extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
-                                   const float* addend, float* dx, idee_stream_t stream) {
+extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const void* dy_, const void* w_packed_dgrad_, const void* relu_ref_,
+                                   const void* addend_, void* dx_, idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
-  IDEE_CHECK_ARG(dy && w_packed_dgrad && dx, "conv_dgrad: null argument");
-  if (is_c1(d) && d->T == 2) {      // (at T = 4 the padded MFMA path is faster for the data gradient: 0.35 vs 0.53 ms at config #4)
+  IDEE_CHECK_ARG(dy_ && w_packed_dgrad_ && dx_, "conv_dgrad: null argument");
+  const bool bf = d->act_dtype == IDEE_DTYPE_BF16;
+  const float* dy = (const float*)dy_; const float* w_packed_dgrad = (const float*)w_packed_dgrad_;
+  const float* relu_ref = (const float*)relu_ref_; const float* addend = (const float*)addend_; float* dx = (float*)dx_;
+  if (is_c1(d) && (d->T == 2 || bf)) {      // (f32, T = 4: the padded MFMA path is faster for the data gradient: 0.35 vs 0.53 ms at config #4)
     IDEE_CHECK_ARG(!addend || addend == dx, "conv_dgrad (Cout = 1): a separate addend is not built");
     const int accumulate = addend != nullptr;
     C1Args c; fill_c1(c, d);
-    c.dy = dy; c.w = w_packed_dgrad; c.relu_ref = relu_ref; c.dx = dx; c.accumulate = accumulate;
-    if (int rc = launch_c1(1, c, (hipStream_t)stream)) return rc;
+    c.dy = dy; c.w = w_packed_dgrad; c.relu_ref = relu_ref_; c.dx = dx_; c.accumulate = accumulate;
+    if (int rc = launch_c1(1, c, bf, (hipStream_t)stream)) return rc;
+    IDEE_LAUNCH_CHECK("conv_dgrad");
+    return IDEE_OK;
+  }
+  if (bf) {
+    if (int rc = check_bf16(d)) return rc;
+    bf16_dgrad(d, dy_, w_packed_dgrad_, relu_ref_, addend_, dx_, (hipStream_t)stream);
     IDEE_LAUNCH_CHECK("conv_dgrad");
     return IDEE_OK;
   }
@@ -2775,14 +2721,22 @@ extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const float* dy, con
   return IDEE_OK;
 }
 
-extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
+extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const void* dy_, float* dw_packed, float* dbias,
                                idee_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
-  IDEE_CHECK_ARG(x && dy && dw_packed, "conv_wgrad: null argument");
+  IDEE_CHECK_ARG(x_ && dy_ && dw_packed, "conv_wgrad: null argument");
+  const bool bf = d->act_dtype == IDEE_DTYPE_BF16;
+  const float* x = (const float*)x_; const float* dy = (const float*)dy_;
   if (is_c1(d)) {
     C1Args c; fill_c1(c, d);
-    c.x = x; c.dy = dy; c.dwp = dw_packed; c.dbias = dbias;
-    if (int rc = launch_c1(2, c, (hipStream_t)stream)) return rc;
+    c.x = x_; c.dy = dy; c.dwp = dw_packed; c.dbias = dbias;
+    if (int rc = launch_c1(2, c, bf, (hipStream_t)stream)) return rc;
+    IDEE_LAUNCH_CHECK("conv_wgrad");
+    return IDEE_OK;
+  }
+  if (bf) {
+    if (int rc = check_bf16(d)) return rc;
+    bf16_wgrad(d, x_, dy_, dw_packed, dbias, (hipStream_t)stream);
     IDEE_LAUNCH_CHECK("conv_wgrad");
     return IDEE_OK;
   }

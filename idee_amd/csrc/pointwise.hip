@@ -49,16 +49,16 @@ __device__ __forceinline__ float tok_sum(float v) {
   return v;
 }
 
-template <int E, int CIN>
+template <int E, int CIN, typename AT>
 __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              const float* __restrict__ bias, AT* __restrict__ y,
                                                               int V, long L) {
   // E/4 adjacent lanes per token, 4 channels each: the output is one contiguous stream of 16-byte pieces
   constexpr int QE = E / 4;
   const int b = blockIdx.y, v = b % V;
   const float* wv = w + (long)v * E * CIN;
   const float* xb = x + (long)b * CIN * L;
-  float* yb = y + (long)b * L * E;
+  AT* yb = y + (long)b * L * E;
   const int q = threadIdx.x % QE;
   float wl[4][CIN], bl[4];
 #pragma unroll
@@ -85,20 +85,20 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
     const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
-    st4(yb + tok * E + 4 * q, f32x4{(e[0] - mean) * rstd, (e[1] - mean) * rstd, (e[2] - mean) * rstd, (e[3] - mean) * rstd});
+    stx4<AT>(yb + tok * E + 4 * q, f32x4{(e[0] - mean) * rstd, (e[1] - mean) * rstd, (e[2] - mean) * rstd, (e[3] - mean) * rstd});
   }
 }
 
-template <int E, int CIN>
+template <int E, int CIN, typename AT>
 __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, const float* __restrict__ dy,
+                                                              const float* __restrict__ bias, const AT* __restrict__ dy,
                                                               float* __restrict__ dw, float* __restrict__ db, int V, long L) {
   // E/4 adjacent lanes per token, 4 channels each: dy is read as one contiguous stream of 16-byte pieces
   constexpr int QE = E / 4;
   const int b = blockIdx.y, v = b % V;
   const float* wv = w + (long)v * E * CIN;
   const float* xb = x + (long)b * CIN * L;
-  const float* dyb = dy + (long)b * L * E;
+  const AT* dyb = dy + (long)b * L * E;
   const int q = threadIdx.x % QE;
   float wl[4][CIN], bl[4], gw[4][CIN], gb[4];
 #pragma unroll
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
       const long u = u0 + r * stride;
       on[r] = u < total;
       const long tok = (on[r] ? u : u0) / QE;
-      gq[r] = ld4(dyb + tok * E + 4 * q);
+      gq[r] = ldx4<AT>(dyb + tok * E + 4 * q);
 #pragma unroll
       for (int c = 0; c < CIN; ++c) xq[r][c] = xb[c * L + tok];
     }
@@ -326,10 +326,10 @@ __device__ __forceinline__ void lfq_probs(const float (&s)[D], float (&p)[1 << D
 
 
 // E/4 adjacent lanes per token, each owning 4 channels: every access is a 16-byte piece of a contiguous stream
-template <int E, int D>
-__global__ __launch_bounds__(256) void lfq_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w_in,
+template <int E, int D, typename AT>
+__global__ __launch_bounds__(256) void lfq_fwd_kernel(const AT* __restrict__ z, const float* __restrict__ w_in,
                                                       const float* __restrict__ b_in, const float* __restrict__ w_out,
-                                                      const float* __restrict__ b_out, float* __restrict__ zq,
+                                                      const float* __restrict__ b_out, AT* __restrict__ zq,
                                                       long long* __restrict__ indices, float* __restrict__ partials,
                                                       float* __restrict__ qs, long M, int training) {
   constexpr int K = 1 << D, R = 2 + K, QE = E / 4;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void lfq_fwd_kernel(const float* __restrict__ 
   bo = ld4(b_out + 4 * q);
   for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
     const long tok = u / QE;
-    const f32x4 zi = ld4(z + tok * E + 4 * q);
+    const f32x4 zi = ldx4<AT>(z + tok * E + 4 * q);
     float s[D], qv[D];
     long long idx = 0;
     f32x4 o = bo;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void lfq_fwd_kernel(const float* __restrict__ 
       idx |= (long long)(a > 0.f) << (D - 1 - i);
       o += wo[i] * qv[i];
     }
-    st4(zq + tok * E + 4 * q, o);
+    stx4<AT>(zq + tok * E + 4 * q, o);
     if (q == 0) {
       indices[tok] = idx;
       if (qs)
@@ -413,12 +413,12 @@ __global__ void lfq_finalize_kernel(const float* __restrict__ partials, int nblo
 }
 
 // backward.  gscal[0] = upstream gradient of the aux loss.  grads accumulate with atomics.
-template <int E, int D, bool HASG /*a dense d z_q exists*/>
-__global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dzq,
+template <int E, int D, bool HASG /*a dense d z_q exists*/, typename AT>
+__global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, const AT* __restrict__ dzq,
                                                       const float* __restrict__ w_in, const float* __restrict__ b_in,
                                                       const float* __restrict__ w_out, const float* __restrict__ stats,
                                                       const float* __restrict__ gscal, const float* __restrict__ dqs,
-                                                      float* __restrict__ dz, float* __restrict__ dw_in,
+                                                      AT* __restrict__ dz, float* __restrict__ dw_in,
                                                       float* __restrict__ db_in, float* __restrict__ dw_out,
                                                       float* __restrict__ db_out, long M, float w_ent, float gamma,
                                                       float w_commit) {
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
    for (int r = 0; r < UN; ++r) {
      const long u = u0 + r * stride;
      tokq[r] = (u < total ? u : u0) / QE;
-     ziq[r] = ld4(z + tokq[r] * E + 4 * q);
-     goq[r] = HASG ? ld4(dzq + tokq[r] * E + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};   // no dense consumer of z_q: no read
+     ziq[r] = ldx4<AT>(z + tokq[r] * E + 4 * q);
+     goq[r] = HASG ? ldx4<AT>(dzq + tokq[r] * E + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};   // no dense consumer of z_q: no read
 #pragma unroll
      for (int i = 0; i < D; ++i) dqq[r][i] = dqs ? dqs[tokq[r] * D + i] : 0.f;
    }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const float* __restrict__ 
       if (q == 0) gbi[i] += ds[i];
     }
     if (HASG) gbo += go;
-    st4(dz + tok * E + 4 * q, o);
+    stx4<AT>(dz + tok * E + 4 * q, o);
    }
   }
   // lanes with equal q hold partials of the same 4 channels: reduce over them, lanes 0..QE-1 publish
@@ -923,16 +923,17 @@ __global__ __launch_bounds__(256) void ln_relu_res_bwd_kernel(const float* __res
 // the masked activation alone carries both masks for the backward pass (x_masked > 0 <=> ReLU active and kept).
 // Counter-based generator: element i of call `seed` keeps iff hash(seed, i) >= p * 2^32 (murmur3 finaliser).
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ x, long n4, unsigned thr, unsigned long long seed) {
+template <typename AT>
+__global__ __launch_bounds__(256) void dropout_mask_kernel(AT* __restrict__ x, long n4, unsigned thr, unsigned long long seed) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    f32x4 v = ld4(x + 4 * i);
+    f32x4 v = ldx4<AT>(x + 4 * i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       unsigned long long h = (unsigned long long)(4 * i + k) ^ (seed * 0x9E3779B97F4A7C15ull);
       h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
       if ((unsigned)h < thr) v[k] = 0.f;
     }
-    st4(x + 4 * i, v);
+    stx4<AT>(x + 4 * i, v);
   }
 }
 
@@ -1205,7 +1206,8 @@ __global__ __launch_bounds__(256) void anomaly_vote_finalize_kernel(const float*
 //   W_eff[co][kt*R + v*D+i][kh,kw] = sum_c W[co][v*C+c][kt,kh,kw] w_out[c][i]
 //   W_eff[co][kt*R + V*D][kh,kw]   = sum_{v,c} W[co][v*C+c][kt,kh,kw] b_out[c].
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __restrict__ qs, float* __restrict__ sp, int N, int V,
+template <typename AT>
+__global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __restrict__ qs, AT* __restrict__ sp, int N, int V,
                                                              int T, long HW, int D, int CP) {
   const int T1 = T / 2, R = V * D + 1, Q = CP / 4;
   const long npix = (long)N * T1 * HW;
@@ -1222,10 +1224,11 @@ __global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __rest
       if (kt < 2) val = ch < V * D ? qs[(((n * V + ch / D) * T + 2 * t1 + kt) * HW + p) * D + ch % D] : 1.f;
       o[k] = val;
     }
-    st4(sp + pix * CP + 4 * q, o);
+    stx4<AT>(sp + pix * CP + 4 * q, o);
   }
 }
-__global__ __launch_bounds__(256) void sign_field_bwd_kernel(const float* __restrict__ dsp, float* __restrict__ dqs, int N, int V,
+template <typename AT>
+__global__ __launch_bounds__(256) void sign_field_bwd_kernel(const AT* __restrict__ dsp, float* __restrict__ dqs, int N, int V,
                                                              int T, long HW, int D, int CP) {
   const int T1 = T / 2, R = V * D + 1;
   const long total = (long)N * V * T * HW * D;
@@ -1234,7 +1237,7 @@ __global__ __launch_bounds__(256) void sign_field_bwd_kernel(const float* __rest
     const long p = r % HW; r /= HW;
     const int t = (int)(r % T); r /= T;
     const int v = (int)(r % V); const long n = r / V;
-    dqs[e] = t < 2 * T1 ? dsp[((n * T1 + t / 2) * HW + p) * CP + (t & 1) * R + v * D + i] : 0.f;   // an odd last frame is never read
+    dqs[e] = t < 2 * T1 ? ldx1<AT>(dsp + ((n * T1 + t / 2) * HW + p) * CP + (t & 1) * R + v * D + i) : 0.f;   // an odd last frame is never read
   }
 }
 // w (Co, V*C, 2, 9) joint | (V, Co, C, 2, 9) per_var -> weff (rows, CP, 9), rows = Co | V*Co (row v*Co+co sees only variable v)
@@ -1467,11 +1470,16 @@ int wg_per_cu(K kernel) {
 }  // namespace
 
 // ---- C-ABI ----------------------------------------------------------------------------------
-extern "C" int idee_patch_embed_ln_fwd(const float* x, const float* w, const float* b, float* y, int N, int V, int Cin,
-                                       long L, int E, idee_stream_t stream) {
+extern "C" int idee_patch_embed_ln_fwd(const float* x, const float* w, const float* b, void* y, int N, int V, int Cin,
+                                       long L, int E, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(x && w && y && N > 0 && V > 0 && L > 0, "patch_embed_ln_fwd: bad argument");
   const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 8, (long)N * V)), N * V);
-#define PE(E_, C_) hipLaunchKernelGGL((patch_embed_fwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, V, L)
+#define PE(E_, C_)                                                                                                              \
+  do {                                                                                                                          \
+    if (act_dtype == IDEE_DTYPE_BF16)                                                                                           \
+      hipLaunchKernelGGL((patch_embed_fwd_kernel<E_, C_, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)y, V, L); \
+    else hipLaunchKernelGGL((patch_embed_fwd_kernel<E_, C_, float>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, (float*)y, V, L); \
+  } while (0)
   if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
   else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "patch_embed_ln: (E=%d, Cin=%d) not built", E, Cin);
@@ -1480,13 +1488,15 @@ extern "C" int idee_patch_embed_ln_fwd(const float* x, const float* w, const flo
   return IDEE_OK;
 }
 
-extern "C" int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dw, float* db,
-                                       int N, int V, int Cin, long L, int E, idee_stream_t stream) {
+extern "C" int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const void* dy, float* dw, float* db,
+                                       int N, int V, int Cin, long L, int E, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(x && w && dy && dw && N > 0 && V > 0 && L > 0, "patch_embed_ln_bwd: bad argument");
 #define PE(E_, C_)                                                                                                  \
   do {                                                                                                              \
-    const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * wg_per_cu(patch_embed_bwd_kernel<E_, C_>), (long)N * V)), N * V); \
-    hipLaunchKernelGGL((patch_embed_bwd_kernel<E_, C_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, dy, dw, db, V, L); \
+    const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * wg_per_cu(patch_embed_bwd_kernel<E_, C_, float>), (long)N * V)), N * V); \
+    if (act_dtype == IDEE_DTYPE_BF16)                                                                               \
+      hipLaunchKernelGGL((patch_embed_bwd_kernel<E_, C_, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, (const bf16_t*)dy, dw, db, V, L); \
+    else hipLaunchKernelGGL((patch_embed_bwd_kernel<E_, C_, float>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, (const float*)dy, dw, db, V, L); \
   } while (0)
   if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
   else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
@@ -1539,9 +1549,9 @@ extern "C" long idee_lfq_workspace_floats(long M, int codebook_size) {
 
 
 
-extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
-                            float* zq, int64_t* indices, float* stats, float* workspace, float* signs, long M, int E,
-                            int codebook_size, int training, float w_entropy, float gamma, float w_commit,
+extern "C" int idee_lfq_fwd(const void* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                            void* zq, int64_t* indices, float* stats, float* workspace, float* signs, long M, int E,
+                            int codebook_size, int training, float w_entropy, float gamma, float w_commit, int act_dtype,
                             idee_stream_t stream) {
   IDEE_CHECK_ARG(z && w_in && b_in && w_out && b_out && zq && indices && M > 0, "lfq_fwd: bad argument");
   IDEE_CHECK_ARG(!training || (stats && workspace), "lfq_fwd: training needs stats and workspace");
@@ -1550,8 +1560,11 @@ extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in
   const int nb = stream_grid(M * 4);
   hipStream_t st = (hipStream_t)stream;
 #define CALL(E_, D_)                                                                                           \
-  hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_>), dim3(nb), dim3(256), 0, st, z, w_in, b_in, w_out, b_out, zq,     \
-                     (long long*)indices, workspace, signs, M, training);                                      \
+  if (act_dtype == IDEE_DTYPE_BF16)                                                                            \
+    hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)z, w_in, b_in, w_out, b_out, \
+                       (bf16_t*)zq, (long long*)indices, workspace, signs, M, training);                       \
+  else hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_, float>), dim3(nb), dim3(256), 0, st, (const float*)z, w_in, b_in, w_out, b_out, \
+                     (float*)zq, (long long*)indices, workspace, signs, M, training);                          \
   if (training) hipLaunchKernelGGL((lfq_finalize_kernel<D_>), dim3(1), dim3(64), 0, st, workspace, nb, stats, M, \
                                    w_entropy, gamma, w_commit)
   LFQ_DISPATCH(CALL)
@@ -1560,22 +1573,25 @@ extern "C" int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in
   return IDEE_OK;
 }
 
-extern "C" int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const float* b_in, const float* w_out,
-                            const float* stats, const float* gloss, const float* dsigns, float* dz, float* dw_in, float* db_in,
+extern "C" int idee_lfq_bwd(const void* z, const void* dzq, const float* w_in, const float* b_in, const float* w_out,
+                            const float* stats, const float* gloss, const float* dsigns, void* dz, float* dw_in, float* db_in,
                             float* dw_out, float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma,
-                            float w_commit, idee_stream_t stream) {
+                            float w_commit, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(z && w_in && b_in && w_out && stats && gloss && dz && dw_in && db_in && dw_out && db_out && M > 0,
                  "lfq_bwd: bad argument");     // dzq may be null: z_q had no dense consumer (gradients arrive through dsigns)
   const int D = log2i(codebook_size);
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
+#define CALL2(E_, D_, AT_)                                                                                         \
+  if (dzq) hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, true, AT_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const AT_*)z, (const AT_*)dzq, w_in, b_in, \
+                     w_out, stats, gloss, dsigns, (AT_*)dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit);  \
+  else hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, false, AT_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const AT_*)z, (const AT_*)dzq, w_in, b_in,    \
+                     w_out, stats, gloss, dsigns, (AT_*)dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
 #define CALL(E_, D_)                                                                                               \
-  const int nb = imin(cdiv(M * 4, 256), kCUs * wg_per_cu(lfq_bwd_kernel<E_, D_, true>));                           \
-  if (dzq) hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in, \
-                     w_out, stats, gloss, dsigns, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit);  \
-  else hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dzq, w_in, b_in,    \
-                     w_out, stats, gloss, dsigns, dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
+  const int nb = imin(cdiv(M * 4, 256), kCUs * wg_per_cu(lfq_bwd_kernel<E_, D_, true, float>));                    \
+  if (act_dtype == IDEE_DTYPE_BF16) { CALL2(E_, D_, bf16_t); } else { CALL2(E_, D_, float); }
   LFQ_DISPATCH(CALL)
 #undef CALL
+#undef CALL2
   IDEE_LAUNCH_CHECK("lfq_bwd");
   return IDEE_OK;
 }
@@ -1730,10 +1746,14 @@ extern "C" int idee_ln_relu_res_bwd(const float* c, const float* gamma, const fl
 }
 
 
-extern "C" int idee_dropout_mask_(float* x, long n, float p, uint64_t seed, idee_stream_t stream) {
+extern "C" int idee_dropout_mask_(void* x, long n, float p, uint64_t seed, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(x && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f, "dropout_mask_: bad argument (n must be a multiple of 4, 0 <= p < 1)");
   const unsigned thr = (unsigned)((double)p * 4294967296.0);
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, thr,
+  if (act_dtype == IDEE_DTYPE_BF16)
+    hipLaunchKernelGGL(dropout_mask_kernel<bf16_t>, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n / 4, thr,
+                       (unsigned long long)seed);
+  else
+    hipLaunchKernelGGL(dropout_mask_kernel<float>, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (float*)x, n / 4, thr,
                      (unsigned long long)seed);
   IDEE_LAUNCH_CHECK("dropout_mask_");
   return IDEE_OK;
@@ -1864,15 +1884,19 @@ extern "C" int idee_anomaly_vote_finalize(const float* acc, const float* cnt, fl
   return IDEE_OK;
 }
 
-extern "C" int idee_lfq_sign_field_fwd(const float* signs, float* sp, int N, int V, int T, long HW, int D, int CP, idee_stream_t stream) {
+extern "C" int idee_lfq_sign_field_fwd(const float* signs, void* sp, int N, int V, int T, long HW, int D, int CP, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(signs && sp && N > 0 && V > 0 && T >= 2 && HW > 0 && D > 0 && CP % 16 == 0 && 2 * (V * D + 1) <= CP, "lfq_sign_field_fwd: bad argument");
-  hipLaunchKernelGGL(sign_field_fwd_kernel, dim3(stream_grid((long)N * (T / 2) * HW * (CP / 4))), dim3(256), 0, (hipStream_t)stream, signs, sp, N, V, T, HW, D, CP);
+  const dim3 grid(stream_grid((long)N * (T / 2) * HW * (CP / 4)));
+  if (act_dtype == IDEE_DTYPE_BF16) hipLaunchKernelGGL(sign_field_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, signs, (bf16_t*)sp, N, V, T, HW, D, CP);
+  else hipLaunchKernelGGL(sign_field_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, signs, (float*)sp, N, V, T, HW, D, CP);
   IDEE_LAUNCH_CHECK("lfq_sign_field_fwd");
   return IDEE_OK;
 }
-extern "C" int idee_lfq_sign_field_bwd(const float* dsp, float* dsigns, int N, int V, int T, long HW, int D, int CP, idee_stream_t stream) {
+extern "C" int idee_lfq_sign_field_bwd(const void* dsp, float* dsigns, int N, int V, int T, long HW, int D, int CP, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(dsp && dsigns && N > 0 && V > 0 && T >= 2 && HW > 0 && D > 0 && CP % 16 == 0 && 2 * (V * D + 1) <= CP, "lfq_sign_field_bwd: bad argument");
-  hipLaunchKernelGGL(sign_field_bwd_kernel, dim3(stream_grid((long)N * V * T * HW * D)), dim3(256), 0, (hipStream_t)stream, dsp, dsigns, N, V, T, HW, D, CP);
+  const dim3 grid(stream_grid((long)N * V * T * HW * D));
+  if (act_dtype == IDEE_DTYPE_BF16) hipLaunchKernelGGL(sign_field_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dsp, dsigns, N, V, T, HW, D, CP);
+  else hipLaunchKernelGGL(sign_field_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dsp, dsigns, N, V, T, HW, D, CP);
   IDEE_LAUNCH_CHECK("lfq_sign_field_bwd");
   return IDEE_OK;
 }

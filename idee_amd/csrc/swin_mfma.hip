@@ -241,11 +241,12 @@ __device__ __forceinline__ void mm_lds(f32x4 (&Y)[OT][M], const float* wl, const
 __device__ __forceinline__ u32x4 frag_b(const Split& p) { return u32x4{p.h01, p.h23, p.l01, p.l23}; }
 
 // weight tile -> the two A fragments (hi | hi), (lo | lo), stored at ((tile * 2 + piece) * 64 + lane) * 4 words
-template <bool F16>
+// (PM_BF16X1: only the hi fragment exists; the B operands carry zeros in their upper K half)
+template <int F16>
 __device__ __forceinline__ void put_wfrag_b(unsigned* wl, int tile, f32x4 w, int lane) {
   const Split p = split2<F16>(w);
   *reinterpret_cast<u32x4*>(wl + ((tile * 2 + 0) * 64 + lane) * 4) = u32x4{p.h01, p.h23, p.h01, p.h23};
-  *reinterpret_cast<u32x4*>(wl + ((tile * 2 + 1) * 64 + lane) * 4) = u32x4{p.l01, p.l23, p.l01, p.l23};
+  if (F16 != PM_BF16X1) *reinterpret_cast<u32x4*>(wl + ((tile * 2 + 1) * 64 + lane) * 4) = u32x4{p.l01, p.l23, p.l01, p.l23};
 }
 __device__ __forceinline__ u32x4 get_wfrag_b(const unsigned* wl, int tile, int piece, int lane) {
   return *reinterpret_cast<const u32x4*>(wl + ((tile * 2 + piece) * 64 + lane) * 4);
@@ -253,33 +254,41 @@ __device__ __forceinline__ u32x4 get_wfrag_b(const unsigned* wl, int tile, int p
 // The same with ONE weight fragment per tile, [w_hi | w_lo] (half the LDS: what lets the C = 32 attention backward keep four
 // waves per workgroup), the duplication moved to the B side: B1 = [x_hi | x_hi], B2 = [x_lo | x_lo] (register moves).
 // WDUP selects the layout: tile t lives at (t * 2 + piece) * 256 words (duplicated) or at t * 256 words (single).
-template <bool F16>
+template <int F16>
 __device__ __forceinline__ void put_wfrag_u(unsigned* wl, int tile, f32x4 w, int lane) {
   const Split p = split2<F16>(w);
   *reinterpret_cast<u32x4*>(wl + (tile * 64 + lane) * 4) = u32x4{p.h01, p.h23, p.l01, p.l23};
 }
-template <bool F16, bool WDUP>
+template <int F16, bool WDUP>
 __device__ __forceinline__ void put_wfrag_x(unsigned* wl, int tile, f32x4 w, int lane) {
   if (WDUP) put_wfrag_b<F16>(wl, tile, w, lane); else put_wfrag_u<F16>(wl, tile, w, lane);
 }
 // acc += W-tile x B for M column blocks, both layouts (xb = [x_hi | x_lo] fragments)
-template <bool F16, bool WDUP, int M>
+template <int F16, bool WDUP, int M>
 __device__ __forceinline__ void mma_tile(f32x4 (&acc)[M], const unsigned* wl, int tile, const u32x4 (&xb)[M], int lane) {
   if (WDUP) {
-    const u32x4 ah = get_wfrag_b(wl, tile, 0, lane), al = get_wfrag_b(wl, tile, 1, lane);
+    const u32x4 ah = get_wfrag_b(wl, tile, 0, lane);
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(ah, xb[m], acc[m]);
+    if (F16 != PM_BF16X1) {
+      const u32x4 al = get_wfrag_b(wl, tile, 1, lane);
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(al, xb[m], acc[m]);
+      for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(al, xb[m], acc[m]);
+    }
   } else {
-    const u32x4 a = *reinterpret_cast<const u32x4*>(wl + (tile * 64 + lane) * 4);
+    const u32x4 a = *reinterpret_cast<const u32x4*>(wl + (tile * 64 + lane) * 4);     // [w_hi | w_lo]  (PM_BF16X1: [w | 0])
+    if (F16 == PM_BF16X1) {
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(a, u32x4{xb[m][0], xb[m][1], xb[m][0], xb[m][1]}, acc[m]);
+      for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(a, xb[m], acc[m]);             // xb = [x | 0]
+    } else {
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(a, u32x4{xb[m][2], xb[m][3], xb[m][2], xb[m][3]}, acc[m]);
+      for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(a, u32x4{xb[m][0], xb[m][1], xb[m][0], xb[m][1]}, acc[m]);
+#pragma unroll
+      for (int m = 0; m < M; ++m) acc[m] = mfma_s<F16>(a, u32x4{xb[m][2], xb[m][3], xb[m][2], xb[m][3]}, acc[m]);
+    }
   }
 }
-template <bool F16, bool WDUP, int OT, int KT, int M>
+template <int F16, bool WDUP, int OT, int KT, int M>
 __device__ __forceinline__ void mm_x(f32x4 (&Y)[OT][M], const unsigned* wl, int tile0, const u32x4 (&XB)[KT][M], int lane) {
 #pragma unroll
   for (int o = 0; o < OT; ++o)
@@ -288,18 +297,12 @@ __device__ __forceinline__ void mm_x(f32x4 (&Y)[OT][M], const unsigned* wl, int 
 }
 
 // Y[OT][M] += W X with the weight fragments of tiles tile0 + o * KT + k in LDS and X already split (B fragments)
-template <bool F16, int OT, int KT, int M>
+template <int F16, int OT, int KT, int M>
 __device__ __forceinline__ void mm_b(f32x4 (&Y)[OT][M], const unsigned* wl, int tile0, const u32x4 (&XB)[KT][M], int lane) {
 #pragma unroll
   for (int o = 0; o < OT; ++o)
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const u32x4 ah = get_wfrag_b(wl, tile0 + o * KT + k, 0, lane), al = get_wfrag_b(wl, tile0 + o * KT + k, 1, lane);
-#pragma unroll
-      for (int m = 0; m < M; ++m) Y[o][m] = mfma_s<F16>(ah, XB[k][m], Y[o][m]);
-#pragma unroll
-      for (int m = 0; m < M; ++m) Y[o][m] = mfma_s<F16>(al, XB[k][m], Y[o][m]);
-    }
+    for (int k = 0; k < KT; ++k) mma_tile<F16, true, M>(Y[o], wl, tile0 + o * KT + k, XB[k], lane);
 }
 
 // bf16 piece images for the token-reduction GEMMs: one 64-byte row per token = 8 slots of 8 bytes (slots 0-3: the hi
@@ -313,10 +316,11 @@ __device__ __forceinline__ void mm_b(f32x4 (&Y)[OT][M], const unsigned* wl, int 
 // writes: SQ_LDS_BANK_CONFLICT was 59 % of SQ_LDS_IDX_ACTIVE in the attention backward, profiles/r02_sq_counters.txt.)
 constexpr int kImgRow = 16;   // 32-bit words per token row
 __device__ __forceinline__ int img_word(int row, int slot) { return row * kImgRow + 2 * (slot ^ (row & 7) ^ ((row >> 3) & 1)); }
+template <int PM = PM_BF16X2>
 __device__ __forceinline__ void put_img_b(unsigned* img, int row, int kq, const Split& p) {
   typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
   *reinterpret_cast<u32x2v*>(img + img_word(row, kq)) = u32x2v{p.h01, p.h23};
-  *reinterpret_cast<u32x2v*>(img + img_word(row, 4 + kq)) = u32x2v{p.l01, p.l23};
+  if (PM != PM_BF16X1) *reinterpret_cast<u32x2v*>(img + img_word(row, 4 + kq)) = u32x2v{p.l01, p.l23};
 }
 // the 4 tokens 16 m + 4 g + {0..3} of position (lane & 15), piece `lo`
 __device__ __forceinline__ unsigned long long tr_read(const unsigned* img, int m, int lo, int lane) {
@@ -326,8 +330,20 @@ __device__ __forceinline__ unsigned long long tr_read(const unsigned* img, int m
   return __builtin_bit_cast(unsigned long long, t);
 }
 // acc[a][b] += sum over the wave's 16 M tokens of A[a][tok] B[b][tok]   (positions a of imgA on rows, b of imgB on columns)
-template <int M>
+// PM_BF16X1: one piece — the K = 32 slots of an MFMA hold TWO 16-token blocks (M even)
+template <int M, int PM = PM_BF16X2>
 __device__ __forceinline__ void gemm_tok_b(f32x4& acc, const unsigned* imgA, const unsigned* imgB, int lane) {
+  if (PM == PM_BF16X1) {
+    static_assert(PM != PM_BF16X1 || M % 2 == 0, "one-piece token GEMM pairs the 16-token blocks");
+#pragma unroll
+    for (int m = 0; m + 1 < M; m += 2) {
+      const unsigned long long a0 = tr_read(imgA, m, 0, lane), a1 = tr_read(imgA, m + 1, 0, lane);
+      const unsigned long long b0 = tr_read(imgB, m, 0, lane), b1 = tr_read(imgB, m + 1, 0, lane);
+      acc = mfma_s<PM_BF16X1>(u32x4{(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)},
+                              u32x4{(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32)}, acc);
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const unsigned long long ah = tr_read(imgA, m, 0, lane), al = tr_read(imgA, m, 1, lane);
@@ -570,9 +586,9 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_mfma_kernel(
 // forward with the four linear layers (qkv, proj, fc1, fc2: 75 % of the block's FLOPs) on the split-bf16 MFMA path;
 // the attention core (K Q^T, softmax, V^T P) stays on the f32 MFMA.  Same arguments and layout as swin_fwd_mfma_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int C, int NH, int NW, bool SAVE_H>
+template <int C, int NH, int NW, bool SAVE_H, int PM /*piece mode of the linear-layer GEMMs*/, typename AT /*token storage*/>
 __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
-    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ hsave, const float* __restrict__ qkv_w,
+    const AT* __restrict__ x, AT* __restrict__ y, AT* __restrict__ hsave, const float* __restrict__ qkv_w,
     const float* __restrict__ qkv_b, const float* __restrict__ proj_w, const float* __restrict__ proj_b,
     const float* __restrict__ fc1_w, const float* __restrict__ fc1_b, const float* __restrict__ fc2_w,
     const float* __restrict__ fc2_b, const float* __restrict__ rel_bias, Geom g) {
@@ -608,7 +624,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
       if ((i++) % 4 == wave) st4(s_bias + (B_Q + o) * 256 + lane * 4, vfrag<HPC>(qkv_b, 16 * o, lane, mul));
 #pragma unroll
       for (int k = 0; k < CT; ++k)
-        if ((i++) % 4 == wave) put_wfrag_b<true>(s_wf, T_Q + o * CT + k, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<PM>(s_wf, T_Q + o * CT + k, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul), lane);
     }
 #pragma unroll
     for (int o = 0; o < CT; ++o) {
@@ -616,17 +632,17 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
       if ((i++) % 4 == wave) st4(s_bias + (B_2 + o) * 256 + lane * 4, vfrag<1>(fc2_b, 16 * o, lane));
 #pragma unroll
       for (int k = 0; k < CT; ++k)
-        if ((i++) % 4 == wave) put_wfrag_b<true>(s_wf, T_P + o * CT + k, wfrag<false, 1, HPC>(proj_w, C, 16 * o, 16 * k, lane), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<PM>(s_wf, T_P + o * CT + k, wfrag<false, 1, HPC>(proj_w, C, 16 * o, 16 * k, lane), lane);
 #pragma unroll
       for (int k = 0; k < HT; ++k)
-        if ((i++) % 4 == wave) put_wfrag_b<true>(s_wf, T_2 + o * HT + k, wfrag<false, 1, 1>(fc2_w, HID, 16 * o, 16 * k, lane), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<PM>(s_wf, T_2 + o * HT + k, wfrag<false, 1, 1>(fc2_w, HID, 16 * o, 16 * k, lane), lane);
     }
 #pragma unroll
     for (int o = 0; o < HT; ++o) {
       if ((i++) % 4 == wave) st4(s_bias + (B_1 + o) * 256 + lane * 4, vfrag<1>(fc1_b, 16 * o, lane));
 #pragma unroll
       for (int k = 0; k < CT; ++k)
-        if ((i++) % 4 == wave) put_wfrag_b<true>(s_wf, T_1 + o * CT + k, wfrag<false, 1, 1>(fc1_w, C, 16 * o, 16 * k, lane), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<PM>(s_wf, T_1 + o * CT + k, wfrag<false, 1, 1>(fc1_w, C, 16 * o, 16 * k, lane), lane);
     }
     __syncthreads();
   }
@@ -659,7 +675,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
       t[m] = locate<NW>(g, b, it0 + wave, 16 * m + j, C);
       keep[m] = t[m].valid;
 #pragma unroll
-      for (int c = 0; c < CT; ++c) X[c][m] = t[m].valid ? ld4(x + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < CT; ++c) X[c][m] = t[m].valid ? ldx4<AT>(x + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     f32x4 XN[CT][MT];
     float rstd[MT];
@@ -671,14 +687,14 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) bXN[c][m] = frag_b(split2<true>(XN[c][m]));
+        for (int m = 0; m < MT; ++m) bXN[c][m] = frag_b(split2<PM>(XN[c][m]));
 #pragma unroll
       for (int o = 0; o < 3 * CT; ++o) {
         const f32x4 bqo = BIAS(B_Q + o);
 #pragma unroll
         for (int m = 0; m < MT; ++m) QKV[o][m] = bqo;
       }
-      mm_b<true, 3 * CT, CT, MT>(QKV, s_wf, T_Q, bXN, lane);
+      mm_b<PM, 3 * CT, CT, MT>(QKV, s_wf, T_Q, bXN, lane);
     }
 
     wave_sync();   // previous iteration's readers of vt / rid are done
@@ -773,9 +789,9 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
       for (int c = 0; c < CT; ++c) {
         const f32x4 bpc = BIAS(B_P + c);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { Hs[c][m] = bpc; bO[c][m] = frag_b(split2<true>(O[c][m])); }
+        for (int m = 0; m < MT; ++m) { Hs[c][m] = bpc; bO[c][m] = frag_b(split2<PM>(O[c][m])); }
       }
-      mm_b<true, CT, CT, MT>(Hs, s_wf, T_P, bO, lane);
+      mm_b<PM, CT, CT, MT>(Hs, s_wf, T_P, bO, lane);
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -786,7 +802,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
       for (int m = 0; m < MT; ++m)
         if (t[m].valid)
 #pragma unroll
-          for (int c = 0; c < CT; ++c) st4(hsave + t[m].off + 16 * c + 4 * kq, Hs[c][m]);
+          for (int c = 0; c < CT; ++c) stx4<AT>(hsave + t[m].off + 16 * c + 4 * kq, Hs[c][m]);
     }
     f32x4 HN[CT][MT];
     float rstd2[MT];
@@ -799,7 +815,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
       for (int c = 0; c < CT; ++c) {
         const f32x4 b2c = BIAS(B_2 + c);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { Y[c][m] = b2c; bHN[c][m] = frag_b(split2<true>(HN[c][m])); }
+        for (int m = 0; m < MT; ++m) { Y[c][m] = b2c; bHN[c][m] = frag_b(split2<PM>(HN[c][m])); }
       }
       // one hidden 16-block at a time: fc1 -> GELU -> split -> fc2 (the hidden activation never exists as a whole)
 #pragma unroll
@@ -808,17 +824,13 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
         const f32x4 b1o = BIAS(B_1 + ho);
 #pragma unroll
         for (int m = 0; m < MT; ++m) A1[0][m] = b1o;
-        mm_b<true, 1, CT, MT>(A1, s_wf, T_1 + ho * CT, bHN, lane);
+        mm_b<PM, 1, CT, MT>(A1, s_wf, T_1 + ho * CT, bHN, lane);
         u32x4 bG[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) bG[m] = frag_b(split2<true>(gelu4(A1[0][m])));
+        for (int m = 0; m < MT; ++m) bG[m] = frag_b(split2<PM>(gelu4(A1[0][m])));
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const u32x4 ah = get_wfrag_b(s_wf, T_2 + c * HT + ho, 0, lane), al = get_wfrag_b(s_wf, T_2 + c * HT + ho, 1, lane);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) Y[c][m] = mfma_s<true>(ah, bG[m], Y[c][m]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) Y[c][m] = mfma_s<true>(al, bG[m], Y[c][m]);
+          mma_tile<PM, true, MT>(Y[c], s_wf, T_2 + c * HT + ho, bG, lane);
         }
       }
 #pragma unroll
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_fwd_b_kernel(
     for (int m = 0; m < MT; ++m)
       if (t[m].valid)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) st4(y + t[m].off + 16 * c + 4 * kq, Y[c][m]);
+        for (int c = 0; c < CT; ++c) stx4<AT>(y + t[m].off + 16 * c + 4 * kq, Y[c][m]);
   }
 }
 
@@ -1070,9 +1082,9 @@ __global__ __launch_bounds__(256, M == 2 ? 2 : 1) void swin_mlp_bwd_kernel(
 // same results to ~2e-6 relative as swin_mlp_bwd_kernel.  Per 32 tokens: 80 bf16 MFMAs (16 cycles each, overlapping the
 // VALU work) instead of 160 f32 MFMAs (32 cycles each, serialised with it) + 20 operand splits.
 // ---------------------------------------------------------------------------------------------
-template <int C, int M>
+template <int C, int M, int PM, typename AT>
 __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_b_kernel(
-    const float* __restrict__ hs, const float* __restrict__ dy, float* __restrict__ dh, const float* __restrict__ fc1_w,
+    const AT* __restrict__ hs, const AT* __restrict__ dy, AT* __restrict__ dh, const float* __restrict__ fc1_w,
     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float* __restrict__ g_fc1_w,
     float* __restrict__ g_fc1_b, float* __restrict__ g_fc2_w, float* __restrict__ g_fc2_b, int V, long L,
     const float* __restrict__ path_scale) {
@@ -1107,9 +1119,9 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_b_kernel(
       if ((i++) % 4 == wave) st4(s_b1 + ho * 256 + lane * 4, vfrag<1>(fc1_b, 16 * ho, lane));
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        if ((i++) % 4 == wave) put_wfrag_b<false>(s_wf, F_W1 + ho * CT + c, wfrag<false, 1, 1>(fc1_w, C, 16 * ho, 16 * c, lane), lane);
-        if ((i++) % 4 == wave) put_wfrag_b<false>(s_wf, F_W2T + ho * CT + c, wfrag<true, 1, 1>(fc2_w, HID, 16 * ho, 16 * c, lane), lane);
-        if ((i++) % 4 == wave) put_wfrag_b<false>(s_wf, F_W1T + c * HT + ho, wfrag<true, 1, 1>(fc1_w, C, 16 * c, 16 * ho, lane), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<PM>(s_wf, F_W1 + ho * CT + c, wfrag<false, 1, 1>(fc1_w, C, 16 * ho, 16 * c, lane), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<PM>(s_wf, F_W2T + ho * CT + c, wfrag<true, 1, 1>(fc2_w, HID, 16 * ho, 16 * c, lane), lane);
+        if ((i++) % 4 == wave) put_wfrag_b<PM>(s_wf, F_W1T + c * HT + ho, wfrag<true, 1, 1>(fc1_w, C, 16 * c, 16 * ho, lane), lane);
       }
     }
     __syncthreads();
@@ -1134,8 +1146,8 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_b_kernel(
         valid[m] = tok < L;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          Hs[c][m] = valid[m] ? ld4(hs + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
-          DY[c][m] = valid[m] ? ld4(dy + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+          Hs[c][m] = valid[m] ? ldx4<AT>(hs + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+          DY[c][m] = valid[m] ? ldx4<AT>(dy + tok * C + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
       bool all[M];
@@ -1150,11 +1162,11 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_b_kernel(
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         const f32x4 dys = DY[c][m] * ps2;       // gradient entering the MLP branch (drop_path factor of this batch item)
-        const Split sh = split2<false>(HN[c][m]), sd = split2<false>(dys);
+        const Split sh = split2<PM>(HN[c][m]), sd = split2<PM>(dys);
         bHN[c][m] = frag_b(sh);
         bDY[c][m] = frag_b(sd);
-        put_img_b(imgHN + c * IMGW, 16 * m + j, kq, sh);
-        put_img_b(imgDY + c * IMGW, 16 * m + j, kq, sd);
+        put_img_b<PM>(imgHN + c * IMGW, 16 * m + j, kq, sh);
+        put_img_b<PM>(imgDY + c * IMGW, 16 * m + j, kq, sd);
         pb2[c] += dys;
       }
     f32x4 dHN[CT][M];
@@ -1169,8 +1181,8 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_b_kernel(
       const f32x4 b1 = ld4(s_b1 + ho * 256 + lane * 4);
 #pragma unroll
       for (int m = 0; m < M; ++m) { A1[0][m] = b1; dG[0][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      mm_b<false, 1, CT, M>(A1, s_wf, F_W1 + ho * CT, bHN, lane);
-      mm_b<false, 1, CT, M>(dG, s_wf, F_W2T + ho * CT, bDY, lane);
+      mm_b<PM, 1, CT, M>(A1, s_wf, F_W1 + ho * CT, bHN, lane);
+      mm_b<PM, 1, CT, M>(dG, s_wf, F_W2T + ho * CT, bDY, lane);
       Split sdg[M], sgl[M];
 #pragma unroll
       for (int m = 0; m < M; ++m) {
@@ -1178,30 +1190,29 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_b_kernel(
         gelu_both4(A1[0][m], gl, dgl);
         dG[0][m] *= dgl;                    // dA1
         pb1[ho] += dG[0][m];
-        sdg[m] = split2<false>(dG[0][m]);
-        sgl[m] = split2<false>(gl);
+        sdg[m] = split2<PM>(dG[0][m]);
+        sgl[m] = split2<PM>(gl);
       }
       // dHN += W1^T dA1 (K = this hidden block)
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const u32x4 ah = get_wfrag_b(s_wf, F_W1T + c * HT + ho, 0, lane), al = get_wfrag_b(s_wf, F_W1T + c * HT + ho, 1, lane);
+        u32x4 bdg[M];
 #pragma unroll
-        for (int m = 0; m < M; ++m) dHN[c][m] = mfma_s<false>(ah, frag_b(sdg[m]), dHN[c][m]);
-#pragma unroll
-        for (int m = 0; m < M; ++m) dHN[c][m] = mfma_s<false>(al, frag_b(sdg[m]), dHN[c][m]);
+        for (int m = 0; m < M; ++m) bdg[m] = frag_b(sdg[m]);
+        mma_tile<PM, true, M>(dHN[c], s_wf, F_W1T + c * HT + ho, bdg, lane);
       }
       // weight gradients: dW1[hid][c] += dA1 . HN^T ; dW2[c][hid] += DY . G^T  (K = tokens)
       if (ho) wave_sync();
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        put_img_b(imgA, 16 * m + j, kq, sdg[m]);
-        put_img_b(imgB, 16 * m + j, kq, sgl[m]);
+        put_img_b<PM>(imgA, 16 * m + j, kq, sdg[m]);
+        put_img_b<PM>(imgB, 16 * m + j, kq, sgl[m]);
       }
       wave_sync();
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        gemm_tok_b<M>(aW1[ho][c], imgA, imgHN + c * IMGW, lane);
-        gemm_tok_b<M>(aW2[c][ho], imgDY + c * IMGW, imgB, lane);
+        gemm_tok_b<M, PM>(aW1[ho][c], imgA, imgHN + c * IMGW, lane);
+        gemm_tok_b<M, PM>(aW2[c][ho], imgDY + c * IMGW, imgB, lane);
       }
     }
     f32x4 dH[CT][M];
@@ -1210,7 +1221,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void swin_mlp_bwd_b_kernel(
     for (int m = 0; m < M; ++m)
       if (valid[m])
 #pragma unroll
-        for (int c = 0; c < CT; ++c) st4(dh + (base + 16 * m + j) * C + 16 * c + 4 * kq, dH[c][m]);
+        for (int c = 0; c < CT; ++c) stx4<AT>(dh + (base + 16 * m + j) * C + 16 * c + 4 * kq, dH[c][m]);
   }
 #pragma unroll
   for (int o = 0; o < HT; ++o) {
@@ -1598,9 +1609,9 @@ __device__ __forceinline__ void flush_acc_perm(float* dst, int ld, const f32x4& 
 }
 __device__ __forceinline__ u32x4 dup2(unsigned long long a) { return u32x4{(unsigned)a, (unsigned)(a >> 32), (unsigned)a, (unsigned)(a >> 32)}; }
 
-template <int C, int NH, int NW, int WPB, int MTK, bool WDUP>
+template <int C, int NH, int NW, int WPB, int MTK, bool WDUP, int PM, typename AT>
 __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
-    const float* __restrict__ x, const float* __restrict__ dh, float* __restrict__ dx, const float* __restrict__ qkv_w,
+    const AT* __restrict__ x, const AT* __restrict__ dh, AT* __restrict__ dx, const float* __restrict__ qkv_w,
     const float* __restrict__ qkv_b, const float* __restrict__ proj_w, const float* __restrict__ rel_bias,
     float* __restrict__ g_qkv_w, float* __restrict__ g_qkv_b, float* __restrict__ g_proj_w, float* __restrict__ g_proj_b,
     float* __restrict__ g_rel_bias, Geom g) {
@@ -1638,16 +1649,16 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
       if ((i++) % WPB == wave) st4(s_bq + o * 256 + lane * 4, vfrag<HPC>(qkv_b, 16 * o, lane, mul));
 #pragma unroll
       for (int k = 0; k < CT; ++k) {
-        if ((i++) % WPB == wave) put_wfrag_x<false, WDUP>(s_wf, W_Q + o * CT + k, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul), lane);
+        if ((i++) % WPB == wave) put_wfrag_x<PM, WDUP>(s_wf, W_Q + o * CT + k, wfrag<false, HPC, 1>(qkv_w, C, 16 * o, 16 * k, lane, mul), lane);
         // [c][o] = qkv_w[o][c] (q rows carry the scale)
-        if ((i++) % WPB == wave) put_wfrag_x<false, WDUP>(s_wf, W_QT + k * 3 * CT + o, wfrag<true, 1, HPC>(qkv_w, C, 16 * k, 16 * o, lane, mul), lane);
+        if ((i++) % WPB == wave) put_wfrag_x<PM, WDUP>(s_wf, W_QT + k * 3 * CT + o, wfrag<true, 1, HPC>(qkv_w, C, 16 * k, 16 * o, lane, mul), lane);
       }
     }
 #pragma unroll
     for (int o = 0; o < CT; ++o)
 #pragma unroll
       for (int k = 0; k < CT; ++k)   // [c'][c] = proj_w[c][c']
-        if ((i++) % WPB == wave) put_wfrag_x<false, WDUP>(s_wf, W_PT + o * CT + k, wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane), lane);
+        if ((i++) % WPB == wave) put_wfrag_x<PM, WDUP>(s_wf, W_PT + o * CT + k, wfrag<true, HPC, 1>(proj_w, C, 16 * o, 16 * k, lane), lane);
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -1711,8 +1722,8 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
       keep[m] = t[m].valid;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        X[c][m] = t[m].valid ? ld4(x + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
-        DH[c][m] = t[m].valid ? ld4(dh + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        X[c][m] = t[m].valid ? ldx4<AT>(x + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        DH[c][m] = t[m].valid ? ldx4<AT>(dh + t[m].off + 16 * c + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     f32x4 XN[CT][MTK];
@@ -1726,11 +1737,11 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int m = 0; m < MTK; ++m) {
-          const Split sx = split2<false>(XN[c][m]), sd = split2<false>(DH[c][m] * ps1);   // ps1: drop_path factor of the attention branch
+          const Split sx = split2<PM>(XN[c][m]), sd = split2<PM>(DH[c][m] * ps1);   // ps1: drop_path factor of the attention branch
           bXN[c][m] = frag_b(sx);
           bDH[c][m] = frag_b(sd);
-          put_img_b(imgXN + c * IMGW, 16 * m + j, kq, sx);     // kept for the weight-gradient GEMMs at the end
-          put_img_b(imgDH + c * IMGW, 16 * m + j, kq, sd);
+          put_img_b<PM>(imgXN + c * IMGW, 16 * m + j, kq, sx);     // kept for the weight-gradient GEMMs at the end
+          put_img_b<PM>(imgDH + c * IMGW, 16 * m + j, kq, sd);
           DO[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
           pbp[c] += DH[c][m] * ps1;
         }
@@ -1740,17 +1751,17 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 #pragma unroll
         for (int m = 0; m < MTK; ++m) QKV[o][m] = bqo;
       }
-      mm_x<false, WDUP, 3 * CT, CT, MTK>(QKV, s_wf, W_Q, bXN, lane);
-      mm_x<false, WDUP, CT, CT, MTK>(DO, s_wf, W_PT, bDH, lane);       // dO = proj_w^T dH
+      mm_x<PM, WDUP, 3 * CT, CT, MTK>(QKV, s_wf, W_Q, bXN, lane);
+      mm_x<PM, WDUP, CT, CT, MTK>(DO, s_wf, W_PT, bDH, lane);       // dO = proj_w^T dH
     }
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int m = 0; m < MTK; ++m) {
-        put_img_b(imgQ + c * IMGW, 16 * m + j, kq, split2<false>(QKV[c][m]));
-        put_img_b(imgK + c * IMGW, 16 * m + j, kq, split2<false>(QKV[CT + c][m]));
-        put_img_b(imgV + c * IMGW, 16 * m + j, kq, split2<false>(QKV[2 * CT + c][m]));
-        put_img_b(imgDO + c * IMGW, 16 * m + j, kq, split2<false>(DO[c][m]));
+        put_img_b<PM>(imgQ + c * IMGW, 16 * m + j, kq, split2<PM>(QKV[c][m]));
+        put_img_b<PM>(imgK + c * IMGW, 16 * m + j, kq, split2<PM>(QKV[CT + c][m]));
+        put_img_b<PM>(imgV + c * IMGW, 16 * m + j, kq, split2<PM>(QKV[2 * CT + c][m]));
+        put_img_b<PM>(imgDO + c * IMGW, 16 * m + j, kq, split2<PM>(DO[c][m]));
       }
     if (kq == 0)
 #pragma unroll
@@ -1823,7 +1834,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 #pragma unroll
         for (int kt = 0; kt < TPW; ++kt)
 #pragma unroll
-          for (int qt = 0; qt < TPW; ++qt) { sP[kt][qt] = split2<false>(P[kt][qt]); sS[kt][qt] = split2<false>(dP[kt][qt]); }
+          for (int qt = 0; qt < TPW; ++qt) { sP[kt][qt] = split2<PM>(P[kt][qt]); sS[kt][qt] = split2<PM>(dP[kt][qt]); }
         // O[chan][query] = sum_keys V^T P ; dQ[chan][query] = sum_keys K^T dS : A from the V / K piece images (transposed read)
         {
           f32x4 acco[TPW], accq[TPW];
@@ -1832,17 +1843,20 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 #pragma unroll
           for (int kt = 0; kt < TPW; ++kt) {
             const int mk = grp * TPW + kt;
-            const u32x4 vh = dup2(tr_read(imgV + c * IMGW, mk, 0, lane)), vl = dup2(tr_read(imgV + c * IMGW, mk, 1, lane));
-            const u32x4 kh = dup2(tr_read(imgK + c * IMGW, mk, 0, lane)), kl = dup2(tr_read(imgK + c * IMGW, mk, 1, lane));
+            const u32x4 vh = dup2(tr_read(imgV + c * IMGW, mk, 0, lane));
+            const u32x4 kh = dup2(tr_read(imgK + c * IMGW, mk, 0, lane));
 #pragma unroll
             for (int qt = 0; qt < TPW; ++qt) {
-              acco[qt] = mfma_s<false>(vh, frag_b(sP[kt][qt]), acco[qt]);
-              accq[qt] = mfma_s<false>(kh, frag_b(sS[kt][qt]), accq[qt]);
+              acco[qt] = mfma_s<PM>(vh, frag_b(sP[kt][qt]), acco[qt]);
+              accq[qt] = mfma_s<PM>(kh, frag_b(sS[kt][qt]), accq[qt]);
             }
+            if (PM != PM_BF16X1) {
+              const u32x4 vl = dup2(tr_read(imgV + c * IMGW, mk, 1, lane)), kl = dup2(tr_read(imgK + c * IMGW, mk, 1, lane));
 #pragma unroll
-            for (int qt = 0; qt < TPW; ++qt) {
-              acco[qt] = mfma_s<false>(vl, frag_b(sP[kt][qt]), acco[qt]);
-              accq[qt] = mfma_s<false>(kl, frag_b(sS[kt][qt]), accq[qt]);
+              for (int qt = 0; qt < TPW; ++qt) {
+                acco[qt] = mfma_s<PM>(vl, frag_b(sP[kt][qt]), acco[qt]);
+                accq[qt] = mfma_s<PM>(kl, frag_b(sS[kt][qt]), accq[qt]);
+              }
             }
           }
 #pragma unroll
@@ -1860,22 +1874,26 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 #pragma unroll
           for (int qt = 0; qt < TPW; ++qt) {
             const int mq = grp * TPW + qt;
-            const u32x4 qh = dup2(tr_read(imgQ + c * IMGW, mq, 0, lane)), ql = dup2(tr_read(imgQ + c * IMGW, mq, 1, lane));
-            const u32x4 dh_ = dup2(tr_read(imgDO + c * IMGW, mq, 0, lane)), dl_ = dup2(tr_read(imgDO + c * IMGW, mq, 1, lane));
+            const u32x4 qh = dup2(tr_read(imgQ + c * IMGW, mq, 0, lane)), dh_ = dup2(tr_read(imgDO + c * IMGW, mq, 0, lane));
+            u32x4 ql = {0u, 0u, 0u, 0u}, dl_ = {0u, 0u, 0u, 0u};
+            if (PM != PM_BF16X1) { ql = dup2(tr_read(imgQ + c * IMGW, mq, 1, lane)); dl_ = dup2(tr_read(imgDO + c * IMGW, mq, 1, lane)); }
 #pragma unroll
             for (int kt = 0; kt < TPW; ++kt) {
               wave_sync();   // the previous tile's readers are done
-              put_img_b(tileP, j, kq, sP[kt][qt]);      // rows = queries, positions = keys
-              put_img_b(tileS, j, kq, sS[kt][qt]);
+              put_img_b<PM>(tileP, j, kq, sP[kt][qt]);      // rows = queries, positions = keys
+              put_img_b<PM>(tileS, j, kq, sS[kt][qt]);
               wave_sync();
-              const unsigned long long ph = tr_read(tileP, 0, 0, lane), pl = tr_read(tileP, 0, 1, lane);
-              const unsigned long long sh = tr_read(tileS, 0, 0, lane), sl = tr_read(tileS, 0, 1, lane);
+              const unsigned long long ph = tr_read(tileP, 0, 0, lane), sh = tr_read(tileS, 0, 0, lane);
+              unsigned long long pl = 0ull, sl = 0ull;
+              if (PM != PM_BF16X1) { pl = tr_read(tileP, 0, 1, lane); sl = tr_read(tileS, 0, 1, lane); }
               const u32x4 PT = {(unsigned)ph, (unsigned)(ph >> 32), (unsigned)pl, (unsigned)(pl >> 32)};
               const u32x4 ST = {(unsigned)sh, (unsigned)(sh >> 32), (unsigned)sl, (unsigned)(sl >> 32)};
-              acck[kt] = mfma_s<false>(qh, ST, acck[kt]);
-              accv[kt] = mfma_s<false>(dh_, PT, accv[kt]);
-              acck[kt] = mfma_s<false>(ql, ST, acck[kt]);
-              accv[kt] = mfma_s<false>(dl_, PT, accv[kt]);
+              acck[kt] = mfma_s<PM>(qh, ST, acck[kt]);
+              accv[kt] = mfma_s<PM>(dh_, PT, accv[kt]);
+              if (PM != PM_BF16X1) {
+                acck[kt] = mfma_s<PM>(ql, ST, acck[kt]);
+                accv[kt] = mfma_s<PM>(dl_, PT, accv[kt]);
+              }
             }
           }
 #pragma unroll
@@ -1895,8 +1913,8 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
         dXN[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
         // the q gradient refers to the pre-scaled q: the scale is folded into wqt (above) and into dWq / dbq at the flush
         pbq[c] += DQ[c][m]; pbq[CT + c] += DK[c][m]; pbq[2 * CT + c] += DV[c][m];
-        sDQ[c][m] = split2<false>(DQ[c][m]); sDK[c][m] = split2<false>(DK[c][m]); sDV[c][m] = split2<false>(DV[c][m]);
-        sO[c][m] = split2<false>(O[c][m]);
+        sDQ[c][m] = split2<PM>(DQ[c][m]); sDK[c][m] = split2<PM>(DK[c][m]); sDV[c][m] = split2<PM>(DV[c][m]);
+        sO[c][m] = split2<PM>(O[c][m]);
       }
 #pragma unroll
     for (int oc = 0; oc < CT; ++oc)
@@ -1905,9 +1923,9 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
         u32x4 bq_[MTK], bk_[MTK], bv_[MTK];
 #pragma unroll
         for (int m = 0; m < MTK; ++m) { bq_[m] = frag_b(sDQ[k][m]); bk_[m] = frag_b(sDK[k][m]); bv_[m] = frag_b(sDV[k][m]); }
-        mma_tile<false, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + k, bq_, lane);
-        mma_tile<false, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + CT + k, bk_, lane);
-        mma_tile<false, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + 2 * CT + k, bv_, lane);
+        mma_tile<PM, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + k, bq_, lane);
+        mma_tile<PM, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + CT + k, bk_, lane);
+        mma_tile<PM, WDUP, MTK>(dXN[oc], s_wf, W_QT + oc * 3 * CT + 2 * CT + k, bv_, lane);
       }
     f32x4 DX[CT][MTK];
     layer_norm_bwd_tl(dXN, XN, rstd, DH, DX);
@@ -1915,7 +1933,7 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
     for (int m = 0; m < MTK; ++m)
       if (t[m].valid)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) st4(dx + t[m].off + 16 * c + 4 * kq, DX[c][m]);
+        for (int c = 0; c < CT; ++c) stx4<AT>(dx + t[m].off + 16 * c + 4 * kq, DX[c][m]);
 
     // ---- token-reduction GEMMs (weight gradients) from piece images that reuse the Q / K / V / dO slots ----
     // dproj_w[c][c'] += dH[c] O[c'] ; dqkv_w[o][c] += dQKV[o] XN[c] ; K = tokens
@@ -1925,21 +1943,21 @@ __global__ __launch_bounds__(64 * WPB) void swin_attn_bwd_b_kernel(
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int m = 0; m < MTK; ++m) put_img_b(imgO + c * IMGW, 16 * m + j, kq, sO[c][m]);
+      for (int m = 0; m < MTK; ++m) put_img_b<PM>(imgO + c * IMGW, 16 * m + j, kq, sO[c][m]);
     wave_sync();
 #pragma unroll
     for (int ca = 0; ca < CT; ++ca)
 #pragma unroll
-      for (int cb = 0; cb < CT; ++cb) gemm_tok_b<MTK>(aWp[ca][cb], imgDH + ca * IMGW, imgO + cb * IMGW, lane);
+      for (int cb = 0; cb < CT; ++cb) gemm_tok_b<MTK, PM>(aWp[ca][cb], imgDH + ca * IMGW, imgO + cb * IMGW, lane);
 #pragma unroll
     for (int o = 0; o < 3 * CT; ++o) {
       if (o) wave_sync();
 #pragma unroll
       for (int m = 0; m < MTK; ++m)
-        put_img_b(imgG, 16 * m + j, kq, o < CT ? sDQ[o][m] : o < 2 * CT ? sDK[o - CT][m] : sDV[o - 2 * CT][m]);
+        put_img_b<PM>(imgG, 16 * m + j, kq, o < CT ? sDQ[o][m] : o < 2 * CT ? sDK[o - CT][m] : sDV[o - 2 * CT][m]);
       wave_sync();
 #pragma unroll
-      for (int cb = 0; cb < CT; ++cb) gemm_tok_b<MTK>(aWq[o][cb], imgG, imgXN + cb * IMGW, lane);
+      for (int cb = 0; cb < CT; ++cb) gemm_tok_b<MTK, PM>(aWq[o][cb], imgG, imgXN + cb * IMGW, lane);
     }
   }
 
@@ -2044,23 +2062,29 @@ dim3 swin_grid(int items_per_wg_loop, int B, int wg_per_cu) {
   else if (C == 32 && NH == 2 && NW == 8) { KERNEL_CALL(32, 2, 8); }                            \
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: (C=%d, heads=%d, window volume=%d) is not built", C, NH, NW);
 
-extern "C" int idee_swin_block_fwd(const float* x, float* y, float* h_save, const idee_swin_params* p,
+// which split kernels run: PM_BF16X1 + bf16 tokens for the bf16 activation path, the two-piece modes (f16 pieces forward,
+// bf16 pieces backward) for IDEE_SWIN_MATH=split on f32 tokens
+extern "C" int idee_swin_block_fwd(const void* x_, void* y_, void* h_save_, const idee_swin_params* p,
                                    const idee_swin_geom* s, idee_stream_t stream) {
-  IDEE_CHECK_ARG(x && y && p && s, "swin_block_fwd: null argument");
+  IDEE_CHECK_ARG(x_ && y_ && p && s, "swin_block_fwd: null argument");
   Geom g; int NW;
   if (int rc = make_geom(s, g, NW)) return rc;
   g.path_scale = p->path_scale;
   const int C = s->C, NH = s->heads, B = s->N * s->V;
-  const bool split = split_math();
+  const bool bf = s->act_dtype == IDEE_DTYPE_BF16;
+  const bool split = split_math() || bf;
   const dim3 grid = swin_grid(cdiv(g.items, 4), B, C == 16 ? (split ? 3 : 2) : 1);
+  const float* x = (const float*)x_; float* y = (float*)y_; float* h_save = (float*)h_save_;
+#define LFWD(KERN, XT)                                                                                                \
+  hipLaunchKernelGGL(KERN, grid, dim3(256), 0, (hipStream_t)stream, (const XT*)x_, (XT*)y_, (XT*)h_save_, p->qkv_w, p->qkv_b, \
+                     p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g)
 #define CALL(C_, NH_, NW_)                                                                                   \
-  if (split) {                                                                                               \
-    if (h_save)                                                                                              \
-      hipLaunchKernelGGL((swin_fwd_b_kernel<C_, NH_, NW_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
-                         p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
-    else                                                                                                     \
-      hipLaunchKernelGGL((swin_fwd_b_kernel<C_, NH_, NW_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
-                         p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
+  if (bf) {                                                                                                  \
+    if (h_save) LFWD((swin_fwd_b_kernel<C_, NH_, NW_, true, PM_BF16X1, bf16_t>), bf16_t);                    \
+    else LFWD((swin_fwd_b_kernel<C_, NH_, NW_, false, PM_BF16X1, bf16_t>), bf16_t);                          \
+  } else if (split) {                                                                                        \
+    if (h_save) LFWD((swin_fwd_b_kernel<C_, NH_, NW_, true, PM_F16X2, float>), float);                       \
+    else LFWD((swin_fwd_b_kernel<C_, NH_, NW_, false, PM_F16X2, float>), float);                             \
   } else if (h_save)                                                                                         \
     hipLaunchKernelGGL((swin_fwd_mfma_kernel<C_, NH_, NW_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, h_save, \
                        p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g); \
@@ -2069,29 +2093,37 @@ extern "C" int idee_swin_block_fwd(const float* x, float* y, float* h_save, cons
                        p->qkv_w, p->qkv_b, p->proj_w, p->proj_b, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->rel_bias, g)
   SWIN_DISPATCH(CALL)
 #undef CALL
+#undef LFWD
   IDEE_LAUNCH_CHECK("swin_block_fwd");
   return IDEE_OK;
 }
 
-extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const float* dy, float* dx, float* dh_workspace,
+extern "C" int idee_swin_block_bwd(const void* x_, const void* h_saved_, const void* dy_, void* dx_, void* dh_workspace_,
                                    const idee_swin_params* p, const idee_swin_grads* d, const idee_swin_geom* s,
                                    idee_stream_t stream) {
-  IDEE_CHECK_ARG(x && h_saved && dy && dx && dh_workspace && p && d && s, "swin_block_bwd: null argument");
+  IDEE_CHECK_ARG(x_ && h_saved_ && dy_ && dx_ && dh_workspace_ && p && d && s, "swin_block_bwd: null argument");
   Geom g; int NW;
   if (int rc = make_geom(s, g, NW)) return rc;
   g.path_scale = p->path_scale;
   const int C = s->C, NH = s->heads, B = s->N * s->V;
   const long L = (long)s->D * s->H * s->W;
   hipStream_t st = (hipStream_t)stream;
+  const bool bf = s->act_dtype == IDEE_DTYPE_BF16;
+  const bool split = split_math() || bf;
+  const float* x = (const float*)x_; const float* h_saved = (const float*)h_saved_; const float* dy = (const float*)dy_;
+  float* dx = (float*)dx_; float* dh_workspace = (float*)dh_workspace_;
+#define LMLP(KERN, XT)                                                                                                     \
+  hipLaunchKernelGGL(KERN, grid, dim3(256), 0, st, (const XT*)h_saved_, (const XT*)dy_, (XT*)dh_workspace_, p->fc1_w, p->fc1_b, \
+                     p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L, p->path_scale)
   {   // part 1: MLP + norm2 (token order)
-    if (C == 32 && split_math()) {      // one workgroup per CU: 96 KB of weight fragments + 48 KB of piece images
+    if (C == 32 && split) {      // one workgroup per CU: 96 KB of weight fragments + 48 KB of piece images
       const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 1);
-      hipLaunchKernelGGL((swin_mlp_bwd_b_kernel<32, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
-                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L, p->path_scale);
-    } else if (C == 16 && split_math()) {
+      if (bf) LMLP((swin_mlp_bwd_b_kernel<32, 2, PM_BF16X1, bf16_t>), bf16_t);
+      else LMLP((swin_mlp_bwd_b_kernel<32, 2, PM_BF16X2, float>), float);
+    } else if (C == 16 && split) {
       const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 2);
-      hipLaunchKernelGGL((swin_mlp_bwd_b_kernel<16, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
-                         p->fc2_w, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b, s->V, L, p->path_scale);
+      if (bf) LMLP((swin_mlp_bwd_b_kernel<16, 2, PM_BF16X1, bf16_t>), bf16_t);
+      else LMLP((swin_mlp_bwd_b_kernel<16, 2, PM_BF16X2, float>), float);
     } else if (C == 16) {   // 32 tokens per wave: half the live registers -> two waves per SIMD overlap GELU with the MFMA chains
       const dim3 grid = swin_grid(cdiv(cdiv(L, 32), 4), B, 2);
       hipLaunchKernelGGL((swin_mlp_bwd_kernel<16, 2>), grid, dim3(256), 0, st, h_saved, dy, dh_workspace, p->fc1_w, p->fc1_b,
@@ -2103,24 +2135,23 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
     }
     else return idee::fail(IDEE_ERR_UNSUPPORTED, "swin: C=%d is not built", C);
   }
+#undef LMLP
   // C = 16: 32 tokens per wave and work item, 8 waves per workgroup (LDS images 13.8 KB per wave): at most 256 registers
   // per lane, so two waves share a SIMD and one's LDS / global latency hides under the other's MFMA chain.
   // C = 32: 64 tokens per wave, 2 waves (48 KB of images each).
-  const bool split = split_math();
   const int WPB = C == 16 ? 8 : (split ? 4 : 2), MTK = C == 16 ? 2 : (split ? 2 : 4);
   Geom ga = g;
   ga.items = cdiv(g.nWin, (16 * MTK) / NW);
   const dim3 grid = swin_grid(cdiv(ga.items, WPB), B, 1);
   const dim3 grid_v = swin_grid(cdiv(ga.items, WPB) * s->N, s->V, 1);      // split kernels: one grid row per variable
+#define LATT(KERN, XT, BLK)                                                                                          \
+  hipLaunchKernelGGL(KERN, grid_v, dim3(BLK), 0, st, (const XT*)x_, (const XT*)dh_workspace_, (XT*)dx_, p->qkv_w, p->qkv_b, \
+                     p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w, d->proj_b, d->rel_bias, ga)
 #define CALL(C_, NH_, NW_)                                                                                           \
-  if (C_ == 32 && split)                                                                                             \
-    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<32, NH_, NW_, 4, 2, false>), grid_v, dim3(256), 0, st, x,             \
-                       dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,  \
-                       d->proj_b, d->rel_bias, ga);                                                                  \
-  else if (C_ == 16 && split)                                                                                        \
-    hipLaunchKernelGGL((swin_attn_bwd_b_kernel<16, NH_, NW_, 8, 2, true>), grid_v, dim3(512), 0, st, x,              \
-                       dh_workspace, dx, p->qkv_w, p->qkv_b, p->proj_w, p->rel_bias, d->qkv_w, d->qkv_b, d->proj_w,  \
-                       d->proj_b, d->rel_bias, ga);                                                                  \
+  if (C_ == 32 && bf) LATT((swin_attn_bwd_b_kernel<32, NH_, NW_, 4, 2, false, PM_BF16X1, bf16_t>), bf16_t, 256);     \
+  else if (C_ == 16 && bf) LATT((swin_attn_bwd_b_kernel<16, NH_, NW_, 8, 2, true, PM_BF16X1, bf16_t>), bf16_t, 512); \
+  else if (C_ == 32 && split) LATT((swin_attn_bwd_b_kernel<32, NH_, NW_, 4, 2, false, PM_BF16X2, float>), float, 256); \
+  else if (C_ == 16 && split) LATT((swin_attn_bwd_b_kernel<16, NH_, NW_, 8, 2, true, PM_BF16X2, float>), float, 512); \
   else                                                                                                               \
   hipLaunchKernelGGL((swin_attn_bwd_kernel<C_, NH_, NW_, (C_ == 16 ? 8 : 2), (C_ == 16 ? 2 : 4)>), grid,             \
                      dim3(64 * (C_ == 16 ? 8 : 2)), 0, st, x,                                                        \
@@ -2128,6 +2159,7 @@ extern "C" int idee_swin_block_bwd(const float* x, const float* h_saved, const f
                      d->proj_b, d->rel_bias, ga)
   SWIN_DISPATCH(CALL)
 #undef CALL
+#undef LATT
   IDEE_LAUNCH_CHECK("swin_block_bwd");
   return IDEE_OK;
 }

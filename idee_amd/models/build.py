@@ -44,13 +44,35 @@ class VQ_model(nn.Module):
 
         self.cls = import_class('classifier', 'CNN_3D')(in_var=config.in_channels_dynamic, embed_dim=config.codebook_dim,
                                                         dim=config.cls_dim, drop_rate=config.cls_drop_rate)
-        self.vq = import_class('codebook', 'LFQ')(dim=config.codebook_dim, codebook_size=config.codebook_size,
-                                                  entropy_loss_weight=config.lambda_entropy,
-                                                  diversity_gamma=config.diversity_gamma,
-                                                  commitment_loss_weight=config.lambda_commitment)
+        # The reference hard-wires LFQ here (build.py:87; its `codebook` flag is never read).  `config.codebook_impl = "VQ"` (an
+        # attribute the caller sets; not a flag of config.py) puts the nearest-neighbour codebook of models/codebook/VQ.py in its
+        # place — BASELINE config #4's "+ VQ codebook" variant: dim = codebook_dim, codebook_size codes, learnable codebook,
+        # commitment weight lambda_commitment.
+        self.codebook_impl = getattr(config, "codebook_impl", "LFQ")
+        if self.codebook_impl == "VQ":
+            self.vq = import_class('codebook', 'VQ')(dim=config.codebook_dim, codebook_size=config.codebook_size,
+                                                     codebook_dim=config.codebook_dim, commitment_weight=config.lambda_commitment)
+        elif self.codebook_impl == "LFQ":
+            self.vq = import_class('codebook', 'LFQ')(dim=config.codebook_dim, codebook_size=config.codebook_size,
+                                                      entropy_loss_weight=config.lambda_entropy,
+                                                      diversity_gamma=config.diversity_gamma,
+                                                      commitment_loss_weight=config.lambda_commitment)
+        else:
+            raise NotImplementedError(f"codebook_impl {self.codebook_impl!r}: 'LFQ' (the reference's wiring) or 'VQ'")
         self.pretrained = config.en_de_pretrained
+        # `config.act_dtype = "bf16"` (an attribute the caller sets; default f32 = the reference's arithmetic): the token tensors
+        # between the fused units (patch embedding -> Swin blocks -> 3^3 convs -> classifier) and their gradients are stored as
+        # bf16 and every GEMM-shaped kernel runs on the bf16 MFMA with f32 accumulation; parameters, LFQ's projections, logits,
+        # losses and the optimizer stay f32 (BASELINE config #4)
+        ad = getattr(config, "act_dtype", "f32")
+        if ad not in ("f32", "bf16"):
+            raise ValueError(f"config.act_dtype must be 'f32' or 'bf16', got {ad!r}")
+        self.act_dtype = torch.bfloat16 if ad == "bf16" else torch.float32
+        if self.act_dtype == torch.bfloat16 and config.encoder != "Swin_3D":
+            raise NotImplementedError("bf16 activation storage is built for the Swin_3D encoder (BASELINE config #4)")
+        self.encoder.act_dtype = self.act_dtype
         # IDEE_SIGN_FIELD=0 runs the classifier on z_q itself, convolution for convolution as build.py:157
-        self.sign_field_classifier = os.environ.get("IDEE_SIGN_FIELD", "1") != "0"
+        self.sign_field_classifier = os.environ.get("IDEE_SIGN_FIELD", "1") != "0" and self.codebook_impl == "LFQ"
         self._init_weights()
 
     def _init_weights(self, init_type='normal', gain=.02):
@@ -70,9 +92,10 @@ class VQ_model(nn.Module):
                     getattr(mod, n).fill_(1.0)
                 for n in norm_b:
                     getattr(mod, n).zero_()
-            for lin in (self.vq.project_in, self.vq.project_out):
-                lin.weight.normal_(0.02, gain)
-                lin.bias.zero_()
+            if self.codebook_impl == "LFQ":
+                for lin in (self.vq.project_in, self.vq.project_out):
+                    lin.weight.normal_(0.02, gain)
+                    lin.bias.zero_()
         if self.pretrained:
             print('initialize weights from pretrained model {} ...'.format(self.pretrained))
             checkpoint = torch.load(self.pretrained, map_location='cpu')
@@ -87,8 +110,16 @@ class VQ_model(nn.Module):
             # z_q has rank codebook_dim per variable: the classifier's first convolutions read the +-1 code bits
             # with weights folded through project_out (exact refactoring, DESIGN.md "rank-d classifier input")
             z_q, anomaly, loss_z_q, signs = self.vq.quantize_tokens_signs(z)
-            zc, y = self.cls.forward_signs(signs, self.vq.project_out)
+            zc, y = self.cls.forward_signs(signs, self.vq.project_out, self.act_dtype)
             self.last_signs = signs if self.training else None   # the train step's anomaly loss reads the bits too (train.py)
+        elif self.codebook_impl == "VQ":
+            # nearest-neighbour codebook variant: an f32 lookup (like LFQ's f32 projection) on the widened tokens; `anomaly` is
+            # the code index, z_q the selected code vectors with the straight-through gradient (VQ.py:897-1112)
+            N, V, T, H, W, E = z.shape
+            z_q, anomaly, loss_z_q = self.vq(z.float().reshape(N * V, T * H * W, E))
+            z_q, anomaly, loss_z_q = z_q.reshape(N, V, T, H, W, E), anomaly.reshape(N, V, T, H, W), loss_z_q.reshape(())
+            zc, y = self.cls.forward_tokens(z_q.to(self.act_dtype))
+            self.last_signs = None
         else:
             z_q, anomaly, loss_z_q = self.vq.quantize_tokens(z)
             zc, y = self.cls.forward_tokens(z_q)

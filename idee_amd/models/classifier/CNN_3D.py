@@ -75,13 +75,13 @@ class CNN_3D(_stacked.StackedModule):
                                          self.h_b1, self.h_w2, self.h_b2, self.h_w3, self.h_b3, *self._dropout_args())
         return z, [y[:, v:v + 1] for v in range(self.in_var)]      # (N,1,H,W) each; (N,1,T/8,H,W) when T > 8, as the reference
 
-    def forward_signs(self, signs, project_out):
+    def forward_signs(self, signs, project_out, act_dtype=torch.float32):
         """The same outputs as forward_tokens(z_q) for z_q = project_out(signs): LFQ's output has rank
         codebook_dim per variable, so conv1 of every head runs on the (N,T,H,W,16)-channel sign field with
         weights folded through project_out (ops.ClassifierHeadsSigns).  signs (N,V,T,H,W,d)."""
         z, y = ops.ClassifierHeadsSigns.apply(signs, project_out.weight, project_out.bias, self.j_w1, self.j_b1, self.j_w2,
                                               self.j_b2, self.j_w3, self.j_b3, self.h_w1, self.h_b1, self.h_w2, self.h_b2,
-                                              self.h_w3, self.h_b3, *self._dropout_args())
+                                              self.h_w3, self.h_b3, *self._dropout_args(), act_dtype)
         return z, [y[:, v:v + 1] for v in range(self.in_var)]
 
     def forward(self, x):

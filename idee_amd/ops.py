@@ -111,6 +111,21 @@ def _f32c(t):
     return t.contiguous()
 
 
+def _act(t):
+    """Contiguous ACTIVATION tensor in its storage dtype: bf16 stays bf16 (the bf16 activation path, idee_hip.h
+    IDEE_DTYPE_BF16), anything else becomes f32."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    return t.contiguous()
+
+
+def _like(t, ref):
+    """t as a contiguous tensor of ref's activation dtype (gradients autograd hands in may be f32 views)."""
+    if t.dtype != ref.dtype:
+        t = t.to(ref.dtype)
+    return t.contiguous()
+
+
 # ----------------------------------------------------------------------------------------
 # PatchEmbed3D(k=1) + LN
 # ----------------------------------------------------------------------------------------
@@ -119,14 +134,16 @@ class PatchEmbedLN(torch.autograd.Function):
     Reference: PatchEmbed3D.forward, models/encoder/Swin_3D.py:473-491, encoder/CNN_3D.py:44-71."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, act_dtype=torch.float32):
+        """act_dtype: storage of the token tensor this produces (torch.float32 | torch.bfloat16)."""
         x, w = _f32c(x), _f32c(w)
         b = _f32c(b) if b is not None else None
         N, V, Cin, T, H, W = x.shape
         E = w.shape[1]
-        y = torch.empty((N, V, T, H, W, E), device=x.device, dtype=torch.float32)
-        L.call("idee_patch_embed_ln_fwd", ptr(x), ptr(w), ptr(b), ptr(y), N, V, Cin, T * H * W, E, L.stream())
+        y = torch.empty((N, V, T, H, W, E), device=x.device, dtype=act_dtype)
+        L.call("idee_patch_embed_ln_fwd", ptr(x), ptr(w), ptr(b), ptr(y), N, V, Cin, T * H * W, E, L.act_dtype(y), L.stream())
         ctx.save_for_backward(x, w, b)
+        ctx.act = act_dtype
         return y
 
     @staticmethod
@@ -134,12 +151,12 @@ class PatchEmbedLN(torch.autograd.Function):
         x, w, b = ctx.saved_tensors
         N, V, Cin, T, H, W = x.shape
         E = w.shape[1]
-        dy = _f32c(dy)
+        dy = dy.to(ctx.act).contiguous()
         dw = _zeros_like(w)
         db = _zeros_like(b) if b is not None else None
         L.call("idee_patch_embed_ln_bwd", ptr(x), ptr(w), ptr(b), ptr(dy), ptr(dw), ptr(db), N, V, Cin, T * H * W, E,
-               L.stream())
-        return None, dw, db
+               L.act_dtype(dy), L.stream())
+        return None, dw, db, None
 
 
 class StageEmbedLN(torch.autograd.Function):
@@ -215,8 +232,9 @@ class SwinBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, table, index, heads, window, shift,
                 qk_scale, path_scale=None):
-        """path_scale (N*V, 2) | None: DropPath factors (mask / keep_prob) of the attention and MLP branch per batch item."""
-        x = _f32c(x)
+        """path_scale (N*V, 2) | None: DropPath factors (mask / keep_prob) of the attention and MLP branch per batch item.
+        x may be bf16 (the bf16 activation path): y, the saved state and all token gradients then are bf16 too."""
+        x = _act(x)
         params = [_f32c(t) for t in (qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b)]
         table = _f32c(table)
         N, V, D, H, W, Cc = x.shape
@@ -224,7 +242,7 @@ class SwinBlock(torch.autograd.Function):
         Nw = ws[0] * ws[1] * ws[2]
         hd = Cc // heads
         geom = L.SwinGeom(N, V, D, H, W, Cc, heads, fc1_w.shape[1], ws[0], ws[1], ws[2], ss[0], ss[1], ss[2],
-                          float(qk_scale) if qk_scale else float(hd) ** -0.5)
+                          float(qk_scale) if qk_scale else float(hd) ** -0.5, L.act_dtype(x))
         idx = index[:Nw, :Nw].contiguous()
         dense = torch.empty((V, heads, Nw, Nw), device=x.device, dtype=torch.float32)
         L.call("idee_relpos_bias_gather", ptr(table), ptr(idx), ptr(dense), V, table.shape[1], heads, Nw, L.stream())
@@ -246,7 +264,7 @@ class SwinBlock(torch.autograd.Function):
         x, *rest = ctx.saved_tensors
         params, table, idx, dense, hs = rest[:8], rest[8], rest[9], rest[10], rest[11]
         geom = ctx.geom
-        dy = _f32c(dy)
+        dy = _like(dy, x)
         dx = torch.empty_like(x)
         dh = torch.empty_like(x)
         zs = _zeros_like_many(*params, dense, table)     # one fill for all accumulating gradient buffers
@@ -266,12 +284,15 @@ class SwinBlock(torch.autograd.Function):
 class ConvLayer:
     """One convolution of the path, described once (idee_conv_desc) and run fwd / dgrad / wgrad."""
 
-    def __init__(self, mode, B, wsets, T, H, W, Cin, Cout, xs, ys, relu, x_units=None, y_units=None):
-        """xs / ys: (sB, sT, sH, sW, sG) float strides.  x_units / y_units = (groups per unit, unit stride): two-level
-        channel groups (the joint head reads the V slices of z_q; the folded head conv writes the V slices of its output)."""
+    def __init__(self, mode, B, wsets, T, H, W, Cin, Cout, xs, ys, relu, x_units=None, y_units=None, act=torch.float32):
+        """xs / ys: (sB, sT, sH, sW, sG) element strides.  x_units / y_units = (groups per unit, unit stride): two-level
+        channel groups (the joint head reads the V slices of z_q; the folded head conv writes the V slices of its output).
+        act: activation storage (torch.float32 | torch.bfloat16) of x, y and their gradients (a Cout == 1 output stays f32)."""
         gpu, sU = x_units if x_units is not None else (0, 0)
         ygpu, ysU = y_units if y_units is not None else (0, 0)
-        self.desc = L.ConvDesc(mode, B, wsets, T, H, W, Cin, Cout, *xs, *ys, int(relu), gpu, ygpu, sU, ysU)
+        self.act = act
+        self.desc = L.ConvDesc(mode, B, wsets, T, H, W, Cin, Cout, *xs, *ys, int(relu), gpu, ygpu, sU, ysU,
+                               L.DTYPE_BF16 if act == torch.bfloat16 else L.DTYPE_F32)
         self.mode, self.B, self.wsets, self.Cin, self.Cout = mode, B, wsets, Cin, Cout
         self.ntaps = {L.CONV_K333_REPLICATE: 27, L.CONV_K233_S2_ZERO: 18, L.CONV_K133_ZERO: 9}[mode]
         self.packed_floats = L.load().idee_conv_packed_floats(C.byref(self.desc))
@@ -279,8 +300,9 @@ class ConvLayer:
 
     def pack(self, w, want_fwd=True, want_dgrad=True):
         dev = w.device
-        pf = torch.empty(self.packed_floats, device=dev, dtype=torch.float32) if want_fwd else None
-        pd = torch.empty(self.packed_floats, device=dev, dtype=torch.float32) if want_dgrad else None
+        pdt = torch.bfloat16 if (self.act == torch.bfloat16 and self.Cout != 1) else torch.float32    # bf16 fragments (idee_hip.h)
+        pf = torch.empty(self.packed_floats, device=dev, dtype=pdt) if want_fwd else None
+        pd = torch.empty(self.packed_floats, device=dev, dtype=pdt) if want_dgrad else None
         L.call("idee_conv_pack_weights", C.byref(self.desc), ptr(w), ptr(pf), ptr(pd), L.stream())
         return pf, pd
 
@@ -320,11 +342,12 @@ class ProjVar(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
-        x, w1, b1, w2, b2 = (_f32c(t) for t in (x, w1, b1, w2, b2))
+        x = _act(x)
+        w1, b1, w2, b2 = (_f32c(t) for t in (w1, b1, w2, b2))
         N, V, T, H, W, Cc = x.shape
         s = _cl_strides(T, H, W, Cc)
-        c1 = ConvLayer(L.CONV_K333_REPLICATE, N * V, V, T, H, W, Cc, Cc, s, s, True)
-        c2 = ConvLayer(L.CONV_K333_REPLICATE, N * V, V, T, H, W, Cc, Cc, s, s, False)
+        c1 = ConvLayer(L.CONV_K333_REPLICATE, N * V, V, T, H, W, Cc, Cc, s, s, True, act=x.dtype)
+        c2 = ConvLayer(L.CONV_K333_REPLICATE, N * V, V, T, H, W, Cc, Cc, s, s, False, act=x.dtype)
         p1f, p1d = c1.pack(w1)
         p2f, p2d = c2.pack(w2)
         a1 = torch.empty_like(x)
@@ -339,7 +362,7 @@ class ProjVar(torch.autograd.Function):
     def backward(ctx, dy):
         x, a1, w1, w2, p1d, p2d = ctx.saved_tensors
         c1, c2 = ctx.convs
-        dy = _f32c(dy)
+        dy = _like(dy, x)
         dw2, db2 = c2.wgrad(a1, dy, w2)
         da1 = torch.empty_like(a1)
         c2.dgrad(dy, p2d, a1, da1)              # masked by ReLU'(a1)
@@ -353,7 +376,7 @@ class ProjVar(torch.autograd.Function):
 
 def _dropout_(t, p, seed):
     """nn.Dropout's mask applied in place to a ReLU output (the 1/(1-p) factor is folded into the next conv's weights)."""
-    L.call("idee_dropout_mask_", ptr(t), t.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, L.stream())
+    L.call("idee_dropout_mask_", ptr(t), t.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, L.act_dtype(t), L.stream())
 
 
 class ClassifierHeads(torch.autograd.Function):
@@ -369,8 +392,10 @@ class ClassifierHeads(torch.autograd.Function):
     def forward(ctx, zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3, drop_p=0.0, drop_seed=0):
         """drop_p, drop_seed: nn.Dropout(drop_rate) after the first ReLU of every head (classifier/CNN_3D.py:41,53,93,133) in
         training: keep-mask in place on the activation, 1/(1-p) folded into conv2's weights."""
-        ts = [_f32c(t) for t in (zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3)]
-        zq, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3 = ts
+        zq = _act(zq)
+        act = zq.dtype
+        ts = [_f32c(t) for t in (jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3)]
+        jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3 = ts
         inv = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
         if drop_p > 0:
             jw2, hw2 = jw2 * inv, hw2 * inv
@@ -387,20 +412,20 @@ class ClassifierHeads(torch.autograd.Function):
         K = L.CONV_K233_S2_ZERO
         # joint head: channel groups of conv1's input are the V slices of zq
         j1 = ConvLayer(K, N, 1, T, H, W, V * Cc, Dj, (V * T * H * W * Cc, H * W * Cc, W * Cc, Cc, 16),
-                       _cl_strides(T1, H, W, Dj), True, x_units=(Cc // 16, T * H * W * Cc))
-        j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True)
-        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False)
-        h1 = ConvLayer(K, N * V, V, T, H, W, Cc, dim, _cl_strides(T, H, W, Cc), _cl_strides(T1, H, W, dim), True)
-        h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True)
-        h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (T3 * H * W, H * W, W, 1, 1), False)
+                       _cl_strides(T1, H, W, Dj), True, x_units=(Cc // 16, T * H * W * Cc), act=act)
+        j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True, act=act)
+        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False, act=act)
+        h1 = ConvLayer(K, N * V, V, T, H, W, Cc, dim, _cl_strides(T, H, W, Cc), _cl_strides(T1, H, W, dim), True, act=act)
+        h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True, act=act)
+        h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (T3 * H * W, H * W, W, 1, 1), False, act=act)
         convs = (j1, j2, j3, h1, h2, h3)
         weights = (jw1, jw2, jw3, hw1, hw2, hw3)
         packs = [c.pack(w) for c, w in zip(convs, weights)]
-        ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=torch.float32)
-        ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=torch.float32)
+        ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=act)
+        ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=act)
         z = torch.empty((N, 1, H, W) if T3 == 1 else (N, 1, T3, H, W), device=dev, dtype=torch.float32)
-        ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=torch.float32)
-        ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=torch.float32)
+        ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=act)
+        ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=act)
         y = torch.empty((N, V, H, W) if T3 == 1 else (N, V, T3, H, W), device=dev, dtype=torch.float32)
         j1.fwd(zq, packs[0][0], jb1, ja1)
         if drop_p > 0:
@@ -460,7 +485,9 @@ class ClassifierHeadsSigns(torch.autograd.Function):
       signs (N,V,T,H,W,D) +-1;  w_out (C,D), b_out (C): LFQ.project_out;  remaining arguments as ClassifierHeads."""
 
     @staticmethod
-    def forward(ctx, signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3, drop_p=0.0, drop_seed=0):
+    def forward(ctx, signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3, drop_p=0.0, drop_seed=0,
+                act=torch.float32):
+        """act: storage of the sign field and of the hidden activations (torch.float32 | torch.bfloat16); logits are f32."""
         ts = [_f32c(t) for t in (signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3)]
         signs, w_out, b_out, jw1, jb1, jw2, jb2, jw3, jb3, hw1, hb1, hw2, hb2, hw3, hb3 = ts
         inv = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0      # nn.Dropout after the first ReLU, as ClassifierHeads
@@ -482,30 +509,30 @@ class ClassifierHeadsSigns(torch.autograd.Function):
         dev = signs.device
         K, KP = L.CONV_K233_S2_ZERO, L.CONV_K133_ZERO
         st = L.stream()
-        sx = torch.empty((N, T1, H, W, CS), device=dev, dtype=torch.float32)
-        L.call("idee_lfq_sign_field_fwd", ptr(signs), ptr(sx), N, V, T, H * W, D, CS, st)
+        sx = torch.empty((N, T1, H, W, CS), device=dev, dtype=act)
+        L.call("idee_lfq_sign_field_fwd", ptr(signs), ptr(sx), N, V, T, H * W, D, CS, L.act_dtype(sx), st)
         jwe = torch.empty((Dj, CS, 1, 3, 3), device=dev, dtype=torch.float32)
         hwe = torch.empty((V * dim, CS, 1, 3, 3), device=dev, dtype=torch.float32)
         L.call("idee_lfq_fold_weights_fwd", ptr(jw1), ptr(w_out), ptr(b_out), ptr(jwe), Dj, V, Cc, D, CS, 0, st)
         L.call("idee_lfq_fold_weights_fwd", ptr(hw1), ptr(w_out), ptr(b_out), ptr(hwe), dim, V, Cc, D, CS, 1, st)
         sxs = _cl_strides(T1, H, W, CS)
-        j1 = ConvLayer(KP, N, 1, T1, H, W, CS, Dj, sxs, _cl_strides(T1, H, W, Dj), True)
+        j1 = ConvLayer(KP, N, 1, T1, H, W, CS, Dj, sxs, _cl_strides(T1, H, W, Dj), True, act=act)
         # the heads' conv1 writes variable v's `dim` channels into slice v of ha1 (N,V,T1,H,W,dim)
         h1 = ConvLayer(KP, N, 1, T1, H, W, CS, V * dim, sxs, (V * T1 * H * W * dim, H * W * dim, W * dim, dim, 16), True,
-                       y_units=(dim // 16, T1 * H * W * dim))
-        j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True)
-        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False)
-        h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True)
-        h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (T3 * H * W, H * W, W, 1, 1), False)
+                       y_units=(dim // 16, T1 * H * W * dim), act=act)
+        j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True, act=act)
+        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False, act=act)
+        h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True, act=act)
+        h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (T3 * H * W, H * W, W, 1, 1), False, act=act)
         convs = (j1, j2, j3, h1, h2, h3)
         weights = (jwe, jw2, jw3, hwe, hw2, hw3)
         need_dx = ctx.needs_input_grad[0]
         packs = [c.pack(w, want_dgrad=(need_dx or i not in (0, 3))) for i, (c, w) in enumerate(zip(convs, weights))]
-        ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=torch.float32)
-        ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=torch.float32)
+        ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=act)
+        ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=act)
         z = torch.empty((N, 1, H, W) if T3 == 1 else (N, 1, T3, H, W), device=dev, dtype=torch.float32)
-        ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=torch.float32)
-        ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=torch.float32)
+        ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=act)
+        ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=act)
         y = torch.empty((N, V, H, W) if T3 == 1 else (N, V, T3, H, W), device=dev, dtype=torch.float32)
         j1.fwd(sx, packs[0][0], jb1, ja1)
         if drop_p > 0:
@@ -561,11 +588,11 @@ class ClassifierHeadsSigns(torch.autograd.Function):
             j1.dgrad(dja1, pd[0], None, dsx)
             h1.dgrad(dha1, pd[3], None, dsx, accumulate=True)
             dsigns = torch.empty((N, V, T, H, W, D), device=dev, dtype=torch.float32)
-            L.call("idee_lfq_sign_field_bwd", ptr(dsx), ptr(dsigns), N, V, T, H * W, D, CS, st)
+            L.call("idee_lfq_sign_field_bwd", ptr(dsx), ptr(dsigns), N, V, T, H * W, D, CS, L.act_dtype(dsx), st)
         if ctx.inv != 1.0:      # conv2 ran with weights * 1/(1-p)
             djw2, dhw2 = djw2 * ctx.inv, dhw2 * ctx.inv
         return (dsigns, dw_out, db_out, djw1, djb1.reshape(-1), djw2, djb2.reshape(-1), djw3, djb3.reshape(-1), dhw1,
-                dhb1.reshape(V, dim), dhw2, dhb2, dhw3, dhb3, None, None)
+                dhb1.reshape(V, dim), dhw2, dhb2, dhw3, dhb3, None, None, None)
 
 
 # ----------------------------------------------------------------------------------------
@@ -578,7 +605,8 @@ class LFQQuantize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, w_in, b_in, w_out, b_out, codebook_size, training, w_entropy, gamma, w_commit, want_signs=False):
-        z, w_in, b_in, w_out, b_out = (_f32c(t) for t in (z, w_in, b_in, w_out, b_out))
+        z = _act(z)       # bf16 tokens stay bf16 (z_q and dz then are bf16 too); projections, bits and statistics are f32
+        w_in, b_in, w_out, b_out = (_f32c(t) for t in (w_in, b_in, w_out, b_out))
         E = z.shape[-1]
         M = z.numel() // E
         dev = z.device
@@ -589,7 +617,7 @@ class LFQQuantize(torch.autograd.Function):
         D = max(1, codebook_size.bit_length() - 1)
         signs = torch.empty(z.shape[:-1] + (D,), device=dev, dtype=torch.float32) if want_signs else None
         L.call("idee_lfq_fwd", ptr(z), ptr(w_in), ptr(b_in), ptr(w_out), ptr(b_out), ptr(zq), ptr(idx), ptr(stats), ptr(ws),
-               ptr(signs), M, E, codebook_size, int(training), w_entropy, gamma, w_commit, L.stream())
+               ptr(signs), M, E, codebook_size, int(training), w_entropy, gamma, w_commit, L.act_dtype(z), L.stream())
         ctx.save_for_backward(z, w_in, b_in, w_out, stats)
         ctx.cfg = (M, E, codebook_size, w_entropy, gamma, w_commit)
         ctx.mark_non_differentiable(idx)
@@ -599,14 +627,14 @@ class LFQQuantize(torch.autograd.Function):
     def backward(ctx, dzq, _didx, dloss, dsigns=None):
         z, w_in, b_in, w_out, stats = ctx.saved_tensors
         M, E, K, w_entropy, gamma, w_commit = ctx.cfg
-        dzq = _f32c(dzq) if dzq is not None else None      # None: no dense consumer of z_q (its users read the signs)
+        dzq = _like(dzq, z) if dzq is not None else None   # None: no dense consumer of z_q (its users read the signs)
         gl = _f32c(dloss).reshape(1) if dloss is not None else torch.zeros(1, device=z.device)
         dz = torch.empty_like(z)
         dw_in, db_in, dw_out = _zeros_like_many(w_in, b_in, w_out)
         db_out = _zeros(E, z.device)
         dsigns = _f32c(dsigns) if dsigns is not None else None
         L.call("idee_lfq_bwd", ptr(z), ptr(dzq), ptr(w_in), ptr(b_in), ptr(w_out), ptr(stats), ptr(gl), ptr(dsigns), ptr(dz),
-               ptr(dw_in), ptr(db_in), ptr(dw_out), ptr(db_out), M, E, K, w_entropy, gamma, w_commit, L.stream())
+               ptr(dw_in), ptr(db_in), ptr(dw_out), ptr(db_out), M, E, K, w_entropy, gamma, w_commit, L.act_dtype(z), L.stream())
         return dz, dw_in, db_in, dw_out, db_out, None, None, None, None, None, None
 
 

@@ -65,8 +65,13 @@ class _TrainStep:
             if parallel.world_size() > 1:
                 l_anom = l_anom * parallel.global_anomaly_scale(den)
             return l_anom
-        vq0 = ops.lfq_code_vectors(self.code0, vq.project_out.weight, vq.project_out.bias, vq.codebook_size)
+        if getattr(self.model, "codebook_impl", "LFQ") == "VQ":       # nearest-neighbour variant: code 0 of the codebook itself
+            vq0 = vq.indices_to_codes(self.code0).detach().reshape(-1).contiguous()
+        else:
+            vq0 = ops.lfq_code_vectors(self.code0, vq.project_out.weight, vq.project_out.bias, vq.codebook_size)
         zq_tokens = z_q.permute(0, 1, 3, 4, 5, 2)
+        if zq_tokens.dtype != torch.float32:       # the dense loss kernel reads f32 (bf16 storage + IDEE_SIGN_FIELD=0 only)
+            zq_tokens = zq_tokens.float()
         l_anom, den = ops.AnomalyL1.apply(zq_tokens if zq_tokens.is_contiguous() else zq_tokens.contiguous(),
                                           mask_loss.float(), mask_valid_t.float() if mask_valid_t is not None else None, vq0)
         if parallel.world_size() > 1:      # global-batch normalisation

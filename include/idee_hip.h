@@ -34,6 +34,13 @@ typedef void* idee_stream_t; /* hipStream_t */
 
 enum { IDEE_OK = 0, IDEE_ERR_INVALID_ARG = 1, IDEE_ERR_UNSUPPORTED = 2, IDEE_ERR_LAUNCH = 3 };
 
+/* Activation storage of the tensors that travel between the fused units (tokens, conv inputs / outputs and their
+ * gradients): f32 (the reference's arithmetic, default) or bf16 (BASELINE config #4: "bf16 activations/GEMMs with fp32
+ * accumulate and fp32 LFQ").  Under IDEE_DTYPE_BF16 every activation pointer of a call that carries an `act_dtype` field or
+ * argument addresses bf16 elements (strides stay in ELEMENTS), GEMM-shaped work runs on v_mfma_f32_16x16x32_bf16 with f32
+ * accumulation, and parameters, biases, parameter gradients, LFQ's projections, logits and losses stay f32. */
+enum { IDEE_DTYPE_F32 = 0, IDEE_DTYPE_BF16 = 1 };
+
 const char* idee_version(void);
 const char* idee_last_error(void);
 /* IDEE_OK iff HIP device `dev` is a gfx950. */
@@ -47,10 +54,11 @@ int idee_check_device(int dev);
  *   y (N, V, L, E)
  * bwd: dw (V, E, Cin), db (V, E) | NULL accumulate.  No dx: x is the model input.
  * ---------------------------------------------------------------------------------------- */
-int idee_patch_embed_ln_fwd(const float* x, const float* w, const float* b, float* y, int N, int V, int Cin, long L,
-                            int E, idee_stream_t stream);
-int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const float* dy, float* dw, float* db, int N,
-                            int V, int Cin, long L, int E, idee_stream_t stream);
+/* act_dtype: storage of y / dy (IDEE_DTYPE_*); x is the f32 model input */
+int idee_patch_embed_ln_fwd(const float* x, const float* w, const float* b, void* y, int N, int V, int Cin, long L,
+                            int E, int act_dtype, idee_stream_t stream);
+int idee_patch_embed_ln_bwd(const float* x, const float* w, const float* b, const void* dy, float* dw, float* db, int N,
+                            int V, int Cin, long L, int E, int act_dtype, idee_stream_t stream);
 
 /* The same PatchEmbed3D (patch (1,1,1), bias, non-affine LayerNorm) BETWEEN two Swin stages of different width — BasicLayer
  * builds it when in_dim != dim (models/encoder/Swin_3D.py:414-419, forward :473-491).  Input is already channels-last tokens.
@@ -77,6 +85,9 @@ typedef struct {
   int wd, wh, ww; /* window (clamped) */
   int sd, sh, sw; /* shift (clamped) */
   float scale;    /* qk scale: head_dim^-0.5 unless overridden (Swin_3D.py:113) */
+  int act_dtype;  /* IDEE_DTYPE_F32 | IDEE_DTYPE_BF16: storage of x, y, h_save, dy, dx, dh_workspace.  BF16: the linear layers,
+                     P.V and the token-reduction weight-gradient GEMMs run on v_mfma_f32_16x16x32_bf16 with one-piece bf16
+                     operands (f32 accumulate); LayerNorm, softmax, GELU and the attention scores stay f32 */
 } idee_swin_geom;
 
 typedef struct {
@@ -94,11 +105,11 @@ typedef struct { /* all accumulate */
 } idee_swin_grads;
 
 /* h_save (same shape as x) | NULL: the block state before the MLP (x + attention), which the backward needs. */
-int idee_swin_block_fwd(const float* x, float* y, float* h_save, const idee_swin_params* p, const idee_swin_geom* g,
+int idee_swin_block_fwd(const void* x, void* y, void* h_save, const idee_swin_params* p, const idee_swin_geom* g,
                         idee_stream_t stream);
 /* two launches: MLP + norm2 (h_saved, dy -> dh_workspace), then attention + norm1 (x, dh_workspace -> dx).
  * dh_workspace: same shape as x. */
-int idee_swin_block_bwd(const float* x, const float* h_saved, const float* dy, float* dx, float* dh_workspace,
+int idee_swin_block_bwd(const void* x, const void* h_saved, const void* dy, void* dx, void* dh_workspace,
                         const idee_swin_params* p, const idee_swin_grads* d, const idee_swin_geom* g, idee_stream_t stream);
 
 /* relative_position_bias_table[relative_position_index] (Swin_3D.py:158-162):
@@ -148,28 +159,32 @@ typedef struct {
    * gpu <= 0 means one level (g * sG).  The joint head reads z_q (N,V,T,H,W,C): gpu = C/16, sU = T*H*W*C, sG = 16. */
   int x_gpu, y_gpu;
   long x_sU, y_sU;
+  /* IDEE_DTYPE_F32 | IDEE_DTYPE_BF16: storage of x, y, dy, dx, relu_ref, addend (a Cout == 1 output and its gradient stay
+   * f32: logits).  BF16: the packed weight buffers hold bf16 (same element count; Cout == 1: f32 as before), bias, dw_packed
+   * and dbias stay f32; Cout must be a multiple of 16 or the streaming Cout == 1 case. */
+  int act_dtype;
 } idee_conv_desc;
 
 /* floats in a packed (fragment-ordered) weight buffer / in a packed weight-gradient buffer */
 long idee_conv_packed_floats(const idee_conv_desc* d);
 long idee_conv_wgrad_floats(const idee_conv_desc* d);
 /* w: reference layout (wsets, Cout, Cin, kt, kh, kw) -> fragment order for fwd and/or dgrad */
-int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, float* packed_fwd, float* packed_dgrad,
+int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, void* packed_fwd, void* packed_dgrad,
                            idee_stream_t stream);
 /* bias: (wsets, Cout) | NULL */
-int idee_conv_fwd(const idee_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+int idee_conv_fwd(const idee_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
                   idee_stream_t stream);
 /* dx = conv^T(dy) [* (relu_ref > 0) if relu_ref != NULL; same layout as x]; accumulate != 0: dx += ...
  * accumulate == 0: dx need not be initialised (REPLICATE mode: the two edge columns, which are accumulated with atomics,
  * are cleared by the call itself); accumulate != 0: dx holds the addend (e.g. a residual gradient). */
-int idee_conv_dgrad(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
-                    float* dx, int accumulate, idee_stream_t stream);
+int idee_conv_dgrad(const idee_conv_desc* d, const void* dy, const void* w_packed_dgrad, const void* relu_ref,
+                    void* dx, int accumulate, idee_stream_t stream);
 /* dx = addend + conv^T(dy) [masked like idee_conv_dgrad]: the shortcut gradient of a residual unit added without a copy.
  * addend has dx's layout and may be dx itself (== accumulate) or NULL (== plain). */
-int idee_conv_dgrad_add(const idee_conv_desc* d, const float* dy, const float* w_packed_dgrad, const float* relu_ref,
-                        const float* addend, float* dx, idee_stream_t stream);
+int idee_conv_dgrad_add(const idee_conv_desc* d, const void* dy, const void* w_packed_dgrad, const void* relu_ref,
+                        const void* addend, void* dx, idee_stream_t stream);
 /* dw_packed (wsets, taps, Cin, CoutPad) and dbias (wsets, CoutPad) | NULL accumulate */
-int idee_conv_wgrad(const idee_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
+int idee_conv_wgrad(const idee_conv_desc* d, const void* x, const void* dy, float* dw_packed, float* dbias,
                     idee_stream_t stream);
 /* packed weight gradient -> reference layout (wsets, Cout, Cin, kt, kh, kw) (overwrites) */
 int idee_conv_unpack_wgrad(const idee_conv_desc* d, const float* dw_packed, float* dw, idee_stream_t stream);
@@ -188,7 +203,7 @@ int idee_ln_relu_res_bwd(const float* c, const float* gamma, const float* beta, 
 
 /* nn.Dropout after the first ReLU of the classifier heads (classifier/CNN_3D.py:41,53): x <- x * keep-mask IN PLACE (the caller
  * folds 1 / (1 - p) into the next convolution's weights); element i keeps iff hash(seed, i) >= p * 2^32.  n % 4 == 0. */
-int idee_dropout_mask_(float* x, long n, float p, uint64_t seed, idee_stream_t stream);
+int idee_dropout_mask_(void* x, long n, float p, uint64_t seed, int act_dtype, idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Lookup-free quantisation with projections (dim -> log2 K -> dim), straight-through gradient,
@@ -203,13 +218,15 @@ long idee_lfq_workspace_floats(long M, int codebook_size);
 /* signs (M, D) | NULL: the +-1 code bits per token; dsigns (M, D) | NULL: an additional gradient on them (straight-through),
  * coming from consumers that read the sign field instead of z_q (the rank-d classifier input and anomaly loss below).
  * dzq | NULL: NULL when z_q has no dense consumer (every gradient arrives through dsigns): the 64-byte-per-token read is skipped. */
-int idee_lfq_fwd(const float* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out, float* zq,
+/* act_dtype: storage of the token tensors z, zq, dz, dzq (IDEE_DTYPE_*); the projections, the code bits, the statistics and
+ * every parameter gradient are f32 in either case ("fp32 LFQ") */
+int idee_lfq_fwd(const void* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out, void* zq,
                  int64_t* indices, float* stats, float* workspace, float* signs, long M, int E, int codebook_size,
-                 int training, float w_entropy, float gamma, float w_commit, idee_stream_t stream);
-int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const float* b_in, const float* w_out,
-                 const float* stats, const float* gloss, const float* dsigns, float* dz, float* dw_in, float* db_in,
+                 int training, float w_entropy, float gamma, float w_commit, int act_dtype, idee_stream_t stream);
+int idee_lfq_bwd(const void* z, const void* dzq, const float* w_in, const float* b_in, const float* w_out,
+                 const float* stats, const float* gloss, const float* dsigns, void* dz, float* dw_in, float* db_in,
                  float* dw_out, float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma, float w_commit,
-                 idee_stream_t stream);
+                 int act_dtype, idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rank-d classifier input (algebraic refactoring; exact in real arithmetic, disclosed in DESIGN.md):
@@ -221,8 +238,9 @@ int idee_lfq_bwd(const float* z, const float* dzq, const float* w_in, const floa
  *   fold: w (Co, V*C, 2,3,3) joint | (V, Co, C, 2,3,3) per_var -> weff (rows, CP, 1,3,3), rows = Co | V*Co;
  *         bwd: dw overwritten, dw_out (C,D) and db_out (C) accumulate.
  * ---------------------------------------------------------------------------------------- */
-int idee_lfq_sign_field_fwd(const float* signs, float* sp, int N, int V, int T, long HW, int D, int CP, idee_stream_t stream);
-int idee_lfq_sign_field_bwd(const float* dsp, float* dsigns, int N, int V, int T, long HW, int D, int CP, idee_stream_t stream);
+/* act_dtype: storage of the sign field sp / its gradient dsp (+-1, 0 and 1 are exact in bf16) */
+int idee_lfq_sign_field_fwd(const float* signs, void* sp, int N, int V, int T, long HW, int D, int CP, int act_dtype, idee_stream_t stream);
+int idee_lfq_sign_field_bwd(const void* dsp, float* dsigns, int N, int V, int T, long HW, int D, int CP, int act_dtype, idee_stream_t stream);
 int idee_lfq_fold_weights_fwd(const float* w, const float* w_out, const float* b_out, float* weff, int Co, int V, int C, int D,
                               int CP, int per_var, idee_stream_t stream);
 int idee_lfq_fold_weights_bwd(const float* dweff, const float* w, const float* w_out, const float* b_out, float* dw,
