@@ -621,6 +621,9 @@ class LFQQuantize(torch.autograd.Function):
         ctx.save_for_backward(z, w_in, b_in, w_out, stats)
         ctx.cfg = (M, E, codebook_size, w_entropy, gamma, w_commit)
         ctx.mark_non_differentiable(idx)
+        # an output nobody differentiates (z_q in a train step whose classifier and anomaly loss read the code bits) must reach
+        # backward as None, not as a materialised zero tensor: that is what lets idee_lfq_bwd skip the dense d z_q stream
+        ctx.set_materialize_grads(False)
         return zq, idx, stats[0], signs
 
     @staticmethod

@@ -15,6 +15,34 @@ import re
 import sys
 
 
+def pretty(k):
+    """Kernel name as written in the sources.  rocprofv3 demangles most names; those with a bf16 template argument (DF16b, which
+    its demangler does not know) arrive mangled: _ZN12_GLOBAL__N_1<len><name>I<literal args>E... -> name<32, 2, true, bf16>."""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", k)
+    if m:
+        n = int(m.group(1))
+        start = m.end()
+        name, rest = k[start:start + n], k[start + n:]
+        args = []
+        if rest.startswith("I"):
+            i = 1
+            while i < len(rest) and rest[i] != "E":
+                t = re.match(r"L([ib])(n?\d+)E", rest[i:])
+                if t:
+                    v = t.group(2).replace("n", "-")
+                    args.append(v if t.group(1) == "i" else ("true" if v == "1" else "false"))
+                    i += t.end()
+                elif rest.startswith("DF16b", i):
+                    args.append("bf16"); i += 5
+                elif rest[i] == "f":
+                    args.append("float"); i += 1
+                else:
+                    break
+        return name + ("<" + ", ".join(args) + ">" if args else "")
+    name = re.sub(r"\(anonymous namespace\)::", "", k)
+    return re.sub(r"\(.*", "", name).replace("void ", "")
+
+
 def load(path, counter):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -28,10 +56,9 @@ def main(fcsv, wcsv, out, steps="3", commit="?"):
     f, w = load(fcsv, "FETCH_SIZE"), load(wcsv, "WRITE_SIZE")
     rows = []
     for k in f:
-        if "anonymous" not in k:
+        if "anonymous" not in k and not k.startswith("_ZN12_GLOBAL__N_1"):
             continue
-        name = re.sub(r"\(anonymous namespace\)::", "", k)
-        name = re.sub(r"\(.*", "", name).replace("void ", "")
+        name = pretty(k)
         fv, wv, dur = [x[0] for x in f[k]], [x[0] for x in w.get(k, [(0, 0)])], [x[1] for x in f[k]]
         fetch, write = sum(fv) / len(fv) * 1024 * 2, sum(wv) / len(wv) * 1024
         rows.append(dict(kernel=name, launches=len(fv), launches_per_step=len(fv) / steps, avg_us_profiled=sum(dur) / len(dur) / 1e3,

@@ -335,17 +335,22 @@ def test_config4_bf16_forward_matches_oracle_on_crop(c4_forward, c4_forward_bf16
     keep = (~flips).unsqueeze(2).expand(-1, -1, 32, -1, -1, -1)
     zq_err = (R(fb["zq"]) - zqo[..., rs, cs]).abs()[keep]
     assert float(zq_err.max()) <= 2.0 ** -7 * float(zqo.abs().max()) + 1e-6
-    bad_px = flips.any(dim=(1, 2)).float().unsqueeze(1)
-    ok_px = (F.max_pool2d(bad_px, 7, 1, 3) == 0)
-    print(f"[config 4 bf16/{crop}] classifier pixels compared {int(ok_px.sum())}/{ok_px.numel()}")
-    assert float(ok_px.float().mean()) >= 0.5
-    zk = ok_px.unsqueeze(2).expand(-1, -1, 2, -1, -1)
-    zr = zo[..., rs, cs]
+    # classifier: with ~0.2 % of the 6 x 16 tokens of a pixel column flipped, no 7x7 neighbourhood is flip-free, so the logits are
+    # compared against the ORACLE's classifier applied to the codes THIS run chose (codes -> project_out -> classifier, f32):
+    # that isolates the classifier's own bf16 error from the (counted) flips upstream.  Crop margins exceed its 3-pixel radius.
+    an_crop = fb["an"][..., r0:r1, c0:c1]                                            # our codes on the whole crop (N,V,T,h,w)
+    zq_ours = O.lfq_indices_to_codes(an_crop.reshape(-1), f["sd"], ocfg).reshape(*an_crop.shape, 32).permute(0, 1, 5, 2, 3, 4)
+    with torch.no_grad():
+        zo2, yo2 = O.classifier(zq_ours, f["sd"])
+    zr = zo2[..., rs, cs]
     scale = float(zr.abs().max())
-    assert float(((R(fb["z"]) - zr).abs() * zk).max()) <= 5e-2 * scale + 1e-3
-    yr = torch.stack(yo)[..., rs, cs]
-    yk = zk.unsqueeze(0).expand(6, -1, -1, -1, -1, -1)
-    assert float(((R(fb["y"]) - yr).abs() * yk).max()) <= 5e-2 * float(yr.abs().max()) + 1e-3
+    zerr = float((R(fb["z"]) - zr).abs().max())
+    yr = torch.stack(yo2)[..., rs, cs]
+    yerr = float((R(fb["y"]) - yr).abs().max())
+    print(f"[config 4 bf16/{crop}] logits vs oracle classifier on the same codes: joint max err {zerr:.3e} (scale {scale:.3e}), "
+          f"heads max err {yerr:.3e} (scale {float(yr.abs().max()):.3e})")
+    assert zerr <= 2e-2 * scale + 1e-3
+    assert yerr <= 2e-2 * float(yr.abs().max()) + 1e-3
 
 
 @pytest.mark.parametrize("impl", ["LFQ", "VQ"])
