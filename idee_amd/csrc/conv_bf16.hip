@@ -80,13 +80,19 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a) {
   bfp addend = reinterpret_cast<bfp>(a.addend);
   bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
   const int Gk = a.Gk;
+  // Work order (L2 locality: every source row segment is wanted by 3 x 3 (t, h) neighbours): a workgroup takes a UNIT = 4
+  // consecutive output rows (one per wave) of one 64-pixel column tile and walks the output frames t = 0 .. To - 1 with them,
+  // so the rows h - 1 .. h + 4 of a frame are fetched once for its 4 waves and stay in L2 for the two following frames
+  // (tiles dealt round-robin to the waves re-fetched every tap from the fabric: 10 GB for a 1 GB input, profiles r03).
   const long wtiles = (a.Wo + 63) / 64;
-  const long tiles = (long)a.To * a.Ho * wtiles;
+  const long hgroups = (a.Ho + 3) / 4;
+  const long units = hgroups * wtiles;
 
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
-    const int wt = (int)(tile % wtiles);
-    const long r = tile / wtiles;
-    const int h = (int)(r % a.Ho), t = (int)(r / a.Ho);
+  for (long un = blockIdx.x; un < units; un += gridDim.x)
+   for (int t = 0; t < a.To; ++t) {
+    const int wt = (int)(un % wtiles);
+    const int h = (int)(un / wtiles) * 4 + wave;
+    if (h >= a.Ho) continue;
     const int w0 = wt * 64;
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a) {
         stx4<bf16_t>(out + o, v);
       }
     }
-  }
+   }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -333,10 +339,10 @@ template <int MODE>
 int launch_conv_bf16(ConvArgs& a, hipStream_t stream) {
   const int NT = pick_nt(a.GnTot);
   const int gz = a.GnTot / NT;
-  const long tiles = (long)a.To * a.Ho * ((a.Wo + 63) / 64);
-  long gx = ((long)kCUs * 8) / ((long)a.B * gz);        // ~8 workgroups per CU in total: every wave loops over its tiles
+  const long units = (long)((a.Ho + 3) / 4) * ((a.Wo + 63) / 64);      // (4-row group, 64-pixel column tile); a workgroup walks t
+  long gx = ((long)kCUs * 8) / ((long)a.B * gz);        // ~8 workgroups per CU in total: every workgroup loops over its units
   if (gx < 1) gx = 1;
-  if (gx > (tiles + 3) / 4) gx = (tiles + 3) / 4;
+  if (gx > units) gx = units;
   const dim3 grid((unsigned)gx, a.B, gz);
 #define LCB(NT_) hipLaunchKernelGGL((conv_bf16_kernel<MODE, NT_>), grid, dim3(256), 0, stream, a)
   if (NT == 6) LCB(6); else if (NT == 3) LCB(3); else if (NT == 2) LCB(2); else LCB(1);

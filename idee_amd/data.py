@@ -158,9 +158,15 @@ class ERA5ClipDataset(torch.utils.data.Dataset):
 
 
 class PrefetchLoader:
-    """Batches of (x_d (B,V,1,T,H,W) f32, mask_extreme (B,H,W) f32, mask_extreme_loss (B,H,W) f32, timestep (B,) int64)
-    on `device`, produced `depth` batches ahead by a worker thread through pinned buffers and a side stream.
-    rank / world shard the (shuffled) index list like a DistributedSampler with drop_last over ranks."""
+    """Device batches produced `depth` batches ahead by a worker thread through pinned buffers and a side stream.
+    rank / world shard the (shuffled) index list like a DistributedSampler with drop_last over ranks.  Two item layouts
+    (detected from the dataset's first item):
+      synthetic  (SyntheticClipDataset items) -> (x_d (B,V,1,T,H,W) f32, mask_extreme (B,H,W), mask_extreme_loss (B,H,W),
+                 timestep (B,) int64)                      — what train_synthetic.py:171-177 moves to the device;
+      era5       (ERA5ClipDataset 8-tuples)   -> (x_d (B,V,2,T,H,W) f32, mask_drought (B,H,W), mask_drought_loss (B,H,W),
+                 mask_cold_surface (B,H,W), mask_cold_surface_loss (B,T,H,W), None)   — train_ERA5_Land.py:168-176
+    each a tuple harness.train_epoch hands to SyntheticTrainStep / ERA5TrainStep (the last element is the time step index
+    for the anomaly collector, None for ERA5 whose items carry a file name instead)."""
 
     def __init__(self, dataset, batch_size, device, shuffle=True, drop_last=True, seed=0, rank=0, world=1, depth=2):
         self.ds, self.bs, self.device = dataset, int(batch_size), torch.device(device)
@@ -168,6 +174,14 @@ class PrefetchLoader:
         self.epoch = 0
         self.cuda = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        first = dataset[0]
+        self.layout = "era5" if (len(first) == 8 and isinstance(first[-1], str)) else "synthetic"
+        # (index in the item, leading-dims-free shape, dtype) of every tensor of a batch
+        if self.layout == "era5":
+            self.fields = [(0, first[0].shape, torch.float32)] + [(i, first[i].shape, torch.float32) for i in (1, 2, 3, 4)]
+        else:
+            self.fields = [(0, first[0].shape, torch.float32), (3, first[3].shape, torch.float32), (4, first[4].shape, torch.float32),
+                           (6, (), torch.int64)]
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -185,23 +199,19 @@ class PrefetchLoader:
 
     def _collate(self, ids, bufs):
         items = [self.ds[int(i)] for i in ids]
-        n = len(items)
-        x, me, ml, ts = bufs
         for k, it in enumerate(items):
-            x[k].copy_(torch.from_numpy(it[0]))
-            me[k].copy_(torch.from_numpy(it[3].astype(np.float32)))
-            ml[k].copy_(torch.from_numpy(it[4].astype(np.float32)))
-            ts[k] = int(it[6][0])
-        return n
+            for buf, (src, shape, dtype) in zip(bufs, self.fields):
+                if shape == ():
+                    buf[k] = int(np.asarray(it[src]).reshape(-1)[0])
+                else:
+                    buf[k].copy_(torch.from_numpy(np.ascontiguousarray(it[src], dtype=np.float32)))
+        return len(items)
 
     def __iter__(self):
         idx = self._indices()
         nb = len(self)
-        V, _, T, H, W = self.ds[0][0].shape
-        ring = [(torch.empty((self.bs, V, 1, T, H, W), dtype=torch.float32, pin_memory=self.cuda),
-                 torch.empty((self.bs, H, W), dtype=torch.float32, pin_memory=self.cuda),
-                 torch.empty((self.bs, H, W), dtype=torch.float32, pin_memory=self.cuda),
-                 torch.empty((self.bs,), dtype=torch.int64, pin_memory=self.cuda)) for _ in range(self.depth + 1)]
+        ring = [tuple(torch.empty((self.bs,) + tuple(shape), dtype=dtype, pin_memory=self.cuda) for _, shape, dtype in self.fields)
+                for _ in range(self.depth + 1)]
         free, ready = queue.Queue(), queue.Queue(maxsize=self.depth)
         for r in range(len(ring)):
             free.put(r)
@@ -236,10 +246,13 @@ class PrefetchLoader:
                 if isinstance(got, BaseException):
                     raise got
                 r, dev, ev = got
+                if self.layout == "era5":
+                    dev = dev + (None,)
                 if ev is not None:
                     torch.cuda.current_stream(self.device).wait_event(ev)     # the training stream waits for THIS batch only
                     for t in dev:
-                        t.record_stream(torch.cuda.current_stream(self.device))
+                        if t is not None:
+                            t.record_stream(torch.cuda.current_stream(self.device))
                     ev.synchronize()                                          # the pinned buffer may be refilled now
                 free.put(r)
                 yield dev

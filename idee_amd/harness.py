@@ -214,7 +214,10 @@ def train_epoch(step, batches, evaluator=None, collector=None):
         losses.append(total)
         if evaluator is not None:
             if len(masks) == 4:          # real data: valid = max(1 - cold surface, 0), joint logits' first map
-                evaluator.update(outs[0][:, 0], masks[0], (1.0 - masks[2].float()).clamp_min_(0.0))
+                pred = outs[0][:, 0]     # (N,H,W), or (N,T3,H,W) at T = 16 where the classifier keeps T3 = 2 temporal maps
+                if pred.dim() == 4:      # the loss scores every slice against the same target and averages (train.py); so does
+                    pred = pred.mean(1)  # the metric: the mean logit over the T3 slices
+                evaluator.update(pred, masks[0], (1.0 - masks[2].float()).clamp_min_(0.0))
             else:
                 evaluator.update(outs[0], masks[0].unsqueeze(1))
         if collector is not None and timestep is not None:

@@ -26,8 +26,8 @@ class CNN_3D(_stacked.StackedModule):
         for l, (ci, co) in enumerate(zip(self.in_channels, self.out_channels)):
             has_ds = ci != co                    # encoder/CNN_3D.py:112-118
             if has_ds:
-                if l != 0:
-                    raise NotImplementedError("idee_amd CNN_3D: a width change after the first block is not built")
+                if l != 0 and not (ci in (16, 32) and co in (16, 32)):
+                    raise NotImplementedError("idee_amd CNN_3D: a width change after the first block is built for widths 16 and 32")
                 self.register_parameter(f"l{l}_ds_w", nn.Parameter(torch.empty(V, co, ci)))
             for u in (1, 2):
                 self.register_parameter(f"l{l}_conv{u}_w", nn.Parameter(torch.empty(V, co, co, 3, 3, 3)))
@@ -94,8 +94,10 @@ class CNN_3D(_stacked.StackedModule):
             raise ValueError(f"CNN_3D: expected (N,{self.in_vars},{self.in_channels[0]},T,H,W), got {tuple(x.shape)}")
         t = None
         for l, ci, co, has_ds in self._layers:
-            if has_ds:
+            if has_ds and l == 0:
                 t = ops.PatchEmbedLN.apply(x, getattr(self, f"l{l}_ds_w"), None)
+            elif has_ds:      # a width change between blocks: the same bias-free 1x1x1 conv + non-affine LN on tokens (:112-118)
+                t = ops.StageEmbedLN.apply(t, getattr(self, f"l{l}_ds_w"), None)
             elif l == 0:
                 raise NotImplementedError("idee_amd CNN_3D: in_channels == out_channels[0] (no patch embedding) is not built")
             for u in (1, 2):

@@ -166,7 +166,9 @@ class StageEmbedLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        """b may be None: the CNN_3D encoder's downsample has no bias (encoder/CNN_3D.py:24-38, :112-118)."""
+        x, w = _f32c(x), _f32c(w)
+        b = _f32c(b) if b is not None else None
         N, V, T, H, W, Cin = x.shape
         E = w.shape[1]
         y = torch.empty((N, V, T, H, W, E), device=x.device, dtype=torch.float32)
@@ -181,7 +183,10 @@ class StageEmbedLN(torch.autograd.Function):
         E = w.shape[1]
         dy = _f32c(dy)
         dx = torch.empty_like(x)
-        dw, db = _zeros_like_many(w, b)
+        if b is not None:
+            dw, db = _zeros_like_many(w, b)
+        else:
+            dw, db = _zeros_like(w), None
         L.call("idee_stage_embed_ln_bwd", ptr(x), ptr(w), ptr(b), ptr(dy), ptr(dx), ptr(dw), ptr(db), N * V, V, Cin, T * H * W, E,
                L.stream())
         return dx, dw, db

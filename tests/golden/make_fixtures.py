@@ -148,6 +148,28 @@ if __name__ == "__main__" and "--hier-only" in sys.argv:
     fx_swin_hier("32_16", (32, 16), 1210)
 
 
+def fx_cnn_hier(tag, out_channels, seed):
+    """A CNN_3D encoder whose width changes after the first block (conv_block builds a bias-free PatchEmbed3D(in -> out) + LN as
+    its `downsample`, encoder/CNN_3D.py:112-118): whole encoder, forward + every gradient."""
+    enc = ref_cnn.CNN_3D(in_vars=2, in_channels=1, out_channels=list(out_channels))
+    rerandomise(enc, seed)
+    x = rand((1, 2, 1, 4, 6, 10), seed + 1)
+    with relu_record() as rec:
+        y = enc(x)
+    assert rec.ties() == 0, f"cnn_hier_{tag}: seed {seed} has a ReLU tie; pick another seed"
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x, y=y.detach(), r=r, out_channels=np.array(out_channels))
+    out.update(sd_arrays(enc))
+    out.update({"grad/" + k: p.grad for k, p in enc.named_parameters()})
+    save("cnn_hier_" + tag, **out)
+
+
+if __name__ == "__main__" and "--cnnhier-only" in sys.argv:
+    fx_cnn_hier("16_32", (16, 32), 1500)
+    fx_cnn_hier("32_16", (32, 16), 1510)
+
+
 def fx_patch_embed(tag, cls, cin, seed):
     pe = cls(patch_size=(1, 1, 1), in_chans=cin, embed_dim=16, norm_layer=nn.LayerNorm)
     rerandomise(pe, seed)
@@ -705,10 +727,13 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
 
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
-                                                                "--era5-only", "--hier-only", "--vqema-only", "--misc-only", "--era5items-only")):
+                                                                "--era5-only", "--hier-only", "--vqema-only", "--misc-only", "--era5items-only",
+                                                                "--cnnhier-only")):
     main()
     fx_swin_hier("16_32", (16, 32), 1200)
     fx_swin_hier("32_16", (32, 16), 1210)
+    fx_cnn_hier("16_32", (16, 32), 1500)
+    fx_cnn_hier("32_16", (32, 16), 1510)
     fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
     fx_patch_mergings()
     fx_dataset_items()

@@ -148,3 +148,49 @@ def test_era5_items_match_reference_getitem():
                     assert np.array_equal(v, ref, equal_nan=True), (is_aug, index, rs, n)
                     n_checked += 1
     assert n_checked == 7 * (3 + 18)
+
+
+def _era5_dataset(is_aug=False):
+    from conftest import GOLDEN
+    from idee_amd.data import ERA5ClipDataset
+    z = np.load(GOLDEN + "/era5_items.npz")
+    Tt = z["dynamic"].shape[2]
+    vci, tci, cold = ([z[f"{k}/{w}"] for w in range(Tt)] for k in ("vci", "tci", "cold"))
+    return ERA5ClipDataset(z["dynamic"], vci, tci, cold, z["mask_water"], z["mask_no_vegetation"], z["mean_var"], z["std_var"],
+                           delta_t=int(z["delta_t"]), threshold=26.0, alpha=0.5, nan_fill=0.0, is_aug=is_aug)
+
+
+def test_prefetch_loader_era5_layout_cpu():
+    """ERA5ClipDataset 8-tuples through the loader: batches (x_d, drought, drought_loss, cold, cold_loss, None) — exactly the
+    tensors train_ERA5_Land.py:168-176 moves to the device — equal to the stacked items."""
+    ds = _era5_dataset()
+    ld = PrefetchLoader(ds, batch_size=2, device="cpu", shuffle=False, drop_last=True)
+    assert ld.layout == "era5"
+    batches = list(ld)
+    assert len(batches) == len(ds) // 2
+    for b, batch in enumerate(batches):
+        assert len(batch) == 6 and batch[5] is None
+        items = [ds[2 * b], ds[2 * b + 1]]
+        for pos, src in enumerate((0, 1, 2, 3, 4)):
+            want = torch.from_numpy(np.stack([np.asarray(it[src], dtype=np.float32) for it in items]))
+            assert batch[pos].dtype == torch.float32 and torch.equal(batch[pos], want), (b, src)
+    V, C, T, H, W = ds[0][0].shape
+    assert batches[0][0].shape == (2, V, C, T, H, W) and batches[0][4].shape == (2, T, H, W)
+
+
+@pytest.mark.gpu
+def test_era5_dataset_loader_train_epoch_on_gpu():
+    """The real-data path end to end: ERA5ClipDataset -> PrefetchLoader -> harness.train_epoch(ERA5TrainStep) with the
+    threshold-0.35 evaluator on the valid pixels (train_ERA5_Land.py:160-229), one small epoch."""
+    from idee_amd.config import default_config
+    from idee_amd.harness import ConfusionEvaluator, train_epoch
+    from idee_amd.train import ERA5TrainStep
+    ds = _era5_dataset(is_aug=True)
+    V, C, T, H, W = ds[0][0].shape
+    ld = PrefetchLoader(ds, batch_size=2, device="cuda:0", shuffle=True, seed=3)
+    cfg = default_config(encoder="Swin_3D", in_channels=C, in_channels_dynamic=V, delta_t=T)
+    step = ERA5TrainStep(cfg, device="cuda:0")
+    ev = ConfusionEvaluator(threshold=0.35, device="cuda:0")
+    mean_loss, res = train_epoch(step, ld, evaluator=ev)
+    assert np.isfinite(mean_loss)
+    assert res is not None and res["seen_all"] > 0

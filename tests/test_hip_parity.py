@@ -850,6 +850,30 @@ def test_swin_hierarchical_encoder_golden(tag, kernel_variant):
     assert checked == len(grads)
 
 
+@pytest.mark.parametrize("tag", ["16_32", "32_16"])
+def test_cnn_hierarchical_encoder_golden(tag):
+    """CNN_3D with a width change after its first block (conv_block's downsample = bias-free PatchEmbed3D(in -> out) + LN,
+    encoder/CNN_3D.py:112-118; then two conv + LN + ReLU units and proj_var at the new width): outputs and every gradient
+    against the reference's own."""
+    from idee_amd.models.encoder.CNN_3D import CNN_3D
+    a, sd, grads = load_golden("cnn_hier_" + tag)
+    enc = CNN_3D(in_vars=2, in_channels=1, out_channels=[int(v) for v in a["out_channels"]])
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(DEV).train()
+    y = enc(dev(a["x"]))
+    close("y", y, a["y"])
+    (y * dev(a["r"])).sum().backward()
+    ps = dict(enc.named_parameters())
+    checked = 0
+    for key, name, idx in enc._key_map():
+        base = name[:-1] if name.endswith("_ds_w5") else name
+        g = ps[base].grad
+        g = g.view(*g.shape, 1, 1, 1) if name.endswith("_ds_w5") else g
+        gclose("d" + key, g if idx is None else g[idx], grads[key], rtol=2e-3, floor=2e-4)
+        checked += 1
+    assert checked == len(grads)
+
+
 @pytest.mark.parametrize("tag", ["plain", "kmeans", "expire"])
 def test_vq_ema_kmeans_expire_golden(tag):
     """VQ with the EMA codebook update, k-means initialisation and dead-code expiry against three training steps of the

@@ -252,6 +252,19 @@ def test_swin_hierarchical_encoder(tag):
     check_grads(sdl, {"encoder." + k: v for k, v in grads.items()}, atol=2e-5, rtol=1e-3)
 
 
+@pytest.mark.parametrize("tag", ["16_32", "32_16"])
+def test_cnn_hierarchical_encoder(tag):
+    """Width change after the first CNN_3D block (conv_block's bias-free PatchEmbed3D(in -> out) + LN downsample,
+    encoder/CNN_3D.py:112-118) in the oracle, against the reference's outputs and gradients."""
+    a, sd, grads = load_golden("cnn_hier_" + tag)
+    cfg = O.default_cfg(encoder="CNN_3D", in_channels_dynamic=2, en_embed_dim=[int(v) for v in a["out_channels"]])
+    sdl = leaf({"encoder." + k: v for k, v in sd.items()})
+    y = O.cnn_encoder(a["x"], sdl, cfg)
+    close(y, a["y"])
+    (y * a["r"]).sum().backward()
+    check_grads(sdl, {"encoder." + k: v for k, v in grads.items()}, atol=2e-5, rtol=1e-3)
+
+
 @pytest.mark.parametrize("tag", ["plain", "kmeans", "expire"])
 def test_vq_ema_kmeans_expire(tag):
     """EuclideanCodebook's EMA update, k-means initialisation and dead-code expiry (VQ.py:213-253, :354-377, :449-475,
