@@ -185,7 +185,18 @@ def test_era5_dataset_loader_train_epoch_on_gpu():
     from idee_amd.config import default_config
     from idee_amd.harness import ConfusionEvaluator, train_epoch
     from idee_amd.train import ERA5TrainStep
-    ds = _era5_dataset(is_aug=True)
+    # (the golden cube has delta_t = 4, below the classifier's three stride-2 temporal kernels: a seeded cube with delta_t = 8)
+    from idee_amd.data import ERA5ClipDataset
+    rs = np.random.RandomState(5)
+    V, Tt, H, W, dt = 3, 11, 12, 16, 8
+    dyn = rs.randn(V, 2, Tt, H, W).astype(np.float32)
+    dyn[rs.rand(*dyn.shape) < 0.01] = np.nan
+    vci = [rs.rand(2, H, W).astype(np.float32) * 100 for _ in range(Tt)]
+    tci = [rs.rand(2, H, W).astype(np.float32) * 100 for _ in range(Tt)]
+    cold = [(rs.rand(2, H, W) < 0.05).astype(np.float32) for _ in range(Tt)]
+    ds = ERA5ClipDataset(dyn, vci, tci, cold, (rs.rand(H, W) < 0.05).astype(np.float32), (rs.rand(H, W) < 0.05).astype(np.float32),
+                         np.zeros(V, np.float32), np.ones(V, np.float32), delta_t=dt, threshold=40.0, is_aug=True,
+                         rng=np.random.RandomState(1))
     V, C, T, H, W = ds[0][0].shape
     ld = PrefetchLoader(ds, batch_size=2, device="cuda:0", shuffle=True, seed=3)
     cfg = default_config(encoder="Swin_3D", in_channels=C, in_channels_dynamic=V, delta_t=T)
