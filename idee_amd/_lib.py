@@ -20,7 +20,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 class SwinGeom(C.Structure):
     _fields_ = [(n, _I) for n in ("N", "V", "D", "H", "W", "C", "heads", "hidden", "wd", "wh", "ww", "sd", "sh", "sw")] + [
-        ("scale", _F), ("act_dtype", _I)]
+        ("scale", _F), ("act_dtype", _I), ("drop", _F), ("attn_drop", _F), ("drop_seed", C.c_uint32)]
 
 
 _SWIN_PTRS = ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "rel_bias")

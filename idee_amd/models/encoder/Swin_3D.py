@@ -25,13 +25,6 @@ def relative_position_index(ws):
     return ((rel[0] + wd - 1) * ((2 * wh - 1) * (2 * ww - 1)) + (rel[1] + wh - 1) * (2 * ww - 1) + (rel[2] + ww - 1)).contiguous()
 
 
-def _check_no_dropout(training, **rates):
-    bad = {k: v for k, v in rates.items() if v and v > 0.0}
-    if training and bad:
-        raise NotImplementedError(f"idee_amd: element-wise dropout inside the fused Swin block {bad} is not built (reference "
-                                  "defaults are 0); stochastic depth (drop_path_rate) is")
-
-
 def drop_path_factors(n_items, rate, device, generator=None):
     """timm DropPath (Swin_3D.py:16) as per-sample factors: bernoulli(keep) / keep, two independent draws per item (the
     attention branch and the MLP branch of a block each call the block's DropPath once, :280-285)."""
@@ -165,7 +158,9 @@ class Swin_3D(_stacked.StackedModule):
     # ---- forward ----
     def forward_tokens(self, x):
         """x (N,V,C,T,H,W) -> channels-last tokens (N,V,T,H,W,E)."""
-        _check_no_dropout(self.training, drop_rate=self.drop_rate, attn_drop_rate=self.attn_drop_rate)
+        # element-wise dropout (Mlp.drop, proj_drop: drop_rate; attn_drop: attn_drop_rate; Swin_3D.py:34-41, :138-140) runs inside
+        # the fused block from a counter-based generator; one fresh seed per block and step from torch's default generator
+        use_drop = self.training and (self.drop_rate > 0.0 or self.attn_drop_rate > 0.0)
         # stochastic depth decay rule: block i of sum(depths) gets linspace(0, drop_path_rate)[i] (Swin_3D.py:562)
         dpr = torch.linspace(0, self.drop_path_rate, sum(self.depths)).tolist()
         blk = 0
@@ -192,7 +187,9 @@ class Swin_3D(_stacked.StackedModule):
                 blk += 1
                 t = ops.SwinBlock.apply(t, *(getattr(self, p + n) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w",
                                                                            "fc1_b", "fc2_w", "fc2_b", "table")),
-                                        index, self.num_heads[s], wsz, (0, 0, 0) if b % 2 == 0 else shift, self.qk_scale, ps)
+                                        index, self.num_heads[s], wsz, (0, 0, 0) if b % 2 == 0 else shift, self.qk_scale, ps,
+                                        self.drop_rate if use_drop else 0.0, self.attn_drop_rate if use_drop else 0.0,
+                                        int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if use_drop else 0)
         return ops.ProjVar.apply(t, self.pv_w1, self.pv_b1, self.pv_w2, self.pv_b2)
 
     def forward(self, x):

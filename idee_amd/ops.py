@@ -236,7 +236,7 @@ class SwinBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, table, index, heads, window, shift,
-                qk_scale, path_scale=None):
+                qk_scale, path_scale=None, drop=0.0, attn_drop=0.0, drop_seed=0):
         """path_scale (N*V, 2) | None: DropPath factors (mask / keep_prob) of the attention and MLP branch per batch item.
         x may be bf16 (the bf16 activation path): y, the saved state and all token gradients then are bf16 too."""
         x = _act(x)
@@ -247,7 +247,10 @@ class SwinBlock(torch.autograd.Function):
         Nw = ws[0] * ws[1] * ws[2]
         hd = Cc // heads
         geom = L.SwinGeom(N, V, D, H, W, Cc, heads, fc1_w.shape[1], ws[0], ws[1], ws[2], ss[0], ss[1], ss[2],
-                          float(qk_scale) if qk_scale else float(hd) ** -0.5, L.act_dtype(x))
+                          float(qk_scale) if qk_scale else float(hd) ** -0.5, L.act_dtype(x), float(drop), float(attn_drop),
+                          int(drop_seed) & 0xFFFFFFFF)
+        # drop / attn_drop: element-wise dropout rates of the block's four Dropout modules (Mlp.drop x2 + proj_drop; attn_drop),
+        # TRAINING ONLY (pass 0 in eval mode); the masks are a function of drop_seed, which the backward reuses through ctx.geom
         idx = index[:Nw, :Nw].contiguous()
         dense = torch.empty((V, heads, Nw, Nw), device=x.device, dtype=torch.float32)
         L.call("idee_relpos_bias_gather", ptr(table), ptr(idx), ptr(dense), V, table.shape[1], heads, Nw, L.stream())
@@ -280,7 +283,7 @@ class SwinBlock(torch.autograd.Function):
                L.stream())
         V, heads, Nw, _ = dense.shape
         L.call("idee_relpos_bias_scatter", ptr(ddense), ptr(idx), ptr(dtable), V, table.shape[1], heads, Nw, L.stream())
-        return (dx, *grads, dtable, None, None, None, None, None, None)
+        return (dx, *grads, dtable, None, None, None, None, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------------------

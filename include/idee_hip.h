@@ -88,6 +88,12 @@ typedef struct {
   int act_dtype;  /* IDEE_DTYPE_F32 | IDEE_DTYPE_BF16: storage of x, y, h_save, dy, dx, dh_workspace.  BF16: the linear layers,
                      P.V and the token-reduction weight-gradient GEMMs run on v_mfma_f32_16x16x32_bf16 with one-piece bf16
                      operands (f32 accumulate); LayerNorm, softmax, GELU and the attention scores stay f32 */
+  /* Element-wise dropout inside the block, training only (rates 0 otherwise): `drop` = Mlp.drop after GELU and after fc2
+   * (Swin_3D.py:34-41) and WindowAttention3D.proj_drop (:140, :176); `attn_drop` on the attention probabilities (:138, :172).
+   * The keep masks come from a counter-based generator keyed by `drop_seed` (the backward must be given the same seed);
+   * built in the exact-f32 kernels (IDEE_UNSUPPORTED under IDEE_SWIN_MATH=split or bf16 storage). */
+  float drop, attn_drop;
+  uint32_t drop_seed;
 } idee_swin_geom;
 
 typedef struct {

@@ -107,8 +107,60 @@ def compute_mask(Dp, Hp, Wp, ws, ss):
     return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
 
 
-def window_attention(xw, sd, pre, num_heads, mask=None, qk_scale=None):
-    """WindowAttention3D.forward, Swin_3D.py:145-178.  xw (B_, Nw, C)."""
+def _hash32(x):
+    """lowbias32 on uint32 arrays (numpy): the counter-based generator of the HIP Swin kernels' element-wise dropout
+    (idee_amd/csrc/swin_mfma.hip hash32).  Dropout masks are implementation-defined randomness — the reference draws them from
+    torch's Philox stream — so parity is checked GIVEN the masks: swin_block(..., dropout=swin_dropout_masks(...))."""
+    import numpy as np
+    x = x.astype(np.uint64)
+    m = np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint64)
+
+
+def window_token_ids(B, D, H, W, ws, ss):
+    """(B_, Nw) int64: global token index ((b D + d) H + h) W + w of every window position after pad / roll / partition as
+    swin_block does them; -1 at padded positions."""
+    pd, pb, pr = (-D) % ws[0], (-H) % ws[1], (-W) % ws[2]
+    ids = torch.arange(B * D * H * W, dtype=torch.float64).reshape(B, D, H, W, 1)
+    ids = F.pad(ids + 1, (0, 0, 0, pr, 0, pb, 0, pd)) - 1          # padding -> -1
+    if any(s > 0 for s in ss):
+        ids = torch.roll(ids, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+    return _partition(ids, ws).squeeze(-1).long()
+
+
+def swin_dropout_masks(seed, drop, attn_drop, B, D, H, W, C, num_heads, window_size, shift_size, hidden=None):
+    """The keep-scale masks (0 or 1/(1-p)) the HIP block applies for `seed`: dict(attn (B_, heads, Nw, Nw) [query, key], proj
+    (B,D,H,W,C), gelu (B,D,H,W,hidden), fc2 (B,D,H,W,C)); element ids and salts as in swin_mfma.hip."""
+    import numpy as np
+    hidden = hidden or 4 * C
+    ws, ss = get_window_size((D, H, W), window_size, shift_size)
+    Nw = ws[0] * ws[1] * ws[2]
+    salt = lambda site: _hash32(np.array([(int(seed) + 0x9E3779B9 * site) & 0xFFFFFFFF], dtype=np.uint64))[0]
+
+    def keep(ids, site, p):
+        thr = np.uint64(int(float(np.float32(p).astype(np.float64)) * 4294967296.0))
+        h = _hash32((ids.astype(np.uint64) & np.uint64(0xFFFFFFFF)) ^ salt(site))
+        inv = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+        return torch.from_numpy(np.where(h >= thr, inv, np.float32(0.0)).astype(np.float32))
+    ntok = B * D * H * W
+    tok = np.arange(ntok, dtype=np.uint64)
+    out = dict(proj=keep((tok[:, None] * C + np.arange(C, dtype=np.uint64)[None]), 2, drop).reshape(B, D, H, W, C),
+               gelu=keep((tok[:, None] * hidden + np.arange(hidden, dtype=np.uint64)[None]), 3, drop).reshape(B, D, H, W, hidden),
+               fc2=keep((tok[:, None] * C + np.arange(C, dtype=np.uint64)[None]), 4, drop).reshape(B, D, H, W, C))
+    wid = window_token_ids(B, D, H, W, ws, ss).numpy()                       # (B_, Nw) query token ids, -1 = padding
+    q = np.where(wid < 0, 0, wid).astype(np.uint64)
+    ids = ((q[:, None, :, None] * num_heads + np.arange(num_heads, dtype=np.uint64)[None, :, None, None]) * Nw
+           + np.arange(Nw, dtype=np.uint64)[None, None, None, :])           # (B_, heads, Nw query, Nw key)
+    out["attn"] = keep(ids, 1, attn_drop)
+    return out
+
+
+def window_attention(xw, sd, pre, num_heads, mask=None, qk_scale=None, attn_keep=None, proj_keep=None):
+    """WindowAttention3D.forward, Swin_3D.py:145-178.  xw (B_, Nw, C).  attn_keep (B_, heads, Nw, Nw) / proj_keep (B_, Nw, C):
+    keep-scale masks of attn_drop (:172) and proj_drop (:176), or None (rates 0 / eval)."""
     B_, Nw, C = xw.shape
     hd = C // num_heads
     scale = qk_scale or hd ** -0.5
@@ -124,12 +176,18 @@ def window_attention(xw, sd, pre, num_heads, mask=None, qk_scale=None):
         attn = attn.reshape(B_ // nW, nW, num_heads, Nw, Nw) + mask[None, :, None]
         attn = attn.reshape(-1, num_heads, Nw, Nw)
     attn = attn.softmax(-1)
+    if attn_keep is not None:
+        attn = attn * attn_keep
     out = (attn @ v).transpose(1, 2).reshape(B_, Nw, C)
-    return F.linear(out, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    out = F.linear(out, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    return out * proj_keep if proj_keep is not None else out
 
 
-def swin_block(x, sd, pre, num_heads, window_size, shift_size, qk_scale=None, path_scale=None):
-    """SwinTransformerBlock3D.forward, Swin_3D.py:224-287 (dropout rates 0).  x (B,D,H,W,C).
+def swin_block(x, sd, pre, num_heads, window_size, shift_size, qk_scale=None, path_scale=None, dropout=None):
+    """SwinTransformerBlock3D.forward, Swin_3D.py:224-287.  x (B,D,H,W,C).
+    dropout: None (rates 0 / eval) or the dict of keep-scale masks of swin_dropout_masks — attn_drop on the probabilities
+    (:172), proj_drop (:176; applied here in token order after the window reverse, which is the same thing for an
+    element-wise mask), Mlp.drop after the activation and after fc2 (:39, :41).
     path_scale (B, 2) | None: the DropPath factors mask / keep_prob timm's DropPath (:16) would draw for the attention
     branch (:280) and the MLP branch (:265, :285) of every sample."""
     B, D, H, W, C = x.shape
@@ -143,18 +201,25 @@ def swin_block(x, sd, pre, num_heads, window_size, shift_size, qk_scale=None, pa
     if shifted:
         h = torch.roll(h, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
         mask = compute_mask(Dp, Hp, Wp, ws, ss)
-    a = window_attention(_partition(h, ws), sd, pre + "attn.", num_heads, mask, qk_scale)
+    a = window_attention(_partition(h, ws), sd, pre + "attn.", num_heads, mask, qk_scale,
+                         attn_keep=dropout["attn"] if dropout is not None else None)
     h = _reverse(a, ws, B, Dp, Hp, Wp)
     if shifted:
         h = torch.roll(h, shifts=ss, dims=(1, 2, 3))
     h = h[:, :D, :H, :W]
+    if dropout is not None:
+        h = h * dropout["proj"]
     if path_scale is not None:
         h = h * path_scale[:, 0].reshape(B, 1, 1, 1, 1)
     x = x + h                                                   # :280
     m = F.layer_norm(x, (C,))                                   # norm2 non-affine
     m = F.linear(m, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
     m = F.gelu(m)                                               # exact erf GELU, Swin_3D.py:31
+    if dropout is not None:
+        m = m * dropout["gelu"]
     m = F.linear(m, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if dropout is not None:
+        m = m * dropout["fc2"]
     if path_scale is not None:
         m = m * path_scale[:, 1].reshape(B, 1, 1, 1, 1)
     return x + m                                                # :285

@@ -959,6 +959,82 @@ def test_swin_block_drop_path_vs_oracle(C, kernel_variant):
         gclose("d" + n, p_.grad, torch.stack([sds[v][n].grad for v in range(V)]))
 
 
+@pytest.mark.parametrize("C,window,shift,D,H,W", [(16, (2, 4, 4), (1, 2, 2), 4, 6, 10), (16, (2, 4, 4), (0, 0, 0), 4, 8, 8),
+                                                   (16, (8, 1, 1), (0, 0, 0), 8, 3, 5), (32, (2, 4, 4), (1, 2, 2), 2, 8, 12),
+                                                   (32, (8, 1, 1), (4, 0, 0), 16, 2, 3)])
+def test_swin_block_elementwise_dropout_vs_oracle(C, window, shift, D, H, W):
+    """Element-wise dropout INSIDE the fused block (en_drop_rate: Mlp.drop after GELU and after fc2 + proj_drop; en_attn_drop_rate
+    on the attention probabilities; Swin_3D.py:34-41, :138-140, :172, :176): output and every gradient against the oracle run
+    with the SAME keep masks (oracle.swin_dropout_masks restates the kernels' counter-based generator; the reference's own
+    masks come from torch's Philox stream, so parity is defined given the masks).  Shifted / padded / temporal windows, C = 16
+    and 32; the backward regenerates the masks from the seed."""
+    from oracle import idee_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(11 + C + D)
+    N, V, NH = 2, 2, 2
+    p_drop, p_attn, seed = 0.15, 0.25, 1234567 + C
+    L_ = (2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1)
+    shapes = {"attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,), "attn.proj.weight": (C, C), "attn.proj.bias": (C,),
+              "mlp.fc1.weight": (4 * C, C), "mlp.fc1.bias": (4 * C,), "mlp.fc2.weight": (C, 4 * C), "mlp.fc2.bias": (C,),
+              "attn.relative_position_bias_table": (L_, NH)}
+    x = torch.randn((N, V, D, H, W, C), generator=g)
+    r = torch.randn((N, V, D, H, W, C), generator=g)
+    sds = [{k: (torch.randn(s_, generator=g) * (0.3 if len(s_) > 1 else 0.1)).requires_grad_() for k, s_ in shapes.items()} for _ in range(V)]
+    index = O.relative_position_index(window)
+    # the kernels number tokens over the whole (N, V, D, H, W) tensor: build the masks for B = N * V items, item b = n * V + v
+    masks = O.swin_dropout_masks(seed, p_drop, p_attn, N * V, D, H, W, C, NH, window, shift)
+    ws, _ = O.get_window_size((D, H, W), window, shift)
+    nwin = masks["attn"].shape[0] // (N * V)
+    xr = x.clone().requires_grad_()
+    outs = []
+    for v in range(V):
+        sdv = dict(sds[v]); sdv["attn.relative_position_index"] = index
+        items = [n * V + v for n in range(N)]                      # rows of the (N*V)-item tensor that belong to variable v
+        mv = dict(proj=masks["proj"][items], gelu=masks["gelu"][items], fc2=masks["fc2"][items],
+                  attn=torch.cat([masks["attn"][b * nwin:(b + 1) * nwin] for b in items], 0))
+        outs.append(O.swin_block(xr[:, v], sdv, "", NH, window, shift, dropout=mv))
+    yo = torch.stack(outs, 1)
+    (yo * r).sum().backward()
+    names = list(shapes)
+    params = [torch.stack([sds[v][n].detach() for v in range(V)]).to(DEV).requires_grad_() for n in names]
+    xd = x.to(DEV).requires_grad_()
+    y = ops.SwinBlock.apply(xd, *params, index.to(DEV), NH, window, shift, None, None, p_drop, p_attn, seed)
+    drop_frac = float((masks["fc2"] == 0).float().mean())
+    assert 0.1 < drop_frac < 0.2
+    close("y", y, yo)
+    (y * r.to(DEV)).sum().backward()
+    gclose("dx", xd.grad, xr.grad)
+    for p_, n in zip(params, names):
+        gclose("d" + n, p_.grad, torch.stack([sds[v][n].grad for v in range(V)]))
+    # without dropout the same call must differ (the masks are actually applied), and eval-mode rates of 0 reproduce the plain block
+    y0 = ops.SwinBlock.apply(xd.detach(), *[p_.detach() for p_ in params], index.to(DEV), NH, window, shift, None, None)
+    assert float((y0 - y.detach()).abs().max()) > 1e-3
+
+
+def test_swin_encoder_dropout_module_flags_and_split_refusal(monkeypatch):
+    """Swin_3D(drop_rate, attn_drop_rate): training forward / backward run with fresh masks per step (two steps differ), eval is
+    deterministic and equals the rate-0 encoder; the split-precision kernels refuse dropout with a clear error."""
+    from idee_amd.models.encoder.Swin_3D import Swin_3D
+    from idee_amd import _lib as L
+    torch.manual_seed(5)
+    enc = Swin_3D(in_vars=2, in_chans=1, drop_rate=0.1, attn_drop_rate=0.1).to(DEV)
+    ref = Swin_3D(in_vars=2, in_chans=1).to(DEV)
+    ref.load_state_dict(enc.state_dict())
+    x = torch.randn(1, 2, 1, 8, 8, 12, device=DEV)
+    enc.train()
+    y1 = enc(x); y2 = enc(x)
+    assert float((y1 - y2).abs().max()) > 1e-4
+    y1.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+    enc.eval(); ref.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(enc(x), ref(x), atol=0, rtol=0)
+    enc.train()
+    monkeypatch.setenv("IDEE_SWIN_MATH", "split")
+    with pytest.raises(L.IdeeHipError, match="dropout"):
+        enc(x)
+
+
 @variants('default', 'swin_split')
 def test_swin_encoder_drop_path_rate_module(kernel_variant):
     """Swin_3D(drop_path_rate > 0): identity in eval mode, stochastic in training (the decay rule gives block 0 rate 0)."""
