@@ -1227,17 +1227,21 @@ __global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __rest
     stx4<AT>(sp + pix * CP + 4 * q, o);
   }
 }
+// One thread per (pixel of the paired field, frame of the pair): its R - 1 = V D gradient channels are read as consecutive words
+// of one pixel row (the pixel's 64 bytes are shared by the two frames' threads) and written to V D planes, consecutive pixels
+// to consecutive addresses (the element-per-thread form read one word per 64-byte line: 67 us for 70 MB).
 template <typename AT>
 __global__ __launch_bounds__(256) void sign_field_bwd_kernel(const AT* __restrict__ dsp, float* __restrict__ dqs, int N, int V,
                                                              int T, long HW, int D, int CP) {
   const int T1 = T / 2, R = V * D + 1;
-  const long total = (long)N * V * T * HW * D;
+  const long total = (long)N * T * HW;               // (n, t, pixel)
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int i = (int)(e % D); long r = e / D;
-    const long p = r % HW; r /= HW;
-    const int t = (int)(r % T); r /= T;
-    const int v = (int)(r % V); const long n = r / V;
-    dqs[e] = t < 2 * T1 ? ldx1<AT>(dsp + ((n * T1 + t / 2) * HW + p) * CP + (t & 1) * R + v * D + i) : 0.f;   // an odd last frame is never read
+    const long p = e % HW; long r = e / HW;
+    const int t = (int)(r % T); const long n = r / T;
+    const AT* src = dsp + ((n * T1 + t / 2) * HW + p) * CP + (t & 1) * R;
+    for (int v = 0; v < V; ++v)
+      for (int i = 0; i < D; ++i)
+        dqs[(((n * V + v) * T + t) * HW + p) * D + i] = t < 2 * T1 ? ldx1<AT>(src + v * D + i) : 0.f;   // an odd last frame is never read
   }
 }
 // w (Co, V*C, 2, 9) joint | (V, Co, C, 2, 9) per_var -> weff (rows, CP, 9), rows = Co | V*Co (row v*Co+co sees only variable v)
@@ -1894,7 +1898,7 @@ extern "C" int idee_lfq_sign_field_fwd(const float* signs, void* sp, int N, int 
 }
 extern "C" int idee_lfq_sign_field_bwd(const void* dsp, float* dsigns, int N, int V, int T, long HW, int D, int CP, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(dsp && dsigns && N > 0 && V > 0 && T >= 2 && HW > 0 && D > 0 && CP % 16 == 0 && 2 * (V * D + 1) <= CP, "lfq_sign_field_bwd: bad argument");
-  const dim3 grid(stream_grid((long)N * V * T * HW * D));
+  const dim3 grid(stream_grid((long)N * T * HW));
   if (act_dtype == IDEE_DTYPE_BF16) hipLaunchKernelGGL(sign_field_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dsp, dsigns, N, V, T, HW, D, CP);
   else hipLaunchKernelGGL(sign_field_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dsp, dsigns, N, V, T, HW, D, CP);
   IDEE_LAUNCH_CHECK("lfq_sign_field_bwd");
