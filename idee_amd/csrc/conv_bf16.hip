@@ -103,6 +103,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a) {
     const int nkind = 3 + (edgeL ? 1 : 0) + (edgeR ? 1 : 0);
     const int nitems = nkind * Gk, npairs = (nitems + 1) >> 1;
     bfp in_b = in + (long)b * a.i_sB;
+    // per-lane pixel columns of the tile and their element offsets, once per tile (the inner loop then costs an add, a
+    // compare and a select per column block; the channel-group offset is a multiply unless the layout has two levels —
+    // goff's division was most of this kernel's VALU work, which is what bounds it: profiles r03, VALU-busy 67 %)
+    const bool flat_in = a.i_gpu >= Gk;
+    const int isw = (int)a.i_sW;
+    int pm[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pm[m] = w0 + 16 * m + j;
 #pragma unroll
     for (int ot = 0; ot < 3; ++ot) {
       const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
@@ -123,25 +131,22 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a) {
           const int ow = kind < 3 ? kind : (kind == 3 ? 0 : 2);                          // W tap whose weights apply
           u32x4 A[NT];
           {
-            bfp wq = wp + ((long)(tapbase + ow) * Gk + cb) * a.GnTot * 256;
+            bfp wq = wp + (unsigned)(((tapbase + ow) * Gk + cb) * a.GnTot) * 256u;
 #pragma unroll
             for (int n = 0; n < NT; ++n) A[n] = item_ok ? ld16(wq + n * 256) : u32x4{0u, 0u, 0u, 0u};
           }
-          bfp colp = rowp + goff(cb, a.i_gpu, a.i_sU, a.i_sG);
+          bfp colp = rowp + (flat_in ? (long)cb * a.i_sG : goff(cb, a.i_gpu, a.i_sU, a.i_sG));
+          // source column = output column + d (forward: the tap offset; data gradient: its mirror; fold kinds: 0)
+          const int d = (MODE == FWD_REP || MODE == FWD_S2) ? ow - 1 : (kind < 3 ? 1 - ow : 0);
           u32x4 Bv[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const int p = w0 + 16 * m + j;
-            int qs;
-            bool ok;
-            if (MODE == FWD_REP) { qs = min(max(p + ow - 1, 0), a.Wi - 1); ok = true; }
-            else if (MODE == DGRAD_REP) {
-              if (kind < 3) { qs = p - (ow - 1); ok = qs >= 0 && qs < a.Wi; }
-              else { qs = p; ok = kind == 3 ? p == 0 : p == a.Wi - 1; }
-            } else if (MODE == FWD_S2) { qs = p + ow - 1; ok = qs >= 0 && qs < a.Wi; }
-            else { qs = p - (ow - 1); ok = qs >= 0 && qs < a.Wi; }
-            ok = ok && item_ok && p < a.Wo;
-            Bv[m] = ok ? ld16(colp + (long)qs * a.i_sW) : u32x4{0u, 0u, 0u, 0u};
+            int qs = pm[m] + d;
+            bool ok = item_ok && pm[m] < a.Wo;
+            if (MODE == FWD_REP) qs = min(max(qs, 0), a.Wi - 1);
+            else ok = ok && (unsigned)qs < (unsigned)a.Wi;
+            if (MODE == DGRAD_REP && kind >= 3) ok = ok && (kind == 3 ? pm[m] == 0 : pm[m] == a.Wi - 1);
+            Bv[m] = ok ? ld16(colp + qs * isw) : u32x4{0u, 0u, 0u, 0u};
           }
 #pragma unroll
           for (int n = 0; n < NT; ++n)
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a) {
         f32x4 v = acc[m][n];
         if (a.bias) v += ld4(a.bias + (long)wset * a.GnTot * 16 + cg * 16 + 4 * g4);
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const long o = row_o + (long)p * a.o_sW + goff(cg, a.o_gpu, a.o_sU, a.o_sG) + 4 * g4;
+        const long o = row_o + (long)p * a.o_sW + (a.o_gpu >= a.GnTot ? (long)cg * a.o_sG : goff(cg, a.o_gpu, a.o_sU, a.o_sG)) + 4 * g4;
         if (ref) {
           const f32x4 rr = ldx4<bf16_t>(ref + o);
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
@@ -247,13 +252,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradArgs a, int nst
       for (int n = 0; n < NB; ++n) {
         unsigned short hv[8];
         const int co = (gb0 + n) * 16 + r16;
+        bfp dy_r = dy_b + (long)h * a.y_sH + goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16;     // (one division per row, not per pixel)
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
           const int p = p0 + 8 * kq + jj;
           const bool on = 8 * kq + jj < 16 * my_sub && p < a.W && co < a.cout_real;
-          hv[jj] = on ? *reinterpret_cast<const unsigned short*>(dy_b + (long)h * a.y_sH + (long)p * a.y_sW +
-                                                                 goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16)
-                      : (unsigned short)0;
+          hv[jj] = on ? *reinterpret_cast<const unsigned short*>(dy_r + (long)p * a.y_sW) : (unsigned short)0;
           bsum[n] += __uint_as_float((unsigned)hv[jj] << 16);
         }
         Bv[n] = u32x4{(unsigned)hv[0] | ((unsigned)hv[1] << 16), (unsigned)hv[2] | ((unsigned)hv[3] << 16),
