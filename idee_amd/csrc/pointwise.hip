@@ -174,6 +174,111 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
 
 
 // -------------------------------------------------------------------------------------------
+// PatchEmbed3D with a patch (pt, ph, pw) != (1,1,1) (Swin_3D.py:473-491: Conv3d(kernel = stride = patch) after zero padding to
+// a multiple of the patch, then the non-affine LN).  The caller presents the input already gathered per patch,
+// x (B, K, L') with K = Cin pt ph pw in the weight's own (Cin, pt, ph, pw) order and L' output tokens, so this is the (1,1,1)
+// kernel above with a RUN-TIME number of input values per token (K <= 128); the weights sit in LDS.
+// -------------------------------------------------------------------------------------------
+constexpr int kPatchKMax = 128;
+template <int E, typename AT>
+__global__ __launch_bounds__(256) void patch_embed_k_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, AT* __restrict__ y, int V, long L,
+                                                                int K) {
+  constexpr int QE = E / 4;
+  __shared__ float s_w[E * kPatchKMax];
+  const int b = blockIdx.y, v = b % V;
+  for (int i = threadIdx.x; i < E * K; i += 256) s_w[i] = w[(long)v * E * K + i];
+  __syncthreads();
+  const float* xb = x + (long)b * K * L;
+  AT* yb = y + (long)b * L * E;
+  const int q = threadIdx.x % QE;
+  float bl[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bl[k] = bias ? bias[v * E + 4 * q + k] : 0.f;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    float e[4] = {bl[0], bl[1], bl[2], bl[3]};
+    for (int c = 0; c < K; ++c) {
+      const float xi = xb[c * L + tok];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = fmaf(s_w[(4 * q + k) * K + c], xi, e[k]);
+    }
+    float sm = (e[0] + e[1]) + (e[2] + e[3]);
+    const float mean = tok_sum<QE>(sm) * (1.f / E);
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+    stx4<AT>(yb + tok * E + 4 * q, f32x4{(e[0] - mean) * rstd, (e[1] - mean) * rstd, (e[2] - mean) * rstd, (e[3] - mean) * rstd});
+  }
+}
+// backward: blockIdx.z owns a chunk of KC input values (its weight-gradient accumulators stay in registers); every block
+// recomputes the token's convolution over all K (the LN statistics need it) — K / KC-fold redundant FMAs on a streaming kernel
+template <int E, typename AT>
+__global__ __launch_bounds__(256) void patch_embed_k_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, const AT* __restrict__ dy,
+                                                                float* __restrict__ dw, float* __restrict__ db, int V, long L, int K) {
+  constexpr int QE = E / 4, KC = 8;
+  __shared__ float s_w[E * kPatchKMax];
+  const int b = blockIdx.y, v = b % V, c0 = blockIdx.z * KC;
+  for (int i = threadIdx.x; i < E * K; i += 256) s_w[i] = w[(long)v * E * K + i];
+  __syncthreads();
+  const float* xb = x + (long)b * K * L;
+  const AT* dyb = dy + (long)b * L * E;
+  const int q = threadIdx.x % QE;
+  float bl[4], gw[4][KC], gb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bl[k] = bias ? bias[v * E + 4 * q + k] : 0.f;
+    gb[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) gw[k][c] = 0.f;
+  }
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < L * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const f32x4 g = ldx4<AT>(dyb + tok * E + 4 * q);
+    float e[4] = {bl[0], bl[1], bl[2], bl[3]};
+    for (int c = 0; c < K; ++c) {
+      const float xi = xb[c * L + tok];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = fmaf(s_w[(4 * q + k) * K + c], xi, e[k]);
+    }
+    const float mean = tok_sum<QE>((e[0] + e[1]) + (e[2] + e[3])) * (1.f / E);
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = e[k] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(tok_sum<QE>(var) * (1.f / E) + kLnEps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { e[k] = (e[k] - mean) * rstd; s1 += g[k]; s2 = fmaf(g[k], e[k], s2); }
+    s1 = tok_sum<QE>(s1) * (1.f / E); s2 = tok_sum<QE>(s2) * (1.f / E);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float de = rstd * (g[k] - s1 - e[k] * s2);
+      gb[k] += de;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) gw[k][c] = fmaf(de, c0 + c < K ? xb[(long)(c0 + c) * L + tok] : 0.f, gw[k][c]);
+    }
+  }
+  auto same_q_sum = [](float val) {
+#pragma unroll
+    for (int o = QE; o < 64; o <<= 1) val += __shfl_xor(val, o, 64);
+    return val;
+  };
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float sb = same_q_sum(gb[k]);
+    if (lane < QE && db && blockIdx.z == 0) atomicAdd(db + v * E + 4 * q + k, sb);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const float sw = same_q_sum(gw[k][c]);
+      if (lane < QE && c0 + c < K) atomicAdd(dw + ((long)v * E + 4 * q + k) * K + c0 + c, sw);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // Stage embedding of a hierarchical Swin encoder: PatchEmbed3D with patch (1,1,1) between two stages of different width
 // (BasicLayer builds it when in_dim != dim, Swin_3D.py:414-419; forward :473-491): y = LN_noaffine(W x + b) per token,
 // input ALREADY channels-last tokens (B, L, CIN), CIN a multiple of 16.  Backward also returns dx.
@@ -1486,6 +1591,12 @@ extern "C" int idee_patch_embed_ln_fwd(const float* x, const float* w, const flo
   } while (0)
   if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
   else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
+  else if ((E == 16 || E == 32) && Cin <= kPatchKMax) {      // Cin = Cin pt ph pw values per token of a gathered patch input
+#define PEK(E_, AT_) hipLaunchKernelGGL((patch_embed_k_fwd_kernel<E_, AT_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, (AT_*)y, V, L, Cin)
+    if (act_dtype == IDEE_DTYPE_BF16) { if (E == 16) PEK(16, bf16_t); else PEK(32, bf16_t); }
+    else { if (E == 16) PEK(16, float); else PEK(32, float); }
+#undef PEK
+  }
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "patch_embed_ln: (E=%d, Cin=%d) not built", E, Cin);
 #undef PE
   IDEE_LAUNCH_CHECK("patch_embed_ln_fwd");
@@ -1504,6 +1615,13 @@ extern "C" int idee_patch_embed_ln_bwd(const float* x, const float* w, const flo
   } while (0)
   if (E == 16 && Cin == 1) PE(16, 1); else if (E == 16 && Cin == 2) PE(16, 2);
   else if (E == 32 && Cin == 1) PE(32, 1); else if (E == 32 && Cin == 2) PE(32, 2);
+  else if ((E == 16 || E == 32) && Cin <= kPatchKMax) {
+    const dim3 grid(imin(cdiv(L * (E / 4), 256), cdiv((long)kCUs * 4, (long)N * V)), N * V, cdiv(Cin, 8));
+#define PEK(E_, AT_) hipLaunchKernelGGL((patch_embed_k_bwd_kernel<E_, AT_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, (const AT_*)dy, dw, db, V, L, Cin)
+    if (act_dtype == IDEE_DTYPE_BF16) { if (E == 16) PEK(16, bf16_t); else PEK(32, bf16_t); }
+    else { if (E == 16) PEK(16, float); else PEK(32, float); }
+#undef PEK
+  }
   else return idee::fail(IDEE_ERR_UNSUPPORTED, "patch_embed_ln: (E=%d, Cin=%d) not built", E, Cin);
 #undef PE
   IDEE_LAUNCH_CHECK("patch_embed_ln_bwd");

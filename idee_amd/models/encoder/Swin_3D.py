@@ -74,19 +74,24 @@ class Swin_3D(_stacked.StackedModule):
         self.patch_size = tuple(patch_size)
         self.patch_norm = patch_norm            # no-op in the reference too (Swin_3D.py:417-418)
         self.use_checkpoint = use_checkpoint    # backward always recomputes the block from its input
-        if self.patch_size != (1, 1, 1):
-            raise NotImplementedError("idee_amd Swin_3D: only patch_size (1,1,1) is built (the reference's setting)")
+        if len(self.patch_size) != 3 or any(int(p) < 1 for p in self.patch_size):
+            raise ValueError(f"Swin_3D: patch_size must be three positive integers, got {self.patch_size}")
+        self._pk = in_chans * self.patch_size[0] * self.patch_size[1] * self.patch_size[2]      # input values per stage-0 token
+        if self._pk > 128:
+            raise NotImplementedError(f"idee_amd Swin_3D: in_chans x patch volume = {self._pk} > 128 is not built")
         V = in_vars
         self._stages = []
         for s in range(self.num_layers):
             C = self.embed_dim[s]
             in_dim = self.embed_dim[s - 1] if s > 0 else in_chans
-            has_ds = in_dim != C                # patch (1,1,1): downsample iff the width changes (Swin_3D.py:414-419)
+            # downsample iff the width changes or (stage 0) the patch is not (1,1,1) (Swin_3D.py:414-419)
+            has_ds = in_dim != C or (s == 0 and self.patch_size != (1, 1, 1))
             hid = int(C * mlp_ratio)
             wd, wh, ww = self.window_size[s]
             L = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1)
             if has_ds:
-                self.register_parameter(f"s{s}_ds_w", nn.Parameter(torch.empty(V, C, in_dim)))
+                # stage 0: the Conv3d(kernel = stride = patch) weight (C, in, pt, ph, pw) flattened over its input side
+                self.register_parameter(f"s{s}_ds_w", nn.Parameter(torch.empty(V, C, self._pk if s == 0 else in_dim)))
                 self.register_parameter(f"s{s}_ds_b", nn.Parameter(torch.zeros(V, C)))
             self.register_buffer(f"s{s}_index", relative_position_index((wd, wh, ww)), persistent=False)
             for b in range(self.depths[s]):
@@ -152,10 +157,25 @@ class Swin_3D(_stacked.StackedModule):
         # "<stage>_ds_w5": the (V, C, Cin, 1, 1, 1) view of the 1x1x1 conv weight, for the state dict
         if name.endswith("_ds_w5"):
             w = super().__getattr__(name[:-1])
+            if name.startswith("s0_") and self.patch_size != (1, 1, 1):      # (V, C, Cin, pt, ph, pw)
+                return w.view(w.shape[0], w.shape[1], self.in_chans, *self.patch_size)
             return w.view(*w.shape, 1, 1, 1)
         return super().__getattr__(name)
 
     # ---- forward ----
+    def _gather_patches(self, x):
+        """x (N,V,C,T,H,W) -> (N,V,C pt ph pw,T',H',W'): PatchEmbed3D's zero padding to a multiple of the patch (Swin_3D.py:476-482)
+        and the per-patch gather of its strided convolution, in the weight's (C, pt, ph, pw) order — a view for patch (1,1,1),
+        one strided copy otherwise (data movement only; the convolution + LayerNorm is idee_patch_embed_ln_*)."""
+        pt, ph, pw = self.patch_size
+        if (pt, ph, pw) == (1, 1, 1):
+            return x
+        N, V, C, T, H, W = x.shape
+        x = torch.nn.functional.pad(x, (0, (-W) % pw, 0, (-H) % ph, 0, (-T) % pt))
+        T2, H2, W2 = x.shape[3] // pt, x.shape[4] // ph, x.shape[5] // pw
+        x = x.reshape(N, V, C, T2, pt, H2, ph, W2, pw).permute(0, 1, 2, 4, 6, 8, 3, 5, 7)
+        return x.reshape(N, V, C * pt * ph * pw, T2, H2, W2).contiguous()
+
     def forward_tokens(self, x):
         """x (N,V,C,T,H,W) -> channels-last tokens (N,V,T,H,W,E)."""
         # element-wise dropout (Mlp.drop, proj_drop: drop_rate; attn_drop: attn_drop_rate; Swin_3D.py:34-41, :138-140) runs inside
@@ -170,7 +190,8 @@ class Swin_3D(_stacked.StackedModule):
         for s, C, in_dim, has_ds in self._stages:
             if has_ds:
                 if s == 0:
-                    t = ops.PatchEmbedLN.apply(x, getattr(self, f"s{s}_ds_w"), getattr(self, f"s{s}_ds_b"), self.act_dtype)
+                    t = ops.PatchEmbedLN.apply(self._gather_patches(x), getattr(self, f"s{s}_ds_w"), getattr(self, f"s{s}_ds_b"),
+                                               self.act_dtype)
                 else:   # hierarchical configuration: the reference re-embeds with PatchEmbed3D(in_dim -> dim) + LN (:414-419)
                     # (an f32 kernel: under bf16 activation storage the tokens are widened for this one stage boundary)
                     t = ops.StageEmbedLN.apply(t.float(), getattr(self, f"s{s}_ds_w"), getattr(self, f"s{s}_ds_b")).to(self.act_dtype)

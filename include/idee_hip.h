@@ -52,6 +52,9 @@ int idee_check_device(int dev);
  * models/encoder/CNN_3D.py:44-71 (b == NULL).
  *   x (N, V, Cin, L) [L = T*H*W, the reference input layout], w (V, E, Cin), b (V, E) | NULL
  *   y (N, V, L, E)
+ * A patch (pt, ph, pw) != (1,1,1) (en_patch_size; Swin_3D.py:473-491 incl. its zero padding) is the same call on the input
+ * gathered per patch by the caller: Cin := Cin pt ph pw values per output token in the weight's own (Cin, pt, ph, pw) order
+ * (<= 128), L := the output tokens.
  * bwd: dw (V, E, Cin), db (V, E) | NULL accumulate.  No dx: x is the model input.
  * ---------------------------------------------------------------------------------------- */
 /* act_dtype: storage of y / dy (IDEE_DTYPE_*); x is the f32 model input */

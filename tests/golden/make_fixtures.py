@@ -165,6 +165,28 @@ def fx_cnn_hier(tag, out_channels, seed):
     save("cnn_hier_" + tag, **out)
 
 
+def fx_swin_patch(tag, patch, in_chans, shape, seed):
+    """Swin_3D with en_patch_size != (1,1,1): stage 0 embeds with Conv3d(kernel = stride = patch) after zero padding to a
+    multiple of the patch (PatchEmbed3D.forward, Swin_3D.py:473-491); whole encoder on the reduced grid, forward + gradients."""
+    enc = ref_swin.Swin_3D(in_vars=2, in_chans=in_chans, patch_size=tuple(patch), depths=[2, 1], num_heads=[2, 2])
+    rerandomise(enc, seed)
+    x = rand((1, 2, in_chans) + tuple(shape), seed + 1)
+    with relu_record() as rec:
+        y = enc(x)
+    assert rec.ties() == 0, f"swin_patch_{tag}: seed {seed} has a ReLU tie; pick another seed"
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x, y=y.detach(), r=r, patch=np.array(patch), in_chans=np.array(in_chans))
+    out.update(sd_arrays(enc))
+    out.update({"grad/" + k: p.grad for k, p in enc.named_parameters()})
+    save("swin_patch_" + tag, **out)
+
+
+if __name__ == "__main__" and "--patch-only" in sys.argv:
+    fx_swin_patch("122", (1, 2, 2), 1, (8, 9, 14), 1600)
+    fx_swin_patch("222_c2", (2, 2, 2), 2, (8, 8, 10), 1610)
+
+
 if __name__ == "__main__" and "--cnnhier-only" in sys.argv:
     fx_cnn_hier("16_32", (16, 32), 1500)
     fx_cnn_hier("32_16", (32, 16), 1510)
@@ -728,12 +750,14 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
                                                                 "--era5-only", "--hier-only", "--vqema-only", "--misc-only", "--era5items-only",
-                                                                "--cnnhier-only")):
+                                                                "--cnnhier-only", "--patch-only")):
     main()
     fx_swin_hier("16_32", (16, 32), 1200)
     fx_swin_hier("32_16", (32, 16), 1210)
     fx_cnn_hier("16_32", (16, 32), 1500)
     fx_cnn_hier("32_16", (32, 16), 1510)
+    fx_swin_patch("122", (1, 2, 2), 1, (8, 9, 14), 1600)
+    fx_swin_patch("222_c2", (2, 2, 2), 2, (8, 8, 10), 1610)
     fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
     fx_patch_mergings()
     fx_dataset_items()

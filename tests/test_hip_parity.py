@@ -850,6 +850,33 @@ def test_swin_hierarchical_encoder_golden(tag, kernel_variant):
     assert checked == len(grads)
 
 
+@pytest.mark.parametrize("tag", ["122", "222_c2"])
+def test_swin_encoder_patch_size_golden(tag):
+    """Swin_3D(patch_size != (1,1,1)) (en_patch_size; PatchEmbed3D with kernel = stride = patch incl. its zero padding,
+    Swin_3D.py:473-491): state-dict keys / shapes as the reference's, outputs and every gradient against the reference's own."""
+    from idee_amd.models.encoder.Swin_3D import Swin_3D
+    a, sd, grads = load_golden("swin_patch_" + tag)
+    enc = Swin_3D(in_vars=2, in_chans=int(a["in_chans"]), patch_size=tuple(int(v) for v in a["patch"]), depths=[2, 1], num_heads=[2, 2])
+    msd = enc.state_dict()
+    assert list(msd) == list(sd) and all(tuple(msd[k].shape) == tuple(sd[k].shape) for k in sd)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(DEV).train()
+    y = enc(dev(a["x"]))
+    close("y", y, a["y"])
+    (y * dev(a["r"])).sum().backward()
+    ps = dict(enc.named_parameters())
+    checked = 0
+    for key, name, idx in enc._key_map():
+        if name.endswith("_index"):
+            continue
+        base = name[:-1] if name.endswith("_ds_w5") else name
+        g = ps[base].grad
+        g = g if idx is None else g[idx]
+        gclose("d" + key, g.reshape(grads[key].shape), grads[key], rtol=2e-3, floor=2e-4)
+        checked += 1
+    assert checked == len(grads)
+
+
 @pytest.mark.parametrize("tag", ["16_32", "32_16"])
 def test_cnn_hierarchical_encoder_golden(tag):
     """CNN_3D with a width change after its first block (conv_block's downsample = bias-free PatchEmbed3D(in -> out) + LN,

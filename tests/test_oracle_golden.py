@@ -252,6 +252,19 @@ def test_swin_hierarchical_encoder(tag):
     check_grads(sdl, {"encoder." + k: v for k, v in grads.items()}, atol=2e-5, rtol=1e-3)
 
 
+@pytest.mark.parametrize("tag", ["122", "222_c2"])
+def test_swin_encoder_patch_size(tag):
+    """en_patch_size != (1,1,1): stage-0 PatchEmbed3D with kernel = stride = patch and zero padding to a multiple of the patch
+    (Swin_3D.py:473-491), the encoder on the reduced grid — oracle against the reference's outputs and gradients."""
+    a, sd, grads = load_golden("swin_patch_" + tag)
+    cfg = O.default_cfg(in_channels_dynamic=2, in_channels=int(a["in_chans"]), en_patch_size=tuple(int(v) for v in a["patch"]))
+    sdl = leaf({"encoder." + k: v for k, v in sd.items()})
+    y = O.swin_encoder(a["x"], sdl, cfg)
+    close(y, a["y"])
+    (y * a["r"]).sum().backward()
+    check_grads(sdl, {"encoder." + k: v for k, v in grads.items()}, atol=2e-5, rtol=1e-3)
+
+
 @pytest.mark.parametrize("tag", ["16_32", "32_16"])
 def test_cnn_hierarchical_encoder(tag):
     """Width change after the first CNN_3D block (conv_block's bias-free PatchEmbed3D(in -> out) + LN downsample,
