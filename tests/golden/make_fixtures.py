@@ -184,7 +184,7 @@ def fx_swin_patch(tag, patch, in_chans, shape, seed):
 
 if __name__ == "__main__" and "--patch-only" in sys.argv:
     fx_swin_patch("122", (1, 2, 2), 1, (8, 9, 14), 1600)
-    fx_swin_patch("222_c2", (2, 2, 2), 2, (8, 8, 10), 1610)
+    fx_swin_patch("222_c2", (2, 2, 2), 2, (16, 8, 10), 1610)
 
 
 if __name__ == "__main__" and "--cnnhier-only" in sys.argv:
@@ -757,7 +757,7 @@ if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "
     fx_cnn_hier("16_32", (16, 32), 1500)
     fx_cnn_hier("32_16", (32, 16), 1510)
     fx_swin_patch("122", (1, 2, 2), 1, (8, 9, 14), 1600)
-    fx_swin_patch("222_c2", (2, 2, 2), 2, (8, 8, 10), 1610)
+    fx_swin_patch("222_c2", (2, 2, 2), 2, (16, 8, 10), 1610)
     fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
     fx_patch_mergings()
     fx_dataset_items()
