@@ -169,3 +169,26 @@ def interval_close(name, got, g0, g1, rtol=1e-3, floor=1e-4, exact=None):
         raise AssertionError(f"{name}: {int(bad.sum())}/{got.numel()} outside the tie interval; worst got {float(got.flatten()[i]):.6g} "
                              f"interval [{float(lo.flatten()[i]):.6g}, {float(hi.flatten()[i]):.6g}]")
     return int(((hi - lo) > tol).sum())
+
+
+def adam_params_close(name, pa, pb, grads_a, grads_b, lr, firm_rel=0.03):
+    """Parameters of two runs that differ only by summation-order noise in their gradients (float atomics), after the Adam
+    steps whose gradients are grads_a[k] / grads_b[k].  An element is FIRM when at every step its gradient exceeds 100 x the
+    largest difference the two runs show at that step: there Adam's update lr * m_hat / (sqrt(v_hat) + eps) moves by ~1 % of
+    lr under that noise, and the parameters must agree to firm_rel * lr per step.  On the other elements the SIGN of a step is
+    decided by the noise (|step| = lr whatever |g|), so only the trivial bound 2 lr per step applies.  Prints the noise and
+    the firm fraction: that is the comparison actually made."""
+    steps = len(grads_a)
+    firm = torch.ones_like(pa, dtype=torch.bool)
+    noises = []
+    for ga, gb in zip(grads_a, grads_b):
+        noise = float((ga - gb).abs().max())
+        noises.append(noise)
+        firm &= (ga.abs() > 100.0 * max(noise, 1e-12)) & (gb.abs() > 100.0 * max(noise, 1e-12))
+    d = (pa - pb).abs()
+    nfirm = int(firm.sum())
+    print(f"[{name}] gradient noise per step {['%.2e' % n for n in noises]}; firm elements {nfirm}/{firm.numel()}; "
+          f"max |dp| firm {float(d[firm].max()) if nfirm else 0.0:.3e}, other {float(d[~firm].max()) if nfirm < firm.numel() else 0.0:.3e}")
+    assert nfirm >= 100, f"{name}: only {nfirm} elements above the noise floor"
+    assert float(d[firm].max()) <= firm_rel * lr * steps, f"{name}: firm elements differ by {float(d[firm].max()):.3e}"
+    assert float(d.max()) <= 2.0 * lr * steps + 1e-7, f"{name}: an element moved by more than 2 lr per step: {float(d.max()):.3e}"

@@ -8,7 +8,7 @@
 import pytest
 import torch
 
-from conftest import tie_relu, interval_close
+from conftest import tie_relu, interval_close, adam_params_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -265,17 +265,21 @@ def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     for k in range(2):
         full_lr.step(*batch(k))
     full_lr.opt.param_groups[0]["lr"] = 7e-4
+    g_full = []
     for k in range(2, 4):
         full_lr.step(*batch(k))
+        g_full.append(full_lr.opt.flat_g.detach().clone())
     path = harness.save_model(first.model, first.opt, 1, 0.5, 0.6, first.config, "train")
     torch.manual_seed(999)
     resumed = SyntheticTrainStep(default_config(**kw), model=VQ_model(default_config(**kw)))
     epoch, ltr, lva = harness.load_model(path, resumed.model, resumed.opt)
     assert (epoch, ltr, lva) == (1, 0.5, 0.6) and resumed.opt.step_count == 2 and resumed.opt.param_groups[0]["lr"] == 7e-4
+    g_res = []
     for k in range(2, 4):
         resumed.step(*batch(k))
-    d = (resumed.opt.flat_p - full_lr.opt.flat_p).abs()
-    assert float(d.max()) <= 2.5e-3 and float((d > 2e-5).float().mean()) < 5e-3, (float(d.max()), float((d > 2e-5).float().mean()))
+        g_res.append(resumed.opt.flat_g.detach().clone())
+    # the two runs differ only by float-atomic summation order in steps 3 and 4: compared where that noise cannot decide a step
+    adam_params_close("resume", resumed.opt.flat_p.detach(), full_lr.opt.flat_p.detach(), g_res, g_full, lr=7e-4)
     assert float((full.opt.flat_p - full_lr.opt.flat_p).abs().max()) > 1e-5      # the learning-rate change is visible at all
 
 

@@ -11,7 +11,7 @@ import sys
 import pytest
 import torch
 
-from conftest import ROOT
+from conftest import ROOT, adam_params_close
 
 pytestmark = pytest.mark.gpu
 WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
@@ -121,12 +121,14 @@ def test_two_host_threads_step_concurrently_on_their_own_streams():
     def run(seed, st, batches, stream, out):
         try:
             with torch.cuda.stream(stream):
-                losses = []
+                losses, grads = [], []
                 for b in batches:
                     total, parts, _ = st.step(*b)
                     losses.append(torch.stack([total.reshape(())] + [parts[n].reshape(()) for n in ("extreme", "anomaly", "var", "z_q")]))
+                    grads.append(st.opt.flat_g.detach().clone())          # stays on the device: no host sync inside the loop
                 stream.synchronize()
-                out[seed] = (torch.stack(losses).float().cpu(), st.opt.flat_p.detach().float().cpu().clone())
+                out[seed] = (torch.stack(losses).float().cpu(), st.opt.flat_p.detach().float().cpu().clone(),
+                             [g_.float().cpu() for g_ in grads])
         except BaseException as e:          # surfaced by the main thread
             out[seed] = e
 
@@ -146,9 +148,8 @@ def test_two_host_threads_step_concurrently_on_their_own_streams():
         for res in (alone[seed], together[seed]):
             if isinstance(res, BaseException):
                 raise res
-        la, pa = alone[seed]
-        lt, pt = together[seed]
+        la, pa, ga = alone[seed]
+        lt, pt, gt = together[seed]
         assert torch.isfinite(lt).all()
         torch.testing.assert_close(lt, la, rtol=2e-4, atol=1e-6)
-        d = (pt - pa).abs()
-        assert float(d.max()) <= 2.5e-3 and float((d > 2e-5).float().mean()) < 5e-3, (float(d.max()), float((d > 2e-5).float().mean()))
+        adam_params_close(f"threads seed {seed}", pt, pa, gt, ga, lr=1e-3)
