@@ -181,6 +181,153 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same convolution for NARROW inputs (Cin = 16 or 32: the 3^3 proj_var convs, the heads' (2,3,3) convs, the sign-field
+// convs) with the activations staged through LDS.  The direct-load kernel above asks L1 for every B fragment of every tap
+// (4 waves x 27 tap pairs x 4 KB per output frame of a 4-row x 64-pixel unit = 432 KB for 25 KB of new input): it is bound by
+// the L1 / texture-address rate, 3x above its MFMA time (profiles r03: WAIT_ANY 56 % of the wave cycles).  Here a workgroup
+// owns the unit (4 rows, one per wave, 64 pixels) and walks the output frames; the source rows h0 - 1 .. h0 + 4 x pixels
+// w0 - 1 .. w0 + 64 of a source frame are staged ONCE, cooperatively, into a ring of 3 frame slots (slot = frame mod 3):
+// replicate padding is applied while staging (clamped source coordinates), zero padding likewise (zeros), so the tap loop has
+// no masks, no clamps and no global activation loads — B fragments are one ds_read_b128 each (a wave reads 16 pixels x 64
+// contiguous bytes: conflict-free).  Weights still stream from L1 / L2 (each fragment serves 4 column blocks).
+// Two workgroup barriers per output frame.  LDS: 3 x 6 x 66 pixels x 64 B = 76 KB at Cin = 32 (two workgroups per CU).
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int GK, int NT>
+__global__ __launch_bounds__(256) void conv_bf16_lds_kernel(ConvArgs a) {
+  constexpr int MT = 4, NR = 6, NP = 66;
+  constexpr int PXB = 32 * GK;                  // bytes per staged pixel
+  constexpr int ROWB = NP * PXB, SLOTB = NR * ROWB;
+  constexpr int OPP = PXB / 16;                 // 16-byte channel octets per pixel
+  constexpr int CHR = NP * OPP;                 // 16-byte chunks per staged row
+  __shared__ __attribute__((aligned(16))) unsigned char s_act[3 * SLOTB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g4 = lane >> 4, hlf = g4 >> 1, ko = 8 * (g4 & 1);
+  const int b = blockIdx.y, ntg = blockIdx.z;
+  const int wset = b % a.wsets;
+  bfp in = reinterpret_cast<bfp>(a.in);
+  bfp wp = reinterpret_cast<bfp>(a.wp) + (long)wset * a.ntaps * GK * a.GnTot * 256 + (long)ntg * NT * 256 + j * 16 + ko;
+  bfp ref = reinterpret_cast<bfp>(a.relu_ref);
+  bfp addend = reinterpret_cast<bfp>(a.addend);
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+  const long wtiles = (a.Wo + 63) / 64;
+  const long units = (long)((a.Ho + 3) / 4) * wtiles;
+  bfp in_b = in + (long)b * a.i_sB;
+  const bool flat_in = a.i_gpu >= GK;
+
+  for (long un = blockIdx.x; un < units; un += gridDim.x) {
+    const int wt = (int)(un % wtiles);
+    const int h0 = (int)(un / wtiles) * 4, h = h0 + wave;
+    const int w0 = wt * 64;
+    const bool edgeL = MODE == DGRAD_REP && w0 == 0, edgeR = MODE == DGRAD_REP && w0 + 64 >= a.Wo;
+    const int nkind = 3 + (edgeL ? 1 : 0) + (edgeR ? 1 : 0);
+    const int nitems = nkind * GK, npairs = (nitems + 1) >> 1;
+    int held0 = -1, held1 = -1, held2 = -1;       // source frame each ring slot holds (for this unit)
+    for (int t = 0; t < a.To; ++t) {
+      __syncthreads();                            // every wave is done with the slots this step may replace
+#pragma unroll
+      for (int ot = 0; ot < 3; ++ot) {
+        const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
+        if (!st.ok) continue;
+        const int slot = st.src % 3;
+        const int cur = slot == 0 ? held0 : slot == 1 ? held1 : held2;
+        if (cur == st.src) continue;
+        if (slot == 0) held0 = st.src; else if (slot == 1) held1 = st.src; else held2 = st.src;
+        bfp src_f = in_b + (long)st.src * a.i_sT;
+        for (int c = threadIdx.x; c < NR * CHR; c += 256) {
+          const int r = c / CHR, cc = c - r * CHR, px = cc / OPP, oc = cc - px * OPP;
+          int hr = h0 - 1 + r, wq = w0 - 1 + px;
+          bool ok = true;
+          if (MODE == FWD_REP) { hr = min(max(hr, 0), a.Hi - 1); wq = min(max(wq, 0), a.Wi - 1); }
+          else ok = (unsigned)hr < (unsigned)a.Hi && (unsigned)wq < (unsigned)a.Wi;
+          const int cb = oc >> 1;
+          const u32x4 v = ok ? ld16(src_f + (long)hr * a.i_sH + (long)wq * a.i_sW +
+                                    (flat_in ? (long)cb * a.i_sG : goff(cb, a.i_gpu, a.i_sU, a.i_sG)) + 8 * (oc & 1))
+                             : u32x4{0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(s_act + slot * SLOTB + r * ROWB + px * PXB + oc * 16) = v;
+        }
+      }
+      __syncthreads();
+      if (h >= a.Ho) continue;                    // (an idle wave of the last row group still stages and meets the barriers)
+      f32x4 acc[MT][NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ot = 0; ot < 3; ++ot) {
+        const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
+        if (!st.ok) continue;
+        const unsigned char* fslot = s_act + (st.src % 3) * SLOTB;
+#pragma unroll
+        for (int oh = 0; oh < 3; ++oh) {
+          const Slot sh = slot_h<MODE>(oh, h, a.Hi);
+          if (!sh.ok) continue;
+          // staged row of this tap: the forward modes stage by UNCLAMPED row index (clamping happened at staging)
+          const int lrow = (MODE == FWD_REP || MODE == FWD_S2) ? wave + oh : sh.src - (h0 - 1);
+          const unsigned char* rowl = fslot + lrow * ROWB + 16 * (GK == 2 ? g4 : (g4 & 1));
+          const int tapbase = (st.tap * 3 + sh.tap) * 3;
+          for (int q = 0; q < npairs; ++q) {
+            const int e = 2 * q + hlf;
+            const bool item_ok = e < nitems;
+            const int ki = GK == 2 ? (e >> 1) : e;                                         // item kind index (e / GK)
+            const int cb = GK == 2 ? (e & 1) : 0;
+            const int kind = ki < 3 ? ki : (ki == 3 && edgeL ? 3 : 4);
+            const int ow = kind < 3 ? kind : (kind == 3 ? 0 : 2);
+            u32x4 A[NT];
+            {
+              bfp wq = wp + (unsigned)(((tapbase + ow) * GK + cb) * a.GnTot) * 256u;
+#pragma unroll
+              for (int n = 0; n < NT; ++n) A[n] = item_ok ? ld16(wq + n * 256) : u32x4{0u, 0u, 0u, 0u};
+            }
+            // staged pixel of output column 16 m + j: local index = column + 1 + d (d = the source shift of this item)
+            const int d = (MODE == FWD_REP || MODE == FWD_S2) ? ow - 1 : (kind < 3 ? 1 - ow : 0);
+            // (GK == 2: the lane's channel octet is 16 g4 bytes into the pixel, both items of a pair share `ow`;
+            //  GK == 1: octet 16 (g4 & 1), the two halves of the wave read different shifts)
+            const unsigned char* bp = rowl + (j + 1 + d) * PXB;
+            u32x4 Bv[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) Bv[m] = *reinterpret_cast<const u32x4*>(bp + m * 16 * PXB);
+            if (MODE == DGRAD_REP && kind >= 3) {          // fold kinds: only the frame's own border column contributes
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                const int p = w0 + 16 * m + j;
+                if (!(kind == 3 ? p == 0 : p == a.Wi - 1)) Bv[m] = u32x4{0u, 0u, 0u, 0u};
+              }
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+              for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf(A[n], Bv[m], acc[m][n]);
+          }
+        }
+      }
+      // ---- epilogue (as conv_bf16_kernel) ----
+      const long row_o = (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int p = w0 + 16 * m + j;
+        if (p >= a.Wo) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int cg = ntg * NT + n;
+          f32x4 v = acc[m][n];
+          if (a.bias) v += ld4(a.bias + (long)wset * a.GnTot * 16 + cg * 16 + 4 * g4);
+          if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          const long o = row_o + (long)p * a.o_sW + (a.o_gpu >= a.GnTot ? (long)cg * a.o_sG : goff(cg, a.o_gpu, a.o_sU, a.o_sG)) + 4 * g4;
+          if (ref) {
+            const f32x4 rr = ldx4<bf16_t>(ref + o);
+            v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+            v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+          }
+          if (addend) v += ldx4<bf16_t>(addend + o);
+          stx4<bf16_t>(out + o, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient: dWp[wset][tap][cin][coutPad] += sum_pixels x[src(pixel, tap)][cin] dy[pixel][cout], K = pixels, 32 per
 // MFMA.  The structure of wgrad16_split_kernel (conv_mfma.hip): every WAVE owns a strip of 32 pixels of one
 // (input block ga, output block group) pair and walks a run of rows of one (batch item, t), with a wave-private LDS ring of
@@ -343,6 +490,21 @@ template <int MODE>
 int launch_conv_bf16(ConvArgs& a, hipStream_t stream) {
   const int NT = pick_nt(a.GnTot);
   const int gz = a.GnTot / NT;
+  // narrow inputs (Cin = 16 / 32): activations staged through LDS.  IDEE_CONV_BF16=direct keeps the direct-load kernel
+  // (the -m gpu suite runs both: tests/conftest.py variant `conv_bf16_direct`).
+  if (a.Gk <= 2 && !env_is("IDEE_CONV_BF16", "direct")) {
+    const long units = (long)((a.Ho + 3) / 4) * ((a.Wo + 63) / 64);
+    long gx = ((long)kCUs * 2 * 2) / ((long)a.B * gz);       // two workgroups per CU (76 KB of LDS each), two rounds
+    if (gx < 1) gx = 1;
+    if (gx > units) gx = units;
+    const dim3 grid((unsigned)gx, a.B, gz);
+#define LCL(GK_, NT_) hipLaunchKernelGGL((conv_bf16_lds_kernel<MODE, GK_, NT_>), grid, dim3(256), 0, stream, a)
+#define LCLN(GK_) do { if (NT == 6) LCL(GK_, 6); else if (NT == 3) LCL(GK_, 3); else if (NT == 2) LCL(GK_, 2); else LCL(GK_, 1); } while (0)
+    if (a.Gk == 2) LCLN(2); else LCLN(1);
+#undef LCLN
+#undef LCL
+    return IDEE_OK;
+  }
   const long units = (long)((a.Ho + 3) / 4) * ((a.Wo + 63) / 64);      // (4-row group, 64-pixel column tile); a workgroup walks t
   long gx = ((long)kCUs * 8) / ((long)a.B * gz);        // ~8 workgroups per CU in total: every workgroup loops over its units
   if (gx < 1) gx = 1;

@@ -43,6 +43,7 @@ KERNEL_VARIANTS = {
     "wgrad16_regs": {"IDEE_WGRAD16_REGS": "1"},                      # register-staged 3^3 weight gradient
     "conv32_generic": {"IDEE_CONV32": "generic"},                    # 32->32 on the generic kernel
     "dgrad_to16_wide": {"IDEE_DGRAD_TO16": "wide"},                  # (1,3,3) data gradient on conv_wide_kernel
+    "conv_bf16_direct": {"IDEE_CONV_BF16": "direct"},                # bf16 path: narrow-input convs without LDS staging
 }
 
 
@@ -55,7 +56,8 @@ def variants(*names):
 @pytest.fixture
 def kernel_variant(request, monkeypatch):
     name = getattr(request, "param", "default")
-    for k in ("IDEE_SWIN_MATH", "IDEE_CONV_MATH", "IDEE_CONV16", "IDEE_WGRAD16_REGS", "IDEE_CONV32", "IDEE_DGRAD_TO16"):
+    for k in ("IDEE_SWIN_MATH", "IDEE_CONV_MATH", "IDEE_CONV16", "IDEE_WGRAD16_REGS", "IDEE_CONV32", "IDEE_DGRAD_TO16",
+              "IDEE_CONV_BF16"):
         monkeypatch.delenv(k, raising=False)
     for k, v in KERNEL_VARIANTS[name].items():
         monkeypatch.setenv(k, v)

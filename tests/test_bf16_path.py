@@ -12,6 +12,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import variants
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 BF = torch.bfloat16
@@ -53,6 +55,9 @@ CONV_CASES = [
     ("k333", 1, 1, 32, 32, 1, 1, 1),
     ("k333", 1, 1, 16, 32, 2, 3, 64),
     ("k333", 2, 1, 32, 32, 3, 4, 129),
+    ("k333", 1, 1, 32, 32, 9, 7, 66),          # the LDS ring over many frames, a 2-pixel last tile, 3 idle rows
+    ("k233", 1, 1, 32, 32, 10, 9, 64),
+    ("k133", 1, 1, 32, 16, 5, 8, 64),
     ("k233", 3, 1, 32, 32, 4, 5, 40),
     ("k233", 1, 2, 96, 96, 4, 4, 33),
     ("k233", 1, 1, 192, 192, 2, 3, 20),
@@ -64,8 +69,9 @@ CONV_CASES = [
 ]
 
 
+@variants("default", "conv_bf16_direct")
 @pytest.mark.parametrize("name,wsets,N,Cin,Cout,T,H,W", CONV_CASES)
-def test_conv_bf16_fwd_dgrad_wgrad_vs_torch(name, wsets, N, Cin, Cout, T, H, W):
+def test_conv_bf16_fwd_dgrad_wgrad_vs_torch(name, wsets, N, Cin, Cout, T, H, W, kernel_variant):
     """Every pass of the bf16 convolution kernels (conv_bf16.hip) against torch conv3d on the same bf16-rounded operands:
     forward with bias + ReLU, data gradient with the ReLU mask, weight and bias gradient."""
     from idee_amd import ops
@@ -128,7 +134,8 @@ def test_conv_bf16_fwd_dgrad_wgrad_vs_torch(name, wsets, N, Cin, Cout, T, H, W):
     torch.testing.assert_close(db.cpu(), br3.grad, atol=2e-4 * float(br3.grad.abs().max()) + 1e-6, rtol=2e-4)
 
 
-def test_conv_bf16_addend_and_grouped_layouts():
+@variants("default", "conv_bf16_direct")
+def test_conv_bf16_addend_and_grouped_layouts(kernel_variant):
     """dgrad with accumulate (dx += ...) and the two-level channel-group addressing the classifier uses (the heads' conv1
     writes the V slices of its output; the dense joint head reads the V slices of z_q)."""
     from idee_amd import ops
