@@ -12,6 +12,7 @@
 // consecutive channels of one pixel = one 8-byte bf16 store.
 #include "common.h"
 #include "conv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a) {
 // owns the unit (4 rows, one per wave, 64 pixels) and walks the output frames; the source rows h0 - 1 .. h0 + 4 x pixels
 // w0 - 1 .. w0 + 64 of a source frame are staged ONCE, cooperatively, into a ring of 3 frame slots (slot = frame mod 3):
 // replicate padding is applied while staging (clamped source coordinates), zero padding likewise (zeros), so the tap loop has
-// no masks, no clamps and no global activation loads — B fragments are one ds_read_b128 each (a wave reads 16 pixels x 64
-// contiguous bytes: conflict-free).  Weights still stream from L1 / L2 (each fragment serves 4 column blocks).
+// no masks, no clamps and no global activation loads — B fragments are one ds_read_b128 each (bank-conflict-free with
+// the octet swizzle below).  Weights still stream from L1 / L2 (each fragment serves 4 column blocks).
 // Two workgroup barriers per output frame.  LDS: 3 x 6 x 66 pixels x 64 B = 76 KB at Cin = 32 (two workgroups per CU).
 // ---------------------------------------------------------------------------------------------
 template <int MODE, int GK, int NT>
@@ -243,7 +244,11 @@ __global__ __launch_bounds__(256) void conv_bf16_lds_kernel(ConvArgs a) {
           const u32x4 v = ok ? ld16(src_f + (long)hr * a.i_sH + (long)wq * a.i_sW +
                                     (flat_in ? (long)cb * a.i_sG : goff(cb, a.i_gpu, a.i_sU, a.i_sG)) + 8 * (oc & 1))
                              : u32x4{0u, 0u, 0u, 0u};
-          *reinterpret_cast<u32x4*>(s_act + slot * SLOTB + r * ROWB + px * PXB + oc * 16) = v;
+          // GK == 2: the octet position inside a pixel is XOR-swizzled by 2 * bit 2 of the staged pixel index — a
+          // ds_read_b128 is served in groups of 16 lanes that mix two octets and pixels j, j + 4, j + 8, j + 12 (256 B apart =
+          // the same banks); the swizzle spreads each group over all 64 banks (MI355X_MICROARCH.md, LDS table)
+          const int ocs = GK == 2 ? (oc ^ (((px >> 2) & 1) << 1)) : oc;
+          *reinterpret_cast<u32x4*>(s_act + slot * SLOTB + r * ROWB + px * PXB + ocs * 16) = v;
         }
       }
       __syncthreads();
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_bf16_lds_kernel(ConvArgs a) {
           if (!sh.ok) continue;
           // staged row of this tap: the forward modes stage by UNCLAMPED row index (clamping happened at staging)
           const int lrow = (MODE == FWD_REP || MODE == FWD_S2) ? wave + oh : sh.src - (h0 - 1);
-          const unsigned char* rowl = fslot + lrow * ROWB + 16 * (GK == 2 ? g4 : (g4 & 1));
+          const unsigned char* rowl = fslot + lrow * ROWB;
           const int tapbase = (st.tap * 3 + sh.tap) * 3;
           for (int q = 0; q < npairs; ++q) {
             const int e = 2 * q + hlf;
@@ -283,7 +288,9 @@ __global__ __launch_bounds__(256) void conv_bf16_lds_kernel(ConvArgs a) {
             const int d = (MODE == FWD_REP || MODE == FWD_S2) ? ow - 1 : (kind < 3 ? 1 - ow : 0);
             // (GK == 2: the lane's channel octet is 16 g4 bytes into the pixel, both items of a pair share `ow`;
             //  GK == 1: octet 16 (g4 & 1), the two halves of the wave read different shifts)
-            const unsigned char* bp = rowl + (j + 1 + d) * PXB;
+            const int pxl = j + 1 + d;
+            const int octet = GK == 2 ? (g4 ^ (((pxl >> 2) & 1) << 1)) : (g4 & 1);        // (+ 16 m pixels keeps bit 2)
+            const unsigned char* bp = rowl + pxl * PXB + 16 * octet;
             u32x4 Bv[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) Bv[m] = *reinterpret_cast<const u32x4*>(bp + m * 16 * PXB);
@@ -321,6 +328,342 @@ __global__ __launch_bounds__(256) void conv_bf16_lds_kernel(ConvArgs a) {
           }
           if (addend) v += ldx4<bf16_t>(addend + o);
           stx4<bf16_t>(out + o, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 32 -> 32 channels, WEIGHT-STATIONARY (the proj_var 3^3 convs and the heads' (2,3,3) convs, both directions): in
+// conv_bf16_lds_kernel every weight fragment still comes from L1 and feeds only 4 MFMAs — 1 KB per 64 MFMA cycles per SIMD is
+// exactly the CU's 64 B/clk of L1 bandwidth, so the kernel cannot pass ~50 % MFMA-busy.  Here a wave keeps ALL its weight
+// fragments in registers for the whole launch (KT x 9 taps x 2 cout blocks x 4 dwords = 216 registers for 3^3; the unified
+// 512-entry file at one wave per SIMD holds them next to 32 accumulators), loaded once per workgroup: the steady state has no
+// global loads but the staging of new activation frames, and those are prefetched a step ahead — the loads of frame t + 2 are
+// issued before the taps of step t and written to the 4th ring slot after them (one barrier per step).
+//   Replicate-padding data gradient: the border folds are written per WEIGHT tap (static register index): tap tau of an edge
+// frame / row / column takes a second source, the clamped one (conv_common.h slot_t / slot_h list the same (source, tap) pairs
+// per loop slot).  The (2,3,3) data gradient uses tap t & 1 of the two in registers.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int KT>
+__global__ __launch_bounds__(256) void conv_bf16_ws_kernel(ConvArgs a) {
+  constexpr int MT = 4, NT = 2, NR = 6, NP = 66, NS = 4;
+  constexpr int PXB = 64, ROWB = NP * PXB, SLOTB = NR * ROWB;
+  constexpr int CHR = NP * 4;                          // 16-byte chunks per staged row
+  constexpr int NCH = (NR * CHR + 255) / 256;          // chunks per thread and frame
+  constexpr bool FWD = MODE == FWD_REP || MODE == FWD_S2;
+  constexpr int NC = MODE == DGRAD_REP ? 2 : 1;        // sources per weight tap and axis (2: a replicate fold)
+  __shared__ __attribute__((aligned(16))) unsigned char s_act[NS * SLOTB];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g4 = lane >> 4, hlf = g4 >> 1, ko = 8 * (g4 & 1);
+  const int b = blockIdx.y;
+  const int wset = b % a.wsets;
+  bfp in = reinterpret_cast<bfp>(a.in);
+  bfp ref = reinterpret_cast<bfp>(a.relu_ref);
+  bfp addend = reinterpret_cast<bfp>(a.addend);
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+
+  u32x4 Aw[KT][3][3][NT];
+  {
+    bfp wp = reinterpret_cast<bfp>(a.wp) + (long)wset * (KT * 9) * 2 * NT * 256 + j * 16 + ko;
+#pragma unroll
+    for (int tt = 0; tt < KT; ++tt)
+#pragma unroll
+      for (int th = 0; th < 3; ++th)
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) Aw[tt][th][tw][n] = ld16(wp + ((((tt * 3 + th) * 3 + tw) * 2 + hlf) * NT + n) * 256);
+  }
+
+  f32x4 biasv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) biasv[n] = a.bias ? ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // byte offset of this lane's B fragment inside a staged row for staged pixel j + d, d = 0..2 (+ 16 m pixels = + 1024 m bytes
+  // keeps the swizzle bit)
+  int lo[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) lo[d] = (j + d) * PXB + ((g4 ^ ((((j + d) >> 2) & 1) << 1)) << 4);
+  auto readB = [&](u32x4 (&Bq)[MT], const unsigned char* bp) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) Bq[m] = *reinterpret_cast<const u32x4*>(bp + m * 16 * PXB);
+  };
+
+  const long wtiles = (a.Wo + 63) / 64;
+  const long units = (long)((a.Ho + 3) / 4) * wtiles;
+  bfp in_b = in + (long)b * a.i_sB;
+
+  for (long un = blockIdx.x; un < units; un += gridDim.x) {
+    const int wt = (int)(un % wtiles);
+    const int h0 = (int)(un / wtiles) * 4, h = h0 + wave;
+    const int w0 = wt * 64;
+    const bool edgeL = MODE == DGRAD_REP && w0 == 0, edgeR = MODE == DGRAD_REP && w0 + 64 >= a.Wo;
+    // this thread's chunks of a staged frame: source offset inside the frame, LDS offset inside the slot, and whether the
+    // chunk is padding (zero) / beyond the slot (not written).  Loads are unconditional (clamped addresses) so that nothing
+    // waits on them before the commit.
+    long coff[NCH];
+    int loff[NCH];
+    bool cz[NCH], cw[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = threadIdx.x + 256 * i;
+      cw[i] = c0 < NR * CHR;
+      const int c = cw[i] ? c0 : threadIdx.x;
+      const int r = c / CHR, cc = c - r * CHR, px = cc >> 2, oc = cc & 3;
+      const int hr = h0 - 1 + r, wq = w0 - 1 + px;
+      cz[i] = MODE != FWD_REP && !((unsigned)hr < (unsigned)a.Hi && (unsigned)wq < (unsigned)a.Wi);
+      coff[i] = (long)min(max(hr, 0), a.Hi - 1) * a.i_sH + (long)min(max(wq, 0), a.Wi - 1) * a.i_sW + (long)(oc >> 1) * a.i_sG +
+                8 * (oc & 1);
+      loff[i] = r * ROWB + px * PXB + ((oc ^ (((px >> 2) & 1) << 1)) << 4);                          // (octet swizzle: see above)
+    }
+    // frames: step s reads (REP) s - 1, s, s + 1 clamped, (FWD_S2) KT s .. KT s + KT - 1, (DGRAD_S2) s / KT.  new_frame(s, k):
+    // the k-th frame step s needs that step s - 1 did not (for s = 0 on top of frame 0 in the replicate modes).
+    constexpr int NPRE = (MODE == FWD_S2 && KT == 2) ? 2 : 1;
+    auto new_frame = [&](int s2, int k2, int& src) -> bool {
+      if (MODE == FWD_REP || MODE == DGRAD_REP) { src = s2 + 1; return src < a.Ti; }
+      if (MODE == FWD_S2) { src = KT * s2 + k2; return src < a.Ti; }
+      src = KT == 2 ? s2 >> 1 : s2;
+      return (KT == 1 || (s2 & 1) == 0) && src < a.Ti;
+    };
+    // Frame pipeline: the frames step t + 1 adds are LOADED during step t - 1 (into `pre`), COMMITTED to their ring slots at the
+    // start of step t (those slots were last read in step t - 1) and visible after the barrier of step t + 1: a full step of
+    // latency tolerance, and the commit's wait never includes a store of the step before.
+    u32x4 pre[NPRE][NCH];
+    int pre_src[NPRE];
+    auto load_new = [&](int s2) {
+#pragma unroll
+      for (int k = 0; k < NPRE; ++k) {
+        int src = 0;
+        const bool nw = s2 < a.To && new_frame(s2, k, src);
+        pre_src[k] = nw ? src : -1;
+        bfp src_f = in_b + (long)(nw ? src : 0) * a.i_sT;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) pre[k][i] = ld16(src_f + coff[i]);
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int k = 0; k < NPRE; ++k) {
+        if (pre_src[k] < 0) continue;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          if (cw[i]) *reinterpret_cast<u32x4*>(s_act + (pre_src[k] & 3) * SLOTB + loff[i]) = cz[i] ? u32x4{0u, 0u, 0u, 0u} : pre[k][i];
+      }
+    };
+    __syncthreads();                                // the previous unit's readers are done
+    {                                               // step 0's frames: all loads first, then the LDS writes
+      u32x4 v0[NCH];
+      if (MODE == FWD_REP || MODE == DGRAD_REP) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) v0[i] = ld16(in_b + coff[i]);
+      }
+      load_new(0);
+      if (MODE == FWD_REP || MODE == DGRAD_REP) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          if (cw[i]) *reinterpret_cast<u32x4*>(s_act + loff[i]) = cz[i] ? u32x4{0u, 0u, 0u, 0u} : v0[i];
+      }
+      commit();
+      load_new(1);
+    }
+    for (int t = 0; t < a.To; ++t) {
+      __syncthreads();                              // the frames of step t are visible; every wave has finished step t - 1
+      commit();                                     // the frames step t + 1 adds
+      load_new(t + 2);
+      // the epilogue's operands (ReLU reference, addend: the data gradient) are fetched now as well: one wave per SIMD has
+      // nobody to hide their latency behind at the end of the step
+      const int hq = min(h, a.Ho - 1);
+      auto out_off = [&](int m, int n) -> long {
+        const int p = min(w0 + 16 * m + j, a.Wo - 1);
+        return (long)b * a.o_sB + (long)t * a.o_sT + (long)hq * a.o_sH + (long)p * a.o_sW +
+               (a.o_gpu >= NT ? (long)n * a.o_sG : goff(n, a.o_gpu, a.o_sU, a.o_sG)) + 4 * g4;
+      };
+      uint2 refv[MT][NT], addv[MT][NT];
+      if (ref) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) refv[m][n] = *reinterpret_cast<const uint2*>(ref + out_off(m, n));
+      }
+      if (addend) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) addv[m][n] = *reinterpret_cast<const uint2*>(addend + out_off(m, n));
+      }
+      f32x4 acc[MT][NT];
+      if (h < a.Ho) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- interior steps (all of FWD_REP: its borders are clamped while staging): every tap has exactly one source, the
+        // tap list is static and the B fragments are read two taps ahead of the MFMAs that use them ----
+        const bool interior = MODE == FWD_REP ? true
+                            : MODE == DGRAD_REP ? (a.Ti >= 2 && h >= 1 && h <= a.Hi - 2)
+                            : MODE == FWD_S2 ? (h >= 1 && h <= a.Hi - 2)
+                            : (h >= 1 && h <= a.Hi - 2 && (KT == 2 ? t >> 1 : t) < a.Ti);
+        auto static_taps = [&](auto TSEL, auto TVAR) {
+          constexpr int tsel = decltype(TSEL)::value;         // DGRAD_S2: the one temporal weight tap of this step; else -1 (all)
+          // DGRAD_REP: 0 = an inner frame (tap tt reads frame t + 1 - tt), 1 = the first frame, 2 = the last: three
+          // (weight tap, frame) pairs each, the fold of the clamped frame included —
+          //   t = 0:      (0, 1) (0, 0) (1, 0)          t = Ti - 1: (2, t - 1) (2, t) (1, t)
+          constexpr int tv = decltype(TVAR)::value;
+          constexpr int NTAP = (tsel < 0 ? KT : 1) * 9;
+          auto pair_tt = [&](int pr) { return tsel >= 0 ? tsel : tv == 1 ? (pr == 2 ? 1 : 0) : tv == 2 ? (pr == 2 ? 1 : 2) : pr; };
+          auto pair_f = [&](int pr) {
+            return MODE == FWD_REP ? min(max(t + pr - 1, 0), a.Ti - 1)
+                 : MODE == DGRAD_REP ? (tv == 1 ? (pr == 0 ? 1 : 0) : tv == 2 ? (pr == 0 ? t - 1 : t) : t - (pr - 1))
+                 : MODE == FWD_S2 ? KT * t + pr : (KT == 2 ? t >> 1 : t);
+          };
+          auto baddr = [&](int k) -> const unsigned char* {
+            const int th = (k / 3) % 3, tw = k % 3;
+            const int lrow = FWD ? wave + th : wave + 2 - th;
+            return s_act + (pair_f(k / 9) & 3) * SLOTB + lrow * ROWB + lo[FWD ? tw : 2 - tw];
+          };
+          u32x4 Bb[3][MT];
+          readB(Bb[0], baddr(0));
+          readB(Bb[1], baddr(1));
+#pragma unroll
+          for (int k = 0; k < NTAP; ++k) {
+            if (k + 2 < NTAP) readB(Bb[(k + 2) % 3], baddr(k + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            const int tt = pair_tt(k / 9), th = (k / 3) % 3, tw = k % 3;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+              for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf(Aw[tt][th][tw][n], Bb[k % 3][m], acc[m][n]);
+          }
+          if (MODE == DGRAD_REP && (edgeL || edgeR)) {
+            // W folds: the frame's border column takes weight tap 0 (left) / 2 (right) of its own pixel once more
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+              if (!(side == 0 ? edgeL : edgeR)) continue;
+              bool keep[MT];
+#pragma unroll
+              for (int m = 0; m < MT; ++m) keep[m] = side == 0 ? (w0 + 16 * m + j == 0) : (w0 + 16 * m + j == a.Wi - 1);
+              auto faddr = [&](int k) -> const unsigned char* {
+                return s_act + (pair_f(k / 3) & 3) * SLOTB + (wave + 2 - k % 3) * ROWB + lo[1];
+              };
+              u32x4 Fb[2][MT];
+              readB(Fb[0], faddr(0));
+#pragma unroll
+              for (int k = 0; k < 9; ++k) {
+                if (k + 1 < 9) readB(Fb[(k + 1) & 1], faddr(k + 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                  if (!keep[m]) Fb[k & 1][m] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                  for (int m = 0; m < MT; ++m)
+                    acc[m][n] = mfma_bf(Aw[pair_tt(k / 3)][k % 3][side == 0 ? 0 : 2][n], Fb[k & 1][m], acc[m][n]);
+              }
+            }
+          }
+        };
+        using ic0 = std::integral_constant<int, 0>;
+        using icm = std::integral_constant<int, -1>;
+        if (interior) {
+          if (MODE == DGRAD_S2 && KT == 2) {
+            if (t & 1) static_taps(std::integral_constant<int, KT == 2 ? 1 : 0>{}, ic0{});
+            else static_taps(ic0{}, ic0{});
+          } else if (MODE == DGRAD_S2) static_taps(ic0{}, ic0{});
+          else if (MODE == DGRAD_REP) {
+            if (t == 0) static_taps(icm{}, std::integral_constant<int, MODE == DGRAD_REP ? 1 : 0>{});
+            else if (t == a.Ti - 1) static_taps(icm{}, std::integral_constant<int, MODE == DGRAD_REP ? 2 : 0>{});
+            else static_taps(icm{}, ic0{});
+          } else static_taps(icm{}, ic0{});
+        } else
+#pragma unroll
+        for (int tt = 0; tt < KT; ++tt) {
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) {
+            // source frame of weight tap tt
+            int fsrc; bool vt;
+            if (MODE == FWD_REP) { fsrc = min(max(t + tt - 1, 0), a.Ti - 1); vt = true; }
+            else if (MODE == DGRAD_REP) {
+              const int q = ct == 0 ? t - (tt - 1) : t + (tt - 1);
+              const bool in = q >= 0 && q < a.Ti;
+              vt = ct == 0 ? in : (tt != 1 && !in);
+              fsrc = min(max(q, 0), a.Ti - 1);
+            } else if (MODE == FWD_S2) { fsrc = KT * t + tt; vt = fsrc < a.Ti; }
+            else { fsrc = KT == 2 ? t >> 1 : t; vt = fsrc < a.Ti && tt == (t & (KT - 1)); }
+            if (!vt) continue;
+            const unsigned char* fslot = s_act + (fsrc & 3) * SLOTB;
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+#pragma unroll
+              for (int chh = 0; chh < NC; ++chh) {
+                // staged row of weight tap th (forward modes stage by unclamped row index, clamped / zeroed while staging)
+                int lrow; bool vh;
+                if (MODE == FWD_REP) { lrow = wave + th; vh = true; }
+                else if (MODE == FWD_S2) { lrow = wave + th; vh = (unsigned)(h + th - 1) < (unsigned)a.Hi; }
+                else if (MODE == DGRAD_S2) { lrow = wave + 2 - th; vh = (unsigned)(h - (th - 1)) < (unsigned)a.Hi; }
+                else {
+                  const int q = chh == 0 ? h - (th - 1) : h + (th - 1);
+                  const bool in = q >= 0 && q < a.Hi;
+                  vh = chh == 0 ? in : (th != 1 && !in);
+                  lrow = min(max(q, 0), a.Hi - 1) - (h0 - 1);
+                }
+                if (!vh) continue;
+                const unsigned char* rowl = fslot + lrow * ROWB;
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw) {
+                  u32x4 Bv[MT];
+                  readB(Bv, rowl + lo[FWD ? tw : 2 - tw]);                                   // staged pixel j + tw / j + 2 - tw
+#pragma unroll
+                  for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf(Aw[tt][th][tw][n], Bv[m], acc[m][n]);
+                }
+                if (MODE == DGRAD_REP && (edgeL || edgeR)) {
+                  // W folds: the frame's border column takes weight tap 0 (left) / 2 (right) of its own pixel once more
+                  const unsigned char* bp = rowl + lo[1];
+#pragma unroll
+                  for (int side = 0; side < 2; ++side) {
+                    if (!(side == 0 ? edgeL : edgeR)) continue;
+                    u32x4 Bv[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                      const int p = w0 + 16 * m + j;
+                      const u32x4 v = *reinterpret_cast<const u32x4*>(bp + m * 16 * PXB);
+                      Bv[m] = (side == 0 ? p == 0 : p == a.Wi - 1) ? v : u32x4{0u, 0u, 0u, 0u};
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                      for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf(Aw[tt][th][side == 0 ? 0 : 2][n], Bv[m], acc[m][n]);
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      // ---- epilogue (as conv_bf16_kernel) ----
+      if (h < a.Ho) {
+        auto bf4 = [](uint2 u) {
+          return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u)};
+        };
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (w0 + 16 * m + j >= a.Wo) continue;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            f32x4 v = acc[m][n] + biasv[n];
+            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (ref) {
+              const f32x4 rr = bf4(refv[m][n]);
+              v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+              v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+            }
+            if (addend) v += bf4(addv[m][n]);
+            stx4<bf16_t>(out + out_off(m, n), v);
+          }
         }
       }
     }
@@ -492,6 +835,19 @@ int launch_conv_bf16(ConvArgs& a, hipStream_t stream) {
   const int gz = a.GnTot / NT;
   // narrow inputs (Cin = 16 / 32): activations staged through LDS.  IDEE_CONV_BF16=direct keeps the direct-load kernel
   // (the -m gpu suite runs both: tests/conftest.py variant `conv_bf16_direct`).
+  // 32 -> 32: the weight-stationary kernel (IDEE_CONV_BF16=lds keeps conv_bf16_lds_kernel on these shapes; variant `conv_bf16_lds`)
+  if (a.Gk == 2 && a.GnTot == 2 && a.i_gpu >= 2 && !env_is("IDEE_CONV_BF16", "direct") && !env_is("IDEE_CONV_BF16", "lds")) {
+    const long units = (long)((a.Ho + 3) / 4) * ((a.Wo + 63) / 64);
+    long gx = (long)kCUs / a.B;                              // one workgroup per CU (101 KB of LDS, ~350 registers per lane)
+    if (gx < 1) gx = 1;
+    if (gx > units) gx = units;
+    const dim3 grid((unsigned)gx, a.B, 1);
+    constexpr bool REP = MODE == FWD_REP || MODE == DGRAD_REP;
+    if constexpr (REP) hipLaunchKernelGGL((conv_bf16_ws_kernel<MODE, 3>), grid, dim3(256), 0, stream, a);
+    else if (a.kt == 2) hipLaunchKernelGGL((conv_bf16_ws_kernel<MODE, REP ? 3 : 2>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_bf16_ws_kernel<MODE, REP ? 3 : 1>), grid, dim3(256), 0, stream, a);
+    return IDEE_OK;
+  }
   if (a.Gk <= 2 && !env_is("IDEE_CONV_BF16", "direct")) {
     const long units = (long)((a.Ho + 3) / 4) * ((a.Wo + 63) / 64);
     long gx = ((long)kCUs * 2 * 2) / ((long)a.B * gz);       // two workgroups per CU (76 KB of LDS each), two rounds

@@ -44,6 +44,7 @@ KERNEL_VARIANTS = {
     "conv32_generic": {"IDEE_CONV32": "generic"},                    # 32->32 on the generic kernel
     "dgrad_to16_wide": {"IDEE_DGRAD_TO16": "wide"},                  # (1,3,3) data gradient on conv_wide_kernel
     "conv_bf16_direct": {"IDEE_CONV_BF16": "direct"},                # bf16 path: narrow-input convs without LDS staging
+    "conv_bf16_lds": {"IDEE_CONV_BF16": "lds"},                      # bf16 path: 32->32 on the LDS kernel, weights from L1
 }
 
 

@@ -58,6 +58,10 @@ CONV_CASES = [
     ("k333", 1, 1, 32, 32, 9, 7, 66),          # the LDS ring over many frames, a 2-pixel last tile, 3 idle rows
     ("k233", 1, 1, 32, 32, 10, 9, 64),
     ("k133", 1, 1, 32, 16, 5, 8, 64),
+    ("k133", 2, 1, 32, 32, 3, 5, 65),          # (1,3,3) 32 -> 32 on the weight-stationary kernel
+    ("k333", 1, 1, 32, 32, 2, 2, 63),          # both W edges in one tile, T = 2: every frame and row is a border
+    ("k333", 1, 1, 32, 32, 1, 9, 130),         # T = 1: both temporal folds on the same frame
+    ("k233", 2, 1, 32, 32, 7, 5, 64),          # odd T (the last frame has no output)
     ("k233", 3, 1, 32, 32, 4, 5, 40),
     ("k233", 1, 2, 96, 96, 4, 4, 33),
     ("k233", 1, 1, 192, 192, 2, 3, 20),
@@ -69,7 +73,7 @@ CONV_CASES = [
 ]
 
 
-@variants("default", "conv_bf16_direct")
+@variants("default", "conv_bf16_direct", "conv_bf16_lds")
 @pytest.mark.parametrize("name,wsets,N,Cin,Cout,T,H,W", CONV_CASES)
 def test_conv_bf16_fwd_dgrad_wgrad_vs_torch(name, wsets, N, Cin, Cout, T, H, W, kernel_variant):
     """Every pass of the bf16 convolution kernels (conv_bf16.hip) against torch conv3d on the same bf16-rounded operands:
@@ -134,7 +138,7 @@ def test_conv_bf16_fwd_dgrad_wgrad_vs_torch(name, wsets, N, Cin, Cout, T, H, W, 
     torch.testing.assert_close(db.cpu(), br3.grad, atol=2e-4 * float(br3.grad.abs().max()) + 1e-6, rtol=2e-4)
 
 
-@variants("default", "conv_bf16_direct")
+@variants("default", "conv_bf16_direct", "conv_bf16_lds")
 def test_conv_bf16_addend_and_grouped_layouts(kernel_variant):
     """dgrad with accumulate (dx += ...) and the two-level channel-group addressing the classifier uses (the heads' conv1
     writes the V slices of its output; the dense joint head reads the V slices of z_q)."""
