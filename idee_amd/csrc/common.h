@@ -96,6 +96,18 @@ template <> __device__ __forceinline__ f32x4 ldx4<bf16_t>(const bf16_t* p) {
   return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
                __uint_as_float(v[1] & 0xffff0000u)};
 }
+// the same load split in two, so that a kernel can issue the memory read an iteration ahead and convert at the point of use
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <> struct Raw4<bf16_t> { typedef u32x2s type; };
+template <typename T> __device__ __forceinline__ typename Raw4<T>::type ldraw4(const T* p) {
+  return *reinterpret_cast<const typename Raw4<T>::type*>(p);
+}
+__device__ __forceinline__ f32x4 cvtraw4(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 cvtraw4(u32x2s v) {
+  return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+               __uint_as_float(v[1] & 0xffff0000u)};
+}
 template <typename T> __device__ __forceinline__ void stx4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void stx4<float>(float* p, f32x4 v) { st4(p, v); }
 template <> __device__ __forceinline__ void stx4<bf16_t>(bf16_t* p, f32x4 v) {
