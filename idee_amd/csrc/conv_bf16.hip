@@ -672,28 +672,43 @@ __global__ __launch_bounds__(256) void conv_bf16_ws_kernel(ConvArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // weight gradient: dWp[wset][tap][cin][coutPad] += sum_pixels x[src(pixel, tap)][cin] dy[pixel][cout], K = pixels, 32 per
-// MFMA.  The structure of wgrad16_split_kernel (conv_mfma.hip): every WAVE owns a strip of 32 pixels of one
-// (input block ga, output block group) pair and walks a run of rows of one (batch item, t), with a wave-private LDS ring of
-// 3 source rows x TSL T-slots staged pixel-major [pixel][16 channels bf16]; the K = pixels operand of x comes out of the
-// transposing LDS read (ds_read_b64_tr_b16: lane (channel i, group g) receives pixels 8g..8g+7 of channel i, shifted by the
-// W tap); dy is read from global memory, one bf16 per (pixel, channel).  All TSL * 9 * NB accumulator tiles stay in registers
-// for the wave's whole share and are flushed once with float atomics.  Any Cin, Cout multiples of 16 (blockIdx.z = pair).
+// MFMA.  Every WAVE owns a strip of 32 KC pixels of one (input block ga, output block group) pair and walks a run of rows of
+// one (batch item, t), with a wave-private LDS ring of 3 source rows x TSL T-slots staged pixel-major [pixel][16 channels
+// bf16] and one staged dy row; both K = pixels operands come out of the transposing LDS read (ds_read_b64_tr_b16).  The K
+// index of a 32-pixel chunk is a PERMUTATION of its pixels, the same for both operands: the lane group kq of the first read
+// takes pixels 4 kq .. 4 kq + 3, of the second 16 + 4 kq .. — a lane group of the read (32 lanes = kq pairs) then touches
+// pixels 0..7 (64 consecutive words: all banks once) where the natural order (pixels 8 kq + ..) put two lanes on every bank
+// (SQ_LDS_BANK_CONFLICT was 43 % of this kernel's LDS cycles), and every tap / chunk offset stays an immediate.
+//   The next row's operands (dy of row h + 1, source row h + 2) are read from memory while row h is multiplied, and the x
+// fragments are read three taps ahead of their MFMA.  All TSL * 9 * NB accumulator tiles stay in registers for the wave's
+// whole share and are flushed once with float atomics.  Any Cin, Cout multiples of 16.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRowPx = 34;                 // staged pixels per row: 32 + halo
-constexpr int kRowW = kRowPx * 8;          // 32-bit words per staged row (16 bf16 channels per pixel)
-
-template <int MODE /*FWD_REP | FWD_S2*/, int TSL, int NB>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
+template <int MODE /*FWD_REP | FWD_S2*/, int TSL, int NB, int KC /*32-pixel K chunks per strip*/, int NWV /*waves per workgroup*/>
+__global__ __launch_bounds__(64 * NWV, 8 / NWV) void wgrad_bf16_kernel(WgradArgs a, int nstrip, int hrun, int nhrun, int gx, int gz,
+                                                                       int pg) {
   constexpr int NTAPS = TSL * 9;
   static_assert(NTAPS * NB <= 36, "accumulator tiles must fit the register file");
-  __shared__ __attribute__((aligned(16))) unsigned s_xw[4][TSL * 3 * kRowW];
+  constexpr int kRowPx = 32 * KC + 2;        // staged pixels per source row: the strip + halo
+  constexpr int kRowW = kRowPx * 8;          // 32-bit words per staged row (16 bf16 channels per pixel)
+  constexpr int kDyW = 32 * KC * 8;          // one staged dy row
+  constexpr int XL = (kRowPx * 4 + 63) / 64; // 8-byte loads per lane and source row
+  constexpr int DL = 2 * KC;                 // 8-byte loads per lane and dy row
+  __shared__ __attribute__((aligned(16))) unsigned s_xw[NWV][TSL * 3 * kRowW + NB * kDyW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
-  const int wset = blockIdx.y;
+  // 1-D grid, XCD-aware: workgroups go to the 8 XCDs round-robin by linear id, and the gz (input block, output block) pairs of
+  // one (unit share bx, weight set) walk the SAME pixels — clusters of `pg` consecutive pairs are given ids 8 apart, so that a
+  // cluster sits on one XCD and shares its L2 (pg: the largest that still spreads the clusters evenly over the 8 XCDs)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cpc = (gz + pg - 1) / pg;                     // clusters per (bx, weight set)
+  const int cl = (slot / pg) * 8 + xcd, pair = (cl % cpc) * pg + slot % pg, comb = cl / cpc;
+  if (comb >= gx * a.wsets || pair >= gz) return;
+  const int bx = comb % gx, wset = comb / gx;
   unsigned* s_x = s_xw[wave];
+  unsigned* s_dy = s_x + TSL * 3 * kRowW;
   const int ngb = (a.CoutPad / 16) / NB;
-  const int ga = blockIdx.z / ngb;
-  const int gb0 = (blockIdx.z % ngb) * NB;
+  const int ga = pair / ngb;
+  const int gb0 = (pair % ngb) * NB;
   bfp x = reinterpret_cast<bfp>(a.x);
   bfp dy = reinterpret_cast<bfp>(a.dy);
   f32x4 acc[NTAPS][NB];
@@ -707,105 +722,158 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradArgs a, int nst
   const int nsub = (a.W + 15) / 16;
   const int nb = a.B / a.wsets;
   const long nunits = (long)nb * a.To * nhrun * nstrip;
-  // transposed-read address of this lane inside a staged row, pixel shift 0: lane 4q + c of group g supplies pixel
-  // 8g + q (+ 4 for the second read), channels 4c .. 4c + 3
-  const int tr_off = (8 * kq + (r16 >> 2)) * 8 + 2 * (r16 & 3);
+  // transposed-read address of this lane inside a staged row (words): lane 4 q + c of group kq supplies pixel 4 kq + q of the
+  // chunk (+ 16 for the second read), channels 4 c .. 4 c + 3; tap shift, second read and chunk are immediates
+  const unsigned* trb_x = s_x + (4 * kq + (r16 >> 2)) * 8 + 2 * (r16 & 3);
+  const unsigned* trb_dy = s_dy + (4 * kq + (r16 >> 2)) * 8 + 2 * (r16 & 3);
   auto tr = [&](const unsigned* p) __attribute__((always_inline)) {
     const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
     return __builtin_bit_cast(unsigned long long, t);
   };
 
-  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+  for (long un = (long)bx * NWV + wave; un < nunits; un += (long)gx * NWV) {
     long r = un;      // t fastest: the users of a source row run together
     const int t = (int)(r % a.To); r /= a.To;
     const int sp = (int)(r % nstrip); r /= nstrip;
     const int hr = (int)(r % nhrun);
     const int b = (int)(r / nhrun) * a.wsets + wset;
-    const int my_sub = min(2, nsub - sp * 2);
-    const int p0 = sp * 32;
+    const int my_sub = min(2 * KC, nsub - sp * 2 * KC);
+    const int p0 = sp * 32 * KC;
     const int rowlen = my_sub * 16 + 2;
     const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
-    int res0 = -1, res1 = -1, res2 = -1;
     bfp x_b = x + (long)b * a.x_sB + goff(ga, a.x_gpu, a.x_sU, a.x_sG);
     bfp dy_b = dy + (long)b * a.y_sB + (long)t * a.y_sT;
     int tsrc[TSL];
 #pragma unroll
     for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : a.kt * t + ot;
 
-    for (int h = h0; h < h1; ++h) {
+    auto wsync = [&]() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // dy of this row: lane (cout = r16, pixels p0 + 8 kq + {0..7}); pixels past the row end contribute zero
-      u32x4 Bv[NB];
+    };
+    // per-lane constants of the unit: source offsets inside a row (clamped) and the padding flags
+    long xo[XL], yo[DL];
+    bool xon[XL], yon[DL];
+#pragma unroll
+    for (int k = 0; k < XL; ++k) {
+      const int u = lane + 64 * k;
+      const int w = p0 + (u >> 2) - 1;
+      xo[k] = (long)min(max(w, 0), a.W - 1) * a.x_sW + 4 * (u & 3);
+      xon[k] = u < rowlen * 4 && (MODE == FWD_REP || (w >= 0 && w < a.W));
+    }
+#pragma unroll
+    for (int k = 0; k < DL; ++k) {
+      const int u = lane + 64 * k, px = u >> 2;
+      yo[k] = (long)min(p0 + px, a.W - 1) * a.y_sW + 4 * (u & 3);
+      yon[k] = px < 16 * my_sub && p0 + px < a.W;
+    }
+    // source row hs of the TSL frames -> registers (lane u = 4 pixel + channel quad).  Unconditional, from clamped addresses:
+    // the padding zeros are applied when the row is written to LDS (a select here would make the wave wait for the load at once)
+    auto load_x = [&](int hs, u32x2s (&stg)[TSL][XL]) {
+#pragma unroll
+      for (int ot = 0; ot < TSL; ++ot) {
+        bfp src = x_b + (long)tsrc[ot] * a.x_sT + (long)min(max(hs, 0), a.H - 1) * a.x_sH;
+#pragma unroll
+        for (int k = 0; k < XL; ++k) stg[ot][k] = *reinterpret_cast<const u32x2s*>(src + xo[k]);
+      }
+    };
+    auto store_x = [&](int hs, const u32x2s (&stg)[TSL][XL]) {
+      const bool inside = hs >= 0 && hs < a.H;
+      const int slot = (hs + 3) % 3;
+#pragma unroll
+      for (int ot = 0; ot < TSL; ++ot) {
+        unsigned* dst = s_x + (ot * 3 + slot) * kRowW + 2 * lane;
+#pragma unroll
+        for (int k = 0; k < XL; ++k)
+          if (lane + 64 * k < kRowPx * 4)      // (past a narrow strip: zeros)
+            *reinterpret_cast<u32x2s*>(dst + 128 * k) = (xon[k] && inside) ? stg[ot][k] : u32x2s{0u, 0u};
+      }
+    };
+    // dy of row h, the NB output blocks of this wave (lane u = 4 pixel + channel quad)
+    auto load_dy = [&](int h, u32x2s (&dv)[NB][DL]) {
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
-        unsigned short hv[8];
-        const int co = (gb0 + n) * 16 + r16;
-        bfp dy_r = dy_b + (long)h * a.y_sH + goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16;     // (one division per row, not per pixel)
+        bfp dy_r = dy_b + (long)h * a.y_sH + goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG);          // (one division per row, not per pixel)
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const int p = p0 + 8 * kq + jj;
-          const bool on = 8 * kq + jj < 16 * my_sub && p < a.W && co < a.cout_real;
-          hv[jj] = on ? *reinterpret_cast<const unsigned short*>(dy_r + (long)p * a.y_sW) : (unsigned short)0;
-          bsum[n] += __uint_as_float((unsigned)hv[jj] << 16);
-        }
-        Bv[n] = u32x4{(unsigned)hv[0] | ((unsigned)hv[1] << 16), (unsigned)hv[2] | ((unsigned)hv[3] << 16),
-                      (unsigned)hv[4] | ((unsigned)hv[5] << 16), (unsigned)hv[6] | ((unsigned)hv[7] << 16)};
+        for (int k = 0; k < DL; ++k) dv[n][k] = *reinterpret_cast<const u32x2s*>(dy_r + yo[k]);
+      }
+    };
+    auto store_dy = [&](const u32x2s (&dv)[NB][DL]) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int k = 0; k < DL; ++k)
+          *reinterpret_cast<u32x2s*>(s_dy + n * kDyW + 2 * lane + 128 * k) = yon[k] ? dv[n][k] : u32x2s{0u, 0u};
+    };
+    auto row_src = [&](int h, int oh) { return MODE == FWD_REP ? min(max(h + oh - 1, 0), a.H - 1) : h + oh - 1; };
+    // prologue of the run: the rows h0 - 1 and h0 staged directly; then, per row h, the NEXT row's operands (dy of row h + 1, the
+    // source row h + 2) are read while row h is multiplied (SQ_WAIT_ANY was 44 % of the wave cycles with the loads in front
+    // of their use)
+    u32x2s stg[TSL][XL];
+    u32x2s dv[NB][DL];
+    wsync();
+    {
+      u32x2s s0[TSL][XL];
+      load_x(row_src(h0, 0), s0);
+      load_x(row_src(h0, 1), stg);
+      store_x(row_src(h0, 0), s0);
+      if (row_src(h0, 1) != row_src(h0, 0)) store_x(row_src(h0, 1), stg);
+    }
+    load_x(row_src(h0, 2), stg);
+    load_dy(h0, dv);
+    for (int h = h0; h < h1; ++h) {
+      wsync();      // the reads of row h - 1 are done
+      store_dy(dv);
+      {
+        const int hs2 = row_src(h, 2);
+        if (hs2 != row_src(h, 1)) store_x(hs2, stg);       // (replicate mode, last row: the clamped row is already there)
+      }
+      wsync();
+      if (h + 1 < h1) {
+        load_x(row_src(h + 1, 2), stg);
+        load_dy(h + 1, dv);
       }
       int slot_of[3];
 #pragma unroll
-      for (int oh = 0; oh < 3; ++oh) {
-        const int hs = MODE == FWD_REP ? min(max(h + oh - 1, 0), a.H - 1) : h + oh - 1;
-        const bool inside = hs >= 0 && hs < a.H;
-        const int slot = (hs + 3) % 3;
-        slot_of[oh] = slot;
-        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
-        if (cur == hs + 1) continue;
-        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
-        u32x2s stg[TSL][3];
+      for (int oh = 0; oh < 3; ++oh) slot_of[oh] = (row_src(h, oh) + 3) % 3;
+      // acc[tap][cin][cout] += sum over the strip's pixels of x[pixel + tap offset][cin] dy[pixel][cout]
 #pragma unroll
-        for (int ot = 0; ot < TSL; ++ot) {
-          bfp src = x_b + (long)tsrc[ot] * a.x_sT + (long)hs * a.x_sH;
+      for (int c = 0; c < KC; ++c) {
+        if (c > 0 && 32 * c >= 16 * my_sub) continue;        // a narrow last strip: this chunk holds no pixel
+        u32x4 Bv[NB];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int u = lane + 64 * k;
-            u32x2s v = {0u, 0u};
-            if (u < rowlen * 4 && inside) {
-              const int w = p0 + (u >> 2) - 1;
-              if (MODE == FWD_REP) v = *reinterpret_cast<const u32x2s*>(src + (long)min(max(w, 0), a.W - 1) * a.x_sW + 4 * (u & 3));
-              else if (w >= 0 && w < a.W) v = *reinterpret_cast<const u32x2s*>(src + (long)w * a.x_sW + 4 * (u & 3));
-            }
-            stg[ot][k] = v;
-          }
+        for (int n = 0; n < NB; ++n) {
+          const unsigned long long b0 = tr(trb_dy + n * kDyW + c * 256), b1 = tr(trb_dy + n * kDyW + c * 256 + 128);
+          Bv[n] = u32x4{(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32)};
         }
+        auto a_read = [&](int tp, unsigned long long (&r2)[2]) {
+          const int ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
+          const unsigned* ap = trb_x + (ot * 3 + slot_of[oh]) * kRowW + c * 256 + ow * 8;
+          r2[0] = tr(ap);
+          r2[1] = tr(ap + 128);
+        };
+        constexpr int AD = 3;
+        unsigned long long Ar[AD + 1][2];
 #pragma unroll
-        for (int ot = 0; ot < TSL; ++ot) {
-          unsigned* dst = s_x + (ot * 3 + slot) * kRowW;
+        for (int tp = 0; tp < AD; ++tp) a_read(tp, Ar[tp]);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int u = lane + 64 * k;
-            if (u < kRowPx * 4) *reinterpret_cast<u32x2s*>(dst + (u >> 2) * 8 + (u & 3) * 2) = stg[ot][k];   // past a one-block strip: zeros
-          }
+        for (int tp = 0; tp < NTAPS; ++tp) {
+          if (tp + AD < NTAPS) a_read(tp + AD, Ar[(tp + AD) % (AD + 1)]);
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned long long a0 = Ar[tp % (AD + 1)][0], a1 = Ar[tp % (AD + 1)][1];
+          const u32x4 Av = {(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)};
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[tp][n] = mfma_bf(Av, Bv[n], acc[tp][n]);
+        }
+        if (a.dbias && ga == 0) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2)
+              bsum[n] += __uint_as_float(Bv[n][w2] << 16) + __uint_as_float(Bv[n][w2] & 0xffff0000u);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // acc[tap][cin][cout] += sum over the strip's 32 pixels of x[pixel + tap offset][cin] dy[pixel][cout]
-#pragma unroll
-      for (int ot = 0; ot < TSL; ++ot)
-#pragma unroll
-        for (int oh = 0; oh < 3; ++oh)
-#pragma unroll
-          for (int ow = 0; ow < 3; ++ow) {
-            const unsigned* ap = s_x + (ot * 3 + slot_of[oh]) * kRowW + ow * 8 + tr_off;
-            const unsigned long long a0 = tr(ap), a1 = tr(ap + 4 * 8);
-            const u32x4 Av = {(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)};
-            const int tp = (ot * 3 + oh) * 3 + ow;
-#pragma unroll
-            for (int n = 0; n < NB; ++n) acc[tp][n] = mfma_bf(Av, Bv[n], acc[tp][n]);
-          }
     }
   }
   float* dw = a.dwp + ((long)wset * NTAPS * a.Cin + ga * 16) * a.CoutPad;
@@ -930,23 +998,32 @@ int bf16_wgrad(const idee_conv_desc* d, const void* x, const void* dy, float* dw
   a.x_sU = d->x_sU; a.x_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30); a.y_sU = d->y_sU; a.y_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30);
   a.rows = a.To * d->H;
   const int Ga = d->Cin / 16, Gb = a.CoutPad / 16;
-  const int nstrip = cdiv(cdiv(d->W, 16), 2);
+  // strips of 64 pixels (two K chunks per row and tap) where the ring fits 8 waves per CU; the 3^3 mode's 3 x 3-row ring of
+  // 64-pixel rows leaves room for 7 waves only — measured slower (1.99 ms) than 8 waves on 32-pixel strips (1.76 ms)
+  const int KC = d->mode == IDEE_CONV_K333_REPLICATE ? 1 : 2;
+  const int nstrip = cdiv(cdiv(d->W, 16), 2 * KC);
   const long btr = (long)(d->B / d->wsets) * a.To;
-  // rows per work unit: enough units to fill the chip twice over, runs of at least 8 rows
-  auto launch = [&](auto kern, int NB) {
+  // two 4-wave workgroups per CU;
+  // rows per work unit: at least 8 units per wave (a wave's share is a whole number of units), runs of at least 8 rows
+  auto launch = [&](auto kern, int NB, int nwv) {
     const int gz = Ga * (Gb / NB);
     int hrun = d->H;
-    while (hrun > 8 && btr * cdiv(d->H, hrun) * nstrip * d->wsets * gz < 2L * kCUs * 8) hrun = (hrun + 1) / 2;
+    while (hrun > 8 && btr * cdiv(d->H, hrun) * nstrip * d->wsets * gz < 8L * kCUs * nwv) hrun = (hrun + 1) / 2;   // >= 8 units per wave
     const int nhrun = cdiv(d->H, hrun);
     const long nunits = btr * nhrun * nstrip;
-    long gx = ((long)kCUs * 2) / ((long)d->wsets * gz);
+    long gx = ((long)kCUs * (8 / nwv)) / ((long)d->wsets * gz);      // 8 waves per CU in all
     if (gx < 1) gx = 1;
-    if (gx > (nunits + 3) / 4) gx = (nunits + 3) / 4;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, d->wsets, gz), dim3(256), 0, st, a, nstrip, hrun, nhrun);
+    if (gx > (nunits + nwv - 1) / nwv) gx = (nunits + nwv - 1) / nwv;
+    const long ncomb = gx * d->wsets;
+    int pg = gz;
+    auto ncl = [&](int g) { return ncomb * ((gz + g - 1) / g); };
+    while (pg > 1 && ncl(pg) % 8 != 0 && ncl(pg) < 64) pg = (pg + 1) / 2;
+    const long grid = ((ncl(pg) + 7) / 8) * 8 * pg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nwv), 0, st, a, nstrip, hrun, nhrun, (int)gx, gz, pg);
   };
-  if (d->mode == IDEE_CONV_K333_REPLICATE) launch(wgrad_bf16_kernel<FWD_REP, 3, 1>, 1);
-  else if (d->mode == IDEE_CONV_K233_S2_ZERO) launch(wgrad_bf16_kernel<FWD_S2, 2, 1>, 1);      // (NB = 2: 144 accumulator registers, spills)
-  else { if (Gb % 2 == 0) launch(wgrad_bf16_kernel<FWD_S2, 1, 2>, 2); else launch(wgrad_bf16_kernel<FWD_S2, 1, 1>, 1); }
+  if (d->mode == IDEE_CONV_K333_REPLICATE) launch(wgrad_bf16_kernel<FWD_REP, 3, 1, 1, 4>, 1, 4);
+  else if (d->mode == IDEE_CONV_K233_S2_ZERO) launch(wgrad_bf16_kernel<FWD_S2, 2, 1, 2, 4>, 1, 4);      // (NB = 2: 144 accumulator registers, spills)
+  else { if (Gb % 2 == 0) launch(wgrad_bf16_kernel<FWD_S2, 1, 2, 2, 4>, 2, 4); else launch(wgrad_bf16_kernel<FWD_S2, 1, 1, 2, 4>, 1, 4); }
   return IDEE_OK;
 }
 
