@@ -671,6 +671,203 @@ __global__ __launch_bounds__(256) void conv_bf16_ws_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// WIDE inputs (Cin >= 64: the joint head's 192 -> 192 (2,3,3) convs and the 192 -> 16 data gradient of the sign-field convs;
+// zero-padding modes).  conv_bf16_kernel re-requests every (tap, channel block) of its 6 x 66 x 384-byte input window from
+// beyond L2 — 9.7 GB fetched per launch for a 0.27 GB input, 4.9 TB/s of fabric traffic: that, not the MFMA (25 % busy), is
+// its bound.  Here a workgroup owns 8 rows x 48 pixels of one output frame (two rows per wave: a weight fragment from L1 feeds
+// 6 MFMAs; W = 424 is 8.83 tiles of 48) and walks the input channels in CHUNKS of 32: the chunk's window (the source frames x
+// 10 rows x 50 pixels x 64 B) goes through LDS once, by LDS-DMA (global_load_lds_dwordx4: no staging registers) into the
+// other half of a double buffer while this chunk is multiplied — one barrier per chunk; padding positions read a 16-byte zero
+// constant.  The accumulators of all chunks stay in registers; A and B fragments are read one tap ahead of their MFMAs.
+// Traffic: 1.3x the input per output-channel slice (row / column halo).
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const unsigned kZero16[4] = {0u, 0u, 0u, 0u};
+// (as conv_mfma.hip's glds16: the DMA is inline asm and its completion is counted by hand — s_waitcnt vmcnt(0) before the barrier
+// that publishes a buffer)
+__device__ __forceinline__ void glds16_bf(const bf16_t* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int MODE /*FWD_S2 | DGRAD_S2*/, int NT, int KT>
+__global__ __launch_bounds__(256) void conv_bf16_cl_kernel(ConvArgs a) {
+  constexpr int RW = 2, MB = 3, MT = RW * MB;          // rows per wave, 16-pixel blocks per row, column blocks per wave
+  constexpr int TW = 16 * MB;                          // tile width
+  constexpr int NR = 4 * RW + 2, NP = TW + 2;          // staged rows and pixels
+  constexpr int NF = MODE == FWD_S2 ? KT : 1;          // staged frames
+  constexpr int PXB = 64, ROWB = NP * PXB, FRB = NR * ROWB;
+  constexpr int NSLOT = NF * NR * NP * 4;              // 16-byte slots of one staged chunk
+  constexpr int NDMA = (NSLOT + 63) / 64;              // wave-wide DMA instructions per chunk
+  constexpr int BUFB = NDMA * 1024;                    // bytes of one buffer (padded to whole DMA instructions)
+  constexpr bool FWD = MODE == FWD_S2;
+  constexpr int NTAP = NF * 9;
+  __shared__ __attribute__((aligned(1024))) unsigned char s_act[2 * BUFB];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g4 = lane >> 4, hlf = g4 >> 1, ko = 8 * (g4 & 1);
+  const int b = blockIdx.y, ntg = blockIdx.z;
+  const int wset = b % a.wsets;
+  bfp in_b = reinterpret_cast<bfp>(a.in) + (long)b * a.i_sB;
+  bfp wp = reinterpret_cast<bfp>(a.wp) + (long)wset * a.ntaps * a.Gk * a.GnTot * 256 + (long)ntg * NT * 256 + j * 16 + ko;
+  bfp ref = reinterpret_cast<bfp>(a.relu_ref);
+  bfp addend = reinterpret_cast<bfp>(a.addend);
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+  bfp zero16 = reinterpret_cast<bfp>(kZero16);
+  const unsigned s_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)s_act);
+  const int nck = a.Gk / 2;                             // channel chunks
+  const int wtiles = (a.Wo + TW - 1) / TW, hgroups = (a.Ho + 4 * RW - 1) / (4 * RW);
+  const long units = (long)a.To * hgroups * wtiles;
+  int lo[3];                                            // this lane's B fragment inside a staged row, staged pixel j + d (octet swizzle)
+#pragma unroll
+  for (int d = 0; d < 3; ++d) lo[d] = (j + d) * PXB + ((g4 ^ ((((j + d) >> 2) & 1) << 1)) << 4);
+
+  // stage s of this workgroup = (unit, chunk); its window: frames, rows h0 - 1 .., pixels w0 - 1 ..
+  struct Stage { int t, h0, w0, ck; };
+  const long nstage = (units > blockIdx.x ? (units - blockIdx.x + gridDim.x - 1) / gridDim.x : 0) * nck;
+  auto stage_of = [&](long sidx) {
+    Stage st;
+    const long ul = sidx / nck;
+    const long un = blockIdx.x + ul * gridDim.x;
+    st.ck = (int)(sidx - ul * nck);
+    const int wt = (int)(un % wtiles);
+    const long r = un / wtiles;
+    st.h0 = (int)(r % hgroups) * 4 * RW;
+    st.t = (int)(r / hgroups);
+    st.w0 = wt * TW;
+    return st;
+  };
+  auto frame_src = [&](int t, int f) { return FWD ? KT * t + f : (KT == 2 ? t >> 1 : t); };
+  // The DMA instructions of a stage are dealt round-robin to the 4 waves (ND each); lane -> slot -> (frame, row, pixel, stored
+  // octet).  A lane's source offsets inside the window depend on the UNIT only (the chunk adds a uniform channel offset: the
+  // host guarantees that the two 16-channel blocks of a chunk are i_sG apart), so they are computed once per unit — per
+  // chunk an instruction then costs a select and a 64-bit add (the full address arithmetic, ~60 VALU + a division per
+  // instruction, made the kernel DMA-issue bound: 1.64 ms against 0.96 ms without the staging).
+  constexpr int ND = (NDMA + 3) / 4;
+  int soff[ND];
+  unsigned sok = 0;
+  int ut = -1, uh0 = -1, uw0 = -1;
+  auto unit_offsets = [&](const Stage& st) {
+    if (st.t == ut && st.h0 == uh0 && st.w0 == uw0) return;
+    ut = st.t; uh0 = st.h0; uw0 = st.w0;
+    sok = 0;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int sl = (wave + 4 * i) * 64 + lane;
+      const int f = sl / (NR * NP * 4), rem = sl - f * (NR * NP * 4);
+      const int r = rem / (NP * 4), rem2 = rem - r * (NP * 4), px = rem2 >> 2;
+      const int oc = (rem2 & 3) ^ (((px >> 2) & 1) << 1);                     // source octet of this stored position
+      const int hr = st.h0 - 1 + r, wq = st.w0 - 1 + px, fs = frame_src(st.t, f);
+      const bool ok = wave + 4 * i < NDMA && sl < NSLOT && (unsigned)hr < (unsigned)a.Hi && (unsigned)wq < (unsigned)a.Wi && fs < a.Ti;
+      sok |= ok ? (1u << i) : 0u;
+      soff[i] = ok ? (int)((long)fs * a.i_sT + (long)hr * a.i_sH + (long)wq * a.i_sW + (long)(oc >> 1) * a.i_sG + 8 * (oc & 1)) : 0;
+    }
+  };
+  auto dma_one = [&](int i, bfp chunk_base, int buf) {               // i static
+    if (wave + 4 * i >= NDMA) return;
+    bfp src = ((sok >> i) & 1u) ? chunk_base + soff[i] : zero16;
+    glds16_bf(src, __builtin_amdgcn_readfirstlane(s_base + buf * BUFB + (wave + 4 * i) * 1024));
+  };
+  auto chunk_base_of = [&](const Stage& st) { return in_b + goff(2 * st.ck, a.i_gpu, a.i_sU, a.i_sG); };
+
+  f32x4 acc[MT][NT];
+  if (nstage > 0) {
+    const Stage s0 = stage_of(0);
+    unit_offsets(s0);
+    bfp cb0 = chunk_base_of(s0);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dma_one(i, cb0, 0);
+  }
+  for (long sidx = 0; sidx < nstage; ++sidx) {
+    const Stage st = stage_of(sidx);
+    const int buf = (int)(sidx & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the chunk has landed
+    __syncthreads();                                   // the chunk is complete; the other buffer's readers are done
+    // the next stage's window: its DMA instructions are issued between the taps below (one per tap, in the MFMAs' shadow)
+    const bool more = sidx + 1 < nstage;
+    Stage sn = st;
+    if (more) { sn = stage_of(sidx + 1); unit_offsets(sn); }
+    bfp cbn = chunk_base_of(sn);
+    int dma_done = 0;
+    if (st.ck == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool live = st.h0 + RW * wave < a.Ho && frame_src(st.t, 0) < a.Ti;       // this wave's rows exist
+    if (live) {
+      const int tt = (!FWD && KT == 2) ? (st.t & 1) : 0;                       // the data gradient's temporal weight tap
+      bfp wck = wp + (long)(2 * st.ck + hlf) * a.GnTot * 256;
+      const unsigned char* sb = s_act + buf * BUFB + (RW * wave) * ROWB;
+      auto a_load = [&](int k, u32x4 (&A)[NT]) {
+        const int f = k / 9, oh = (k / 3) % 3, ow = k % 3;
+        const int tap = ((FWD ? f : tt) * 3 + oh) * 3 + ow;
+        bfp wq = wck + (long)tap * a.Gk * a.GnTot * 256;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) A[n] = ld16(wq + n * 256);
+      };
+      auto b_read = [&](int k, u32x4 (&Bv)[MT]) {
+        const int f = k / 9, oh = (k / 3) % 3, ow = k % 3;
+        const unsigned char* bp = sb + f * FRB + (FWD ? oh : 2 - oh) * ROWB + lo[FWD ? ow : 2 - ow];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) Bv[rr * MB + mb] = *reinterpret_cast<const u32x4*>(bp + rr * ROWB + mb * 16 * PXB);
+      };
+      u32x4 Ar[2][NT], Br[2][MT];
+      a_load(0, Ar[0]);
+      b_read(0, Br[0]);
+#pragma unroll
+      for (int k = 0; k < NTAP; ++k) {
+        if (k + 1 < NTAP) { a_load(k + 1, Ar[(k + 1) & 1]); b_read(k + 1, Br[(k + 1) & 1]); }
+        constexpr int per = (ND + NTAP - 1) / NTAP;                  // DMA instructions per tap
+#pragma unroll
+        for (int i = k * per; i < (k + 1) * per && i < ND; ++i)
+          if (more) dma_one(i, cbn, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf(Ar[k & 1][n], Br[k & 1][m], acc[m][n]);
+      }
+      dma_done = 1;
+    }
+    if (!dma_done && more) {
+#pragma unroll
+      for (int i = 0; i < ND; ++i) dma_one(i, cbn, buf ^ 1);
+    }
+    if (st.ck != nck - 1) continue;
+    // ---- epilogue of the unit (as conv_bf16_kernel) ----
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      const int h = st.h0 + RW * wave + rr;
+      if (h >= a.Ho) continue;
+      const long row_o = (long)b * a.o_sB + (long)st.t * a.o_sT + (long)h * a.o_sH;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int p = st.w0 + 16 * mb + j;
+        if (p >= a.Wo) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int cg = ntg * NT + n;
+          f32x4 v = live ? acc[rr * MB + mb][n] : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (a.bias) v += ld4(a.bias + (long)wset * a.GnTot * 16 + cg * 16 + 4 * g4);
+          if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          const long o = row_o + (long)p * a.o_sW + (a.o_gpu >= a.GnTot ? (long)cg * a.o_sG : goff(cg, a.o_gpu, a.o_sU, a.o_sG)) + 4 * g4;
+          if (ref) {
+            const f32x4 rr4 = ldx4<bf16_t>(ref + o);
+            v[0] = rr4[0] > 0.f ? v[0] : 0.f; v[1] = rr4[1] > 0.f ? v[1] : 0.f;
+            v[2] = rr4[2] > 0.f ? v[2] : 0.f; v[3] = rr4[3] > 0.f ? v[3] : 0.f;
+          }
+          if (addend) v += ldx4<bf16_t>(addend + o);
+          stx4<bf16_t>(out + o, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient: dWp[wset][tap][cin][coutPad] += sum_pixels x[src(pixel, tap)][cin] dy[pixel][cout], K = pixels, 32 per
 // MFMA.  Every WAVE owns a strip of 32 KC pixels of one (input block ga, output block group) pair and walks a run of rows of
 // one (batch item, t), with a wave-private LDS ring of 3 source rows x TSL T-slots staged pixel-major [pixel][16 channels
@@ -915,6 +1112,25 @@ int launch_conv_bf16(ConvArgs& a, hipStream_t stream) {
     else if (a.kt == 2) hipLaunchKernelGGL((conv_bf16_ws_kernel<MODE, REP ? 3 : 2>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((conv_bf16_ws_kernel<MODE, REP ? 3 : 1>), grid, dim3(256), 0, stream, a);
     return IDEE_OK;
+  }
+  // wide inputs in the zero-padding modes: channel-chunked LDS staging (IDEE_CONV_BF16=direct keeps conv_bf16_kernel)
+  if constexpr (MODE == FWD_S2 || MODE == DGRAD_S2) {
+    const bool chunk_ok = a.i_gpu >= a.Gk || a.i_gpu % 2 == 0;              // the two 16-channel blocks of a chunk lie i_sG apart
+    const bool off_ok = (long)a.Ti * a.i_sT < (1L << 31);                     // 32-bit window offsets
+    if (a.Gk >= 4 && a.Gk % 2 == 0 && (a.kt == 1 || a.kt == 2) && chunk_ok && off_ok && !env_is("IDEE_CONV_BF16", "direct")) {
+      const long units = (long)a.To * ((a.Ho + 7) / 8) * ((a.Wo + 47) / 48);
+      const int wg_per_cu = (MODE == FWD_S2 && a.kt == 2) ? 1 : (NT >= 6 ? 1 : 2);      // LDS: 128 KB with two staged frames, else 64 KB
+      long gx = ((long)kCUs * wg_per_cu) / ((long)a.B * gz);
+      if (gx < 1) gx = 1;
+      if (gx > units) gx = units;
+      const dim3 grid((unsigned)gx, a.B, gz);
+#define LCC(NT_, KT_) hipLaunchKernelGGL((conv_bf16_cl_kernel<MODE, NT_, KT_>), grid, dim3(256), 0, stream, a)
+#define LCCN(KT_) do { if (NT == 6) LCC(6, KT_); else if (NT == 3) LCC(3, KT_); else if (NT == 2) LCC(2, KT_); else LCC(1, KT_); } while (0)
+      if (a.kt == 2) LCCN(2); else LCCN(1);
+#undef LCCN
+#undef LCC
+      return IDEE_OK;
+    }
   }
   if (a.Gk <= 2 && !env_is("IDEE_CONV_BF16", "direct")) {
     const long units = (long)((a.Ho + 3) / 4) * ((a.Wo + 63) / 64);

@@ -62,6 +62,9 @@ CONV_CASES = [
     ("k333", 1, 1, 32, 32, 2, 2, 63),          # both W edges in one tile, T = 2: every frame and row is a border
     ("k333", 1, 1, 32, 32, 1, 9, 130),         # T = 1: both temporal folds on the same frame
     ("k233", 2, 1, 32, 32, 7, 5, 64),          # odd T (the last frame has no output)
+    ("k233", 1, 1, 64, 96, 4, 11, 50),         # wide input: the channel-chunked LDS-DMA kernel, 2-pixel last tile, 3 idle rows
+    ("k233", 2, 1, 192, 192, 3, 9, 47),        # odd T through the chunked kernel (NT = 6), a tile one pixel short
+    ("k133", 1, 2, 64, 16, 2, 17, 97),         # (1,3,3) wide -> 16
     ("k233", 3, 1, 32, 32, 4, 5, 40),
     ("k233", 1, 2, 96, 96, 4, 4, 33),
     ("k233", 1, 1, 192, 192, 2, 3, 20),
