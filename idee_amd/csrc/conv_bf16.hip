@@ -1238,7 +1238,10 @@ int bf16_wgrad(const idee_conv_desc* d, const void* x, const void* dy, float* dw
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nwv), 0, st, a, nstrip, hrun, nhrun, (int)gx, gz, pg);
   };
   if (d->mode == IDEE_CONV_K333_REPLICATE) launch(wgrad_bf16_kernel<FWD_REP, 3, 1, 1, 4>, 1, 4);
-  else if (d->mode == IDEE_CONV_K233_S2_ZERO) launch(wgrad_bf16_kernel<FWD_S2, 2, 1, 2, 4>, 1, 4);      // (NB = 2: 144 accumulator registers, spills)
+  else if (d->mode == IDEE_CONV_K233_S2_ZERO) {
+    if (Gb % 2 == 0 && Gb >= 4) launch(wgrad_bf16_kernel<FWD_S2, 2, 2, 2, 4>, 2, 4);     // wide outputs: an x fragment feeds two output blocks
+    else launch(wgrad_bf16_kernel<FWD_S2, 2, 1, 2, 4>, 1, 4);
+  }
   else { if (Gb % 2 == 0) launch(wgrad_bf16_kernel<FWD_S2, 1, 2, 2, 4>, 2, 4); else launch(wgrad_bf16_kernel<FWD_S2, 1, 1, 2, 4>, 1, 4); }
   return IDEE_OK;
 }
