@@ -2439,7 +2439,8 @@ void split_tiles(ConvArgs& a, int Wframe) {
 }
 
 // IDEE_CONV_MATH=split selects the split-precision 16 -> 16 kernels (default: exact f32 MFMA)
-bool conv_split_math() { return env_is("IDEE_CONV_MATH", "split"); }
+// (IDEE_CONV_MATH=fwd22: only the forward passes, whose f16 pieces round operands at 2^-22; see swin_mfma.hip split_math)
+bool conv_split_math(bool forward) { return env_is("IDEE_CONV_MATH", "split") || (forward && env_is("IDEE_CONV_MATH", "fwd22")); }
 
 template <int MODE>
 int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
@@ -2447,7 +2448,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
     // 32 -> 32 replicate convolutions (config #4's width) as 2 x 2 sub-problems on the 16 -> 16 strip kernel: output block n =
     // sum over input blocks g, the second pass adding to the first in place (the generic kernel ran them at 73-78 TFLOP/s)
     const bool no_split = env_is("IDEE_CONV32", "generic"), reg16 = env_is("IDEE_CONV16", "regs");   // read at every launch
-    if (!cin1 && !no_split && !reg16 && !conv_split_math() && a.Gk == 2 && a.GnTot == 2 && a.cout_real == 32 && !a.w_tap_stride &&
+    if (!cin1 && !no_split && !reg16 && !conv_split_math(MODE == FWD_REP || MODE == FWD_S2) && a.Gk == 2 && a.GnTot == 2 && a.cout_real == 32 && !a.w_tap_stride &&
         !(a.addend && a.relu)) {
       const int GA = a.Gk, GB = a.GnTot;        // fwd: input, output blocks ; dgrad: dy, dx blocks (packed [tap][GA][GB])
       for (int n = 0; n < GB; ++n)
@@ -2484,7 +2485,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       const int hrun = pick_hrun(a.Ho, bt * nstrip, a.wsets, 2);
       const int nhrun = cdiv(a.Ho, hrun);
       const long nunits = bt * nhrun * nstrip;
-      if (conv_split_math()) {      // opt-in split-precision path: f16 pieces forward, bf16 pieces in the data gradient
+      if (conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) {      // opt-in split-precision path: f16 pieces forward, bf16 pieces in the data gradient
         auto kern = conv16_split_kernel<MODE, (MODE == FWD_REP || MODE == FWD_S2)>;
         const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
         hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
@@ -2543,7 +2544,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         a.hgroups = imin(imax(g_b / a.To, 1), cdiv((long)a.Ho * a.nsub, 32));
         a.tiles = a.To * a.hgroups;
       }
-      if (conv_split_math() && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2)) {
+      if (conv_split_math(MODE == FWD_REP || MODE == FWD_S2) && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2)) {
         const long lds2 = 2 * slab_bytes;
 #define LCS(NT_)                                                                                               \
   do {                                                                                                         \
@@ -2777,7 +2778,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
     hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits, 4), (long)d->wsets * gz, wg_per_cu(kern, 256)), d->wsets, gz), \
                        dim3(256), 0, st, a, nstrip, hr2, nhr2);                                               \
   } while (0)
-    const bool split = conv_split_math() && Gb == 1 && Ga == 1;
+    const bool split = conv_split_math(false) && Gb == 1 && Ga == 1;
     if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSTRIP((wgrad16_split_kernel<FWD_S2, 2>));
     else if (rep && !env_is("IDEE_WGRAD16_REGS", "1")) {

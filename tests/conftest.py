@@ -39,6 +39,7 @@ KERNEL_VARIANTS = {
     "swin_split": {"IDEE_SWIN_MATH": "split"},                       # two-piece split GEMMs in the Swin block (opt-in)
     "conv_split": {"IDEE_CONV_MATH": "split"},                       # split-precision convolutions (opt-in)
     "all_split": {"IDEE_SWIN_MATH": "split", "IDEE_CONV_MATH": "split"},
+    "fwd22": {"IDEE_SWIN_MATH": "fwd22", "IDEE_CONV_MATH": "fwd22"},   # split kernels in the forward only, exact backward
     "conv16_regs": {"IDEE_CONV16": "regs"},                          # register-staged 16->16 strip kernel
     "wgrad16_regs": {"IDEE_WGRAD16_REGS": "1"},                      # register-staged 3^3 weight gradient
     "conv32_generic": {"IDEE_CONV32": "generic"},                    # 32->32 on the generic kernel

@@ -575,7 +575,7 @@ def _safe_tokens(a, sd, cfg):
 
 
 @pytest.mark.parametrize("tag", ["swin_v2_14x18", "swin_v6_8x8_c2", "cnn_v2_12x16"])
-@variants('default', 'all_split')
+@variants('default', 'all_split', 'fwd22')
 def test_e2e_eval_forward_golden(tag, kernel_variant):
     from idee_amd.models.build import VQ_model
     a, sd, _ = load_golden("e2e_" + tag)
@@ -597,7 +597,7 @@ def test_e2e_eval_forward_golden(tag, kernel_variant):
 
 
 @pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16", "era5_swin_v3_c2_10x12"])
-@variants('default', 'all_split')
+@variants('default', 'all_split', 'fwd22')
 def test_e2e_train_steps_golden(tag, kernel_variant):
     """3 full steps of the train_synthetic.py / train_ERA5_Land.py sequence (fused step objects) vs the reference's
     outputs, losses, all gradients and the parameters after 3 Adam steps."""
