@@ -10,6 +10,13 @@
 // its pixel for the B operand (activations) and one 16-byte load of its output-channel row for the A operand (weights).
 // D^T orientation as everywhere in this library: rows = output channels, columns = pixels, so a lane ends with 4
 // consecutive channels of one pixel = one 8-byte bf16 store.
+//
+// Kernels (launch_conv_bf16 picks by shape; IDEE_CONV_BF16 = direct | lds forces the simpler ones, all covered by -m gpu):
+//   conv_bf16_kernel      direct loads from L1 / L2, any shape — the fallback and the narrow-output data gradients
+//   conv_bf16_lds_kernel  Cin = 16 / 32: activations staged once per frame into an LDS ring, weights from L1
+//   conv_bf16_ws_kernel   32 -> 32: weight-stationary (all weight fragments in registers), LDS frame ring, static tap lists
+//   conv_bf16_cl_kernel   Cin >= 64, zero padding: channel-chunked window by LDS-DMA into a double buffer
+//   wgrad_bf16_kernel     weight gradient: K = pixels, both operands through transposing LDS reads
 #include "common.h"
 #include "conv_common.h"
 #include <type_traits>
@@ -60,8 +67,8 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict
 // forward / data gradient.  Every WAVE owns an output tile of 64 pixels of one row (4 MFMA column blocks) x NT output
 // channel blocks and walks the (T tap, H tap) combinations that exist for its row; inside a combination the k-items
 // (W tap, channel block) are consumed two per MFMA.  Operands come straight from global memory (the activations' 3 x 3 x 3
-// re-use is served by L1 / L2; the bf16 MFMA is so much faster than the f32 one that these kernels are load-issue and
-// address-arithmetic bound, not MFMA bound).  No LDS, no barriers, no atomics:
+// re-use is served by L1 / L2; at config #4's sizes that re-use spills L2 and the kernel becomes fabric-traffic bound — the
+// staged kernels below take those shapes, this one remains for everything they do not cover).  No LDS, no barriers, no atomics:
 //   * replicate padding (FWD_REP) is a clamp of the source coordinates;
 //   * its data gradient (DGRAD_REP) folds the out-of-frame taps back onto the border: in T and H by the (source row, tap)
 //     pair lists of slot_t / slot_h, in W by two extra k-item kinds that exist only in tiles touching a frame edge —
