@@ -678,6 +678,170 @@ __global__ __launch_bounds__(256) void conv_bf16_ws_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cin = 16 FORWARD (the sign-field convs 16 -> 192 of the classifier, the E = 16 models' 3^3 / (2,3,3) convs): the weight-stationary
+// structure of conv_bf16_ws_kernel for one input channel block.  K = 32 of an MFMA = TWO W taps x 16 channels: pair q of a
+// (T tap, H tap) holds the W taps 2q (lanes 0..31) and 2q + 1 (lanes 32..63; absent for q = 1: zero weights), so the two lane
+// halves read their B fragment one pixel apart.  All KT x 3 x 2 x NT weight fragments stay in registers; the padding is applied
+// while staging (clamped / zeroed), so every step runs the static tap list — forward modes have no folds.  conv_bf16_lds_kernel
+// on this shape re-read its weights from L1 for every pair and staged synchronously: 0.61 ms for the 16 -> 192 launch whose
+// 0.54 GB of output take 0.11 ms to write.
+// ---------------------------------------------------------------------------------------------
+template <int MODE /*FWD_REP | FWD_S2*/, int KT, int NT>
+__global__ __launch_bounds__(256) void conv_bf16_ws16_kernel(ConvArgs a) {
+  constexpr int MT = 4, NR = 6, NP = 66, NS = 4;
+  constexpr int PXB = 32, ROWB = NP * PXB, SLOTB = NR * ROWB;
+  constexpr int CHR = NP * 2;                          // 16-byte chunks per staged row
+  constexpr int NCH = (NR * CHR + 255) / 256;          // chunks per thread and frame
+  constexpr int NTAP = KT * 6;                         // (T tap, H tap, W-tap pair) steps
+  __shared__ __attribute__((aligned(16))) unsigned char s_act[NS * SLOTB];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g4 = lane >> 4, hlf = g4 >> 1, ko = 8 * (g4 & 1);
+  const int b = blockIdx.y, ntg = blockIdx.z;
+  const int wset = b % a.wsets;
+  bfp in = reinterpret_cast<bfp>(a.in);
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+
+  u32x4 Aw[KT][3][2][NT];
+  int lq[2];                                           // this lane's B fragment inside a staged row for pair q (its own W tap)
+  {
+    bfp wp = reinterpret_cast<bfp>(a.wp) + (long)wset * (KT * 9) * a.GnTot * 256 + (long)ntg * NT * 256 + j * 16 + ko;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = 2 * q + hlf, ow = min(e, 2);
+      lq[q] = (j + ow) * PXB + 16 * (g4 & 1);
+#pragma unroll
+      for (int tt = 0; tt < KT; ++tt)
+#pragma unroll
+        for (int th = 0; th < 3; ++th)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const u32x4 v = ld16(wp + ((long)((tt * 3 + th) * 3 + ow) * a.GnTot + n) * 256);
+            Aw[tt][th][q][n] = e < 3 ? v : u32x4{0u, 0u, 0u, 0u};
+          }
+    }
+  }
+  f32x4 biasv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+    biasv[n] = a.bias ? ld4(a.bias + (long)wset * a.GnTot * 16 + (ntg * NT + n) * 16 + 4 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  auto readB = [&](u32x4 (&Bq)[MT], const unsigned char* bp) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) Bq[m] = *reinterpret_cast<const u32x4*>(bp + m * 16 * PXB);
+  };
+
+  const long wtiles = (a.Wo + 63) / 64;
+  const long units = (long)((a.Ho + 3) / 4) * wtiles;
+  bfp in_b = in + (long)b * a.i_sB;
+
+  for (long un = blockIdx.x; un < units; un += gridDim.x) {
+    const int wt = (int)(un % wtiles);
+    const int h0 = (int)(un / wtiles) * 4, h = h0 + wave;
+    const int w0 = wt * 64;
+    long coff[NCH];
+    int loff[NCH];
+    bool cz[NCH], cw[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = threadIdx.x + 256 * i;
+      cw[i] = c0 < NR * CHR;
+      const int c = cw[i] ? c0 : threadIdx.x;
+      const int r = c / CHR, cc = c - r * CHR, px = cc >> 1, oc = cc & 1;
+      const int hr = h0 - 1 + r, wq = w0 - 1 + px;
+      cz[i] = MODE != FWD_REP && !((unsigned)hr < (unsigned)a.Hi && (unsigned)wq < (unsigned)a.Wi);
+      coff[i] = (long)min(max(hr, 0), a.Hi - 1) * a.i_sH + (long)min(max(wq, 0), a.Wi - 1) * a.i_sW + 8 * oc;
+      loff[i] = r * ROWB + px * PXB + oc * 16;
+    }
+    // frame pipeline: as conv_bf16_ws_kernel (loaded a step ahead of their commit, committed a step ahead of their use)
+    constexpr int NPRE = (MODE == FWD_S2 && KT == 2) ? 2 : 1;
+    auto new_frame = [&](int s2, int k2, int& src) -> bool {
+      if (MODE == FWD_REP) { src = s2 + 1; return src < a.Ti; }
+      src = KT * s2 + k2;
+      return src < a.Ti;
+    };
+    u32x4 pre[NPRE][NCH];
+    int pre_src[NPRE];
+    auto load_new = [&](int s2) {
+#pragma unroll
+      for (int k2 = 0; k2 < NPRE; ++k2) {
+        int src = 0;
+        const bool nw = s2 < a.To && new_frame(s2, k2, src);
+        pre_src[k2] = nw ? src : -1;
+        bfp src_f = in_b + (long)(nw ? src : 0) * a.i_sT;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) pre[k2][i] = ld16(src_f + coff[i]);
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int k2 = 0; k2 < NPRE; ++k2) {
+        if (pre_src[k2] < 0) continue;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          if (cw[i]) *reinterpret_cast<u32x4*>(s_act + (pre_src[k2] & 3) * SLOTB + loff[i]) = cz[i] ? u32x4{0u, 0u, 0u, 0u} : pre[k2][i];
+      }
+    };
+    __syncthreads();                                // the previous unit's readers are done
+    {
+      u32x4 v0[NCH];
+      if (MODE == FWD_REP) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) v0[i] = ld16(in_b + coff[i]);
+      }
+      load_new(0);
+      if (MODE == FWD_REP) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          if (cw[i]) *reinterpret_cast<u32x4*>(s_act + loff[i]) = v0[i];
+      }
+      commit();
+      load_new(1);
+    }
+    for (int t = 0; t < a.To; ++t) {
+      __syncthreads();                              // the frames of step t are visible; every wave has finished step t - 1
+      commit();
+      load_new(t + 2);
+      if (h >= a.Ho) continue;
+      f32x4 acc[MT][NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto baddr = [&](int k) -> const unsigned char* {
+        const int tt = k / 6, th = (k / 2) % 3, q = k % 2;
+        const int f = MODE == FWD_REP ? min(max(t + tt - 1, 0), a.Ti - 1) : KT * t + tt;
+        return s_act + (f & 3) * SLOTB + (wave + th) * ROWB + lq[q];
+      };
+      u32x4 Bb[3][MT];
+      readB(Bb[0], baddr(0));
+      readB(Bb[1], baddr(1));
+#pragma unroll
+      for (int k = 0; k < NTAP; ++k) {
+        if (k + 2 < NTAP) readB(Bb[(k + 2) % 3], baddr(k + 2));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf(Aw[k / 6][(k / 2) % 3][k % 2][n], Bb[k % 3][m], acc[m][n]);
+      }
+      const long row_o = (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int p = w0 + 16 * m + j;
+        if (p >= a.Wo) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int cg = ntg * NT + n;
+          f32x4 v = acc[m][n] + biasv[n];
+          if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          const long o = row_o + (long)p * a.o_sW + (a.o_gpu >= a.GnTot ? (long)cg * a.o_sG : goff(cg, a.o_gpu, a.o_sU, a.o_sG)) + 4 * g4;
+          stx4<bf16_t>(out + o, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // WIDE inputs (Cin >= 64: the joint head's 192 -> 192 (2,3,3) convs and the 192 -> 16 data gradient of the sign-field convs;
 // zero-padding modes).  conv_bf16_kernel re-requests every (tap, channel block) of its 6 x 66 x 384-byte input window from
 // beyond L2 — 9.7 GB fetched per launch for a 0.27 GB input, 4.9 TB/s of fabric traffic: that, not the MFMA (25 % busy), is
@@ -1136,6 +1300,26 @@ int launch_conv_bf16(ConvArgs& a, hipStream_t stream) {
       if (a.kt == 2) LCCN(2); else LCCN(1);
 #undef LCCN
 #undef LCC
+      return IDEE_OK;
+    }
+  }
+  // one input channel block, forward: weight-stationary (IDEE_CONV_BF16=lds keeps conv_bf16_lds_kernel)
+  if constexpr (MODE == FWD_REP || MODE == FWD_S2) {
+    const int kt = MODE == FWD_REP ? 3 : a.kt;
+    if (a.Gk == 1 && kt * NT <= 9 && !a.relu_ref && !a.addend && !env_is("IDEE_CONV_BF16", "direct") && !env_is("IDEE_CONV_BF16", "lds")) {
+      const long units = (long)((a.Ho + 3) / 4) * ((a.Wo + 63) / 64);
+      long gx = (long)kCUs / ((long)a.B * gz);               // one workgroup per CU
+      if (gx < 1) gx = 1;
+      if (gx > units) gx = units;
+      const dim3 grid((unsigned)gx, a.B, gz);
+#define LW16(KT_, NT_) hipLaunchKernelGGL((conv_bf16_ws16_kernel<MODE, KT_, NT_>), grid, dim3(256), 0, stream, a)
+#define LW16N(KT_) do { if (NT == 6) LW16(KT_, 6); else if (NT == 3) LW16(KT_, 3); else if (NT == 2) LW16(KT_, 2); else LW16(KT_, 1); } while (0)
+      // (kt * NT <= 9: the weight fragments, 24 kt NT registers, fit beside the accumulators)
+      if constexpr (MODE == FWD_REP) { if (NT == 3) LW16(3, 3); else if (NT == 2) LW16(3, 2); else LW16(3, 1); }
+      else if (kt == 2) { if (NT == 3) LW16(2, 3); else if (NT == 2) LW16(2, 2); else LW16(2, 1); }
+      else LW16N(1);
+#undef LW16N
+#undef LW16
       return IDEE_OK;
     }
   }
