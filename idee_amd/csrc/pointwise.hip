@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, 
     gwi[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gwo[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gbi[i] = 0.f;
   }
   // UN tokens per lane and trip: 2 UN sixteen-byte loads in flight before the first dependent instruction
-  constexpr int UN = HASG ? 8 : 16;     // the same number of 16-byte loads in flight per lane either way
+  constexpr int UN = 8;
   const long total = M * QE, stride = (long)gridDim.x * 256;
   for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += UN * stride) {
    long tokq[UN];
