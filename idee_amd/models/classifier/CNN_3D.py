@@ -15,15 +15,16 @@ from ... import ops
 class CNN_3D(_stacked.StackedModule):
     def __init__(self, in_var: int = 6, embed_dim: int = 16, dim: int = 16, n_classes: int = 1, drop_rate: int = 0.2):
         super().__init__()
-        if n_classes != 1:
-            raise NotImplementedError("idee_amd classifier: n_classes != 1 is not built (models/build.py:81-84 uses 1)")
+        if not 1 <= n_classes <= 16:
+            raise NotImplementedError("idee_amd classifier: n_classes must be 1..16 (one output channel block of the joint head's conv3)")
         self.in_var, self.embed_dim, self.dim = in_var, embed_dim * in_var, dim * in_var
         self.n_classes, self.drop_rate = n_classes, drop_rate
         V, E, D, Dj, Ej = in_var, embed_dim, dim, dim * in_var, embed_dim * in_var
         k = (2, 3, 3)
         self.j_w1 = nn.Parameter(torch.empty(Dj, Ej, *k)); self.j_b1 = nn.Parameter(torch.zeros(Dj))
         self.j_w2 = nn.Parameter(torch.empty(Dj, Dj, *k)); self.j_b2 = nn.Parameter(torch.zeros(Dj))
-        self.j_w3 = nn.Parameter(torch.empty(1, Dj, *k)); self.j_b3 = nn.Parameter(torch.zeros(1))
+        # the joint head ends in n_classes logits; the per-variable heads always in one (classifier/CNN_3D.py:85, 90)
+        self.j_w3 = nn.Parameter(torch.empty(n_classes, Dj, *k)); self.j_b3 = nn.Parameter(torch.zeros(n_classes))
         self.h_w1 = nn.Parameter(torch.empty(V, D, E, *k)); self.h_b1 = nn.Parameter(torch.zeros(V, D))
         self.h_w2 = nn.Parameter(torch.empty(V, D, D, *k)); self.h_b2 = nn.Parameter(torch.zeros(V, D))
         self.h_w3 = nn.Parameter(torch.empty(V, 1, D, *k)); self.h_b3 = nn.Parameter(torch.zeros(V, 1))
@@ -71,18 +72,33 @@ class CNN_3D(_stacked.StackedModule):
 
     def forward_tokens(self, zq):
         """zq (N,V,T,H,W,C) channels-last -> (z (N,1,H,W), [y_v (N,1,H,W)] * V)."""
-        z, y = ops.ClassifierHeads.apply(zq, self.j_w1, self.j_b1, self.j_w2, self.j_b2, self.j_w3, self.j_b3, self.h_w1,
+        z, y = ops.ClassifierHeads.apply(zq, self.j_w1, self.j_b1, self.j_w2, self.j_b2, *self._joint_out(), self.h_w1,
                                          self.h_b1, self.h_w2, self.h_b2, self.h_w3, self.h_b3, *self._dropout_args())
-        return z, [y[:, v:v + 1] for v in range(self.in_var)]      # (N,1,H,W) each; (N,1,T/8,H,W) when T > 8, as the reference
+        return self._joint_logits(z), [y[:, v:v + 1] for v in range(self.in_var)]      # (N,1,H,W) each; (N,1,T/8,H,W) when T > 8, as the reference
+
+    def _joint_out(self):
+        """conv3 of the joint head as the kernels take it: one class -> the streaming Cout = 1 kernels; n_classes > 1 -> zero-padded
+        to one block of 16 output channels (differentiable padding: the extra rows receive zero gradient)."""
+        if self.n_classes == 1:
+            return self.j_w3, self.j_b3
+        pad = 16 - self.n_classes
+        return nn.functional.pad(self.j_w3, (0, 0) * 4 + (0, pad)), nn.functional.pad(self.j_b3, (0, pad))
+
+    def _joint_logits(self, z):
+        """(N,T3,H,W,16) padded logits -> (N,n_classes,H,W) (T3 = 1, squeezed as classifier/CNN_3D.py:137) or (N,n_classes,T3,H,W)"""
+        if self.n_classes == 1:
+            return z
+        z = z[..., :self.n_classes].float().permute(0, 4, 1, 2, 3)
+        return z.squeeze(2) if z.shape[2] == 1 else z
 
     def forward_signs(self, signs, project_out, act_dtype=torch.float32):
         """The same outputs as forward_tokens(z_q) for z_q = project_out(signs): LFQ's output has rank
         codebook_dim per variable, so conv1 of every head runs on the (N,T,H,W,16)-channel sign field with
         weights folded through project_out (ops.ClassifierHeadsSigns).  signs (N,V,T,H,W,d)."""
         z, y = ops.ClassifierHeadsSigns.apply(signs, project_out.weight, project_out.bias, self.j_w1, self.j_b1, self.j_w2,
-                                              self.j_b2, self.j_w3, self.j_b3, self.h_w1, self.h_b1, self.h_w2, self.h_b2,
+                                              self.j_b2, *self._joint_out(), self.h_w1, self.h_b1, self.h_w2, self.h_b2,
                                               self.h_w3, self.h_b3, *self._dropout_args(), act_dtype)
-        return z, [y[:, v:v + 1] for v in range(self.in_var)]
+        return self._joint_logits(z), [y[:, v:v + 1] for v in range(self.in_var)]
 
     def forward(self, x):
         """x (N,V,C,T,H,W) as CNN_3D.forward (classifier/CNN_3D.py:112-139)."""

@@ -422,7 +422,9 @@ class ClassifierHeads(torch.autograd.Function):
         j1 = ConvLayer(K, N, 1, T, H, W, V * Cc, Dj, (V * T * H * W * Cc, H * W * Cc, W * Cc, Cc, 16),
                        _cl_strides(T1, H, W, Dj), True, x_units=(Cc // 16, T * H * W * Cc), act=act)
         j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True, act=act)
-        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False, act=act)
+        J3 = jw3.shape[0]            # 1, or 16: n_classes > 1 padded to one output channel block by the module (z is then (N,T3,H,W,16))
+        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, J3, _cl_strides(T2, H, W, Dj),
+                       (T3 * H * W, H * W, W, 1, 1) if J3 == 1 else _cl_strides(T3, H, W, J3), False, act=act)
         h1 = ConvLayer(K, N * V, V, T, H, W, Cc, dim, _cl_strides(T, H, W, Cc), _cl_strides(T1, H, W, dim), True, act=act)
         h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True, act=act)
         h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (T3 * H * W, H * W, W, 1, 1), False, act=act)
@@ -431,7 +433,8 @@ class ClassifierHeads(torch.autograd.Function):
         packs = [c.pack(w) for c, w in zip(convs, weights)]
         ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=act)
         ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=act)
-        z = torch.empty((N, 1, H, W) if T3 == 1 else (N, 1, T3, H, W), device=dev, dtype=torch.float32)
+        z = (torch.empty((N, 1, H, W) if T3 == 1 else (N, 1, T3, H, W), device=dev, dtype=torch.float32) if J3 == 1 else
+             torch.empty((N, T3, H, W, J3), device=dev, dtype=act))
         ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=act)
         ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=act)
         y = torch.empty((N, V, H, W) if T3 == 1 else (N, V, T3, H, W), device=dev, dtype=torch.float32)
@@ -456,7 +459,7 @@ class ClassifierHeads(torch.autograd.Function):
         jw1, jw2, jw3, hw1, hw2, hw3 = saved[5:11]
         pd = saved[11:17]
         j1, j2, j3, h1, h2, h3 = ctx.convs
-        dz, dy = _f32c(dz), _f32c(dy)
+        dz, dy = (_f32c(dz) if jw3.shape[0] == 1 else dz.to(ja2.dtype).contiguous()), _f32c(dy)
         # joint head
         djw3, djb3 = j3.wgrad(ja2, dz, jw3)
         dja2 = torch.empty_like(ja2)
@@ -529,7 +532,9 @@ class ClassifierHeadsSigns(torch.autograd.Function):
         h1 = ConvLayer(KP, N, 1, T1, H, W, CS, V * dim, sxs, (V * T1 * H * W * dim, H * W * dim, W * dim, dim, 16), True,
                        y_units=(dim // 16, T1 * H * W * dim), act=act)
         j2 = ConvLayer(K, N, 1, T1, H, W, Dj, Dj, _cl_strides(T1, H, W, Dj), _cl_strides(T2, H, W, Dj), True, act=act)
-        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, 1, _cl_strides(T2, H, W, Dj), (T3 * H * W, H * W, W, 1, 1), False, act=act)
+        J3 = jw3.shape[0]            # 1, or 16 (n_classes > 1 padded by the module: see ClassifierHeads)
+        j3 = ConvLayer(K, N, 1, T2, H, W, Dj, J3, _cl_strides(T2, H, W, Dj),
+                       (T3 * H * W, H * W, W, 1, 1) if J3 == 1 else _cl_strides(T3, H, W, J3), False, act=act)
         h2 = ConvLayer(K, N * V, V, T1, H, W, dim, dim, _cl_strides(T1, H, W, dim), _cl_strides(T2, H, W, dim), True, act=act)
         h3 = ConvLayer(K, N * V, V, T2, H, W, dim, 1, _cl_strides(T2, H, W, dim), (T3 * H * W, H * W, W, 1, 1), False, act=act)
         convs = (j1, j2, j3, h1, h2, h3)
@@ -538,7 +543,8 @@ class ClassifierHeadsSigns(torch.autograd.Function):
         packs = [c.pack(w, want_dgrad=(need_dx or i not in (0, 3))) for i, (c, w) in enumerate(zip(convs, weights))]
         ja1 = torch.empty((N, T1, H, W, Dj), device=dev, dtype=act)
         ja2 = torch.empty((N, T2, H, W, Dj), device=dev, dtype=act)
-        z = torch.empty((N, 1, H, W) if T3 == 1 else (N, 1, T3, H, W), device=dev, dtype=torch.float32)
+        z = (torch.empty((N, 1, H, W) if T3 == 1 else (N, 1, T3, H, W), device=dev, dtype=torch.float32) if J3 == 1 else
+             torch.empty((N, T3, H, W, J3), device=dev, dtype=act))
         ha1 = torch.empty((N, V, T1, H, W, dim), device=dev, dtype=act)
         ha2 = torch.empty((N, V, T2, H, W, dim), device=dev, dtype=act)
         y = torch.empty((N, V, H, W) if T3 == 1 else (N, V, T3, H, W), device=dev, dtype=torch.float32)
@@ -566,7 +572,7 @@ class ClassifierHeadsSigns(torch.autograd.Function):
         pd = saved[15:21]
         j1, j2, j3, h1, h2, h3 = ctx.convs
         N, V, T, H, W, D, CS, Cc, dim, Dj = ctx.geom
-        dz, dy = _f32c(dz), _f32c(dy)
+        dz, dy = (_f32c(dz) if jw3.shape[0] == 1 else dz.to(ja2.dtype).contiguous()), _f32c(dy)
         st = L.stream()
         dev = sx.device
         djw3, djb3 = j3.wgrad(ja2, dz, jw3)

@@ -255,8 +255,8 @@ def fx_lfq(tag, K, training, seed):
     save("lfq_" + tag, **out)
 
 
-def fx_classifier(seed, V=2):
-    c = RefCls(in_var=V, embed_dim=16, dim=16, drop_rate=0.0)
+def fx_classifier(seed, V=2, n_classes=1):
+    c = RefCls(in_var=V, embed_dim=16, dim=16, n_classes=n_classes, drop_rate=0.0)
     rerandomise(c, seed)
     x = rand((2, V, 16, 8, 6, 10), seed + 1).requires_grad_()
     z, y = c(x)
@@ -266,7 +266,11 @@ def fx_classifier(seed, V=2):
     out = dict(x=x.detach(), z=z.detach(), y=torch.stack([t.detach() for t in y]), rz=rz, ry=ry, dx=x.grad)
     out.update(sd_arrays(c))
     out.update({"grad/" + k: p.grad for k, p in c.named_parameters()})
-    save("classifier_v%d" % V, **out)
+    save("classifier_v%d" % V + ("" if n_classes == 1 else "_k%d" % n_classes), **out)
+
+
+if __name__ == "__main__" and "--clsk-only" in sys.argv:
+    fx_classifier(1700, V=2, n_classes=3)
 
 
 def fx_losses(seed):
@@ -750,8 +754,9 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
                                                                 "--era5-only", "--hier-only", "--vqema-only", "--misc-only", "--era5items-only",
-                                                                "--cnnhier-only", "--patch-only")):
+                                                                "--cnnhier-only", "--patch-only", "--clsk-only")):
     main()
+    fx_classifier(1700, V=2, n_classes=3)
     fx_swin_hier("16_32", (16, 32), 1200)
     fx_swin_hier("32_16", (32, 16), 1210)
     fx_cnn_hier("16_32", (16, 32), 1500)

@@ -295,14 +295,15 @@ def test_lfq_golden(tag):
 
 def _classifier(sd, V):
     from idee_amd.models.classifier.CNN_3D import CNN_3D
-    c = CNN_3D(in_var=V, embed_dim=16, dim=16, drop_rate=0.0)
+    c = CNN_3D(in_var=V, embed_dim=16, dim=16, n_classes=sd["conv3.weight"].shape[0], drop_rate=0.0)
     c.load_state_dict(sd, strict=True)
     return c.to(DEV)
 
 
+@pytest.mark.parametrize("tag", ["classifier_v2", "classifier_v2_k3"])       # _k3: n_classes = 3 (joint head only, as the reference)
 @variants('default', 'conv_split')
-def test_classifier_golden(kernel_variant):
-    a, sd, grads = load_golden("classifier_v2")
+def test_classifier_golden(tag, kernel_variant):
+    a, sd, grads = load_golden(tag)
     c = _classifier(sd, 2)
     x = dev(a["x"]).requires_grad_()
     z, y = c(x)
@@ -372,6 +373,17 @@ def test_classifier_vs_oracle(V, H, W, E, monkeypatch, kernel_variant):
 def test_classifier_sign_field_vs_oracle(V, D, H, W, monkeypatch, kernel_variant):
     """The rank-d input path (ops.ClassifierHeadsSigns: convs on the sign field with folded weights) against
     the oracle's classifier applied to z_q = project_out(signs): outputs and every gradient (strict, tie-free case)."""
+    _sign_field_case(V, D, H, W, monkeypatch, 1)
+
+
+@pytest.mark.parametrize("V,D,H,W,ncls", [(2, 1, 5, 24, 3), (3, 2, 4, 20, 16)])
+def test_classifier_sign_field_n_classes(V, D, H, W, ncls, monkeypatch):
+    """n_classes > 1 (the joint head's conv3 has n_classes outputs, classifier/CNN_3D.py:85; the per-variable heads keep one):
+    the sign-field path against the oracle, as above."""
+    _sign_field_case(V, D, H, W, monkeypatch, ncls)
+
+
+def _sign_field_case(V, D, H, W, monkeypatch, ncls):
     from oracle import idee_oracle as O
     from idee_amd.models.classifier.CNN_3D import CNN_3D
     N, T, E = (1 if W == 200 else 2), 8, 16
@@ -379,13 +391,13 @@ def test_classifier_sign_field_vs_oracle(V, D, H, W, monkeypatch, kernel_variant
         monkeypatch.setenv("IDEE_CONV_HRUN", "8")
 
     torch.manual_seed(V * 100 + W)
-    c = CNN_3D(in_var=V, embed_dim=E, dim=16, drop_rate=0.0)
+    c = CNN_3D(in_var=V, embed_dim=E, dim=16, n_classes=ncls, drop_rate=0.0)
     po = torch.nn.Linear(D, E)
     with torch.no_grad():
         po.bias.normal_(0, 0.3)
     sd = {k: v.clone() for k, v in c.state_dict().items()}
     signs = (torch.randint(0, 2, (N, V, T, H, W, D)).float() * 2 - 1)
-    rz, ry = torch.randn(N, 1, H, W), torch.randn(V, N, 1, H, W)
+    rz, ry = torch.randn(N, ncls, H, W), torch.randn(V, N, 1, H, W)
     runs = []
     for mode in (0, 1, 2):                   # 2: float64, plain ReLU (this case only: its head 5 has thousands of near-tie units)
         if mode == 2 and H != 19:

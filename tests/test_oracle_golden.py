@@ -109,8 +109,9 @@ def test_lfq(tag):
         check_grads(sd, grads)
 
 
-def test_classifier():
-    a, sd, grads = load_golden("classifier_v2")
+@pytest.mark.parametrize("tag", ["classifier_v2", "classifier_v2_k3"])       # _k3: n_classes = 3
+def test_classifier(tag):
+    a, sd, grads = load_golden(tag)
     sd = leaf(sd)
     x = a["x"].clone().requires_grad_()
     z, y = O.classifier(x, sd, pre="")
