@@ -2145,19 +2145,23 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
   const int QC = a.C / 4, Gi = a.C / 16;
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, GPB = 256 / LPP;
   const int WG = (a.W + PXT - 1) / PXT;
-  const long ngrp = (long)a.B * a.To * a.H * WG;       // (item, output frame) pairs walk like a batch of a.B * a.To items
+  // 32-bit pixel-group arithmetic (launch_c1_t checks the count): the 64-bit divisions by run-time values this loop used to do
+  // per lane and trip are ~150-instruction routines each — more vector work than the dot products themselves
+  const unsigned ngrp = (unsigned)a.B * a.To * a.H * WG;       // (item, output frame) pairs walk like a batch of a.B * a.To items
   // this lane's 4 channels of all 18 taps stay in registers (re-read when the weight set changes: per-variable heads)
   f32x4 wr[18];
   int wcur = -1;
-  for (long g0 = (long)blockIdx.x * GPB; g0 < ngrp; g0 += (long)gridDim.x * GPB) {
-    const long g = g0 + pl;
+  for (unsigned g0 = blockIdx.x * GPB; g0 < ngrp; g0 += gridDim.x * GPB) {
+    const unsigned g = g0 + pl;
     f32x4 accv[PXT];
 #pragma unroll
     for (int o = 0; o < PXT; ++o) accv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
     int b = 0, h = 0, w0 = 0;
     if (g < ngrp && q < QC) {
-      w0 = (int)(g % WG) * PXT; h = (int)((g / WG) % a.H);
-      b = (int)(g / ((long)WG * a.H));           // (item, frame) pair index; item = b / To
+      const unsigned gr = g / (unsigned)WG;
+      w0 = (int)(g - gr * WG) * PXT;
+      b = (int)(gr / (unsigned)a.H);             // (item, frame) pair index; item = b / To
+      h = (int)(gr - (unsigned)b * a.H);
       const int wset = (b / a.To) % a.wsets;
       if (wset != wcur) {
         wcur = wset;
@@ -2215,15 +2219,17 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
       for (int u = 0; u < 4; ++u) wr[tap][u] = c1_w_dgrad(wp, Gi, tap, 4 * q + u);
   }
   const int nb = a.B / a.wsets;
-  const long npw = (long)nb * a.To * 2 * a.H * a.W;
+  const unsigned npw = (unsigned)nb * a.To * 2 * a.H * a.W;       // (32-bit index arithmetic: see c1_fwd_kernel)
   (void)npix;
-  for (long p0 = (long)blockIdx.x * PPB; p0 < npw; p0 += (long)gridDim.x * PPB) {
-    const long p = p0 + pl;
+  for (unsigned p0 = blockIdx.x * PPB; p0 < npw; p0 += gridDim.x * PPB) {
+    const unsigned p = p0 + pl;
     if (p >= npw || q >= QC) continue;
-    const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H), kt = (int)((p / ((long)a.W * a.H)) % 2);
-    const long bt = p / ((long)a.W * a.H * 2);                           // (item of this weight set, output frame)
-    const int to = (int)(bt % a.To);
-    const int b = (int)(bt / a.To) * a.wsets + wset;
+    const unsigned pr = p / (unsigned)a.W, ph = pr / (unsigned)a.H;
+    const int w = (int)(p - pr * a.W), h = (int)(pr - ph * a.H), kt = (int)(ph & 1u);
+    const unsigned bt = ph >> 1;                                         // (item of this weight set, output frame)
+    const unsigned bi = bt / (unsigned)a.To;
+    const int to = (int)(bt - bi * a.To);
+    const int b = (int)bi * a.wsets + wset;
     const float* dyb = a.dy + ((long)b * a.To + to) * a.H * a.W;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2256,7 +2262,7 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
   const int wset = blockIdx.y;
   const int nb = a.B / a.wsets;
-  const long npix = (long)nb * a.To * a.H * a.W;     // source pixels per kt for this weight set
+  const unsigned npix = (unsigned)nb * a.To * a.H * a.W;     // source pixels per kt for this weight set (32-bit: see c1_fwd_kernel)
   f32x4 acc[2][9];
   float bsum = 0.f;
 #pragma unroll
@@ -2265,20 +2271,21 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
     for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] = f32x4{0.f, 0.f, 0.f, 0.f};
   // four source pixels per lane and trip: their x and dy loads are all in flight before the first fma
   constexpr int UN = 4;
-  const long pstride = (long)gridDim.x * PPB;
-  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += UN * pstride) {
+  const unsigned pstride = gridDim.x * PPB;
+  for (unsigned p0 = blockIdx.x * PPB; p0 < npix; p0 += UN * pstride) {
     f32x4 xq[UN][2];
     float gq[UN][9];
     bool on[UN];
 #pragma unroll
     for (int r = 0; r < UN; ++r) {
-      const long p = p0 + r * pstride + pl;
+      const unsigned p = p0 + r * pstride + pl;
       on[r] = p < npix && q < QC;
-      const long pc = on[r] ? p : 0;
-      const int ws = (int)(pc % a.W), hs = (int)((pc / a.W) % a.H);
-      const long bt = pc / ((long)a.W * a.H);
-      const int to = (int)(bt % a.To);
-      const int b = (int)(bt / a.To) * a.wsets + wset;
+      const unsigned pc = on[r] ? p : 0u;
+      const unsigned pr = pc / (unsigned)a.W, bt = pr / (unsigned)a.H;
+      const int ws = (int)(pc - pr * a.W), hs = (int)(pr - bt * a.H);
+      const unsigned bi = bt / (unsigned)a.To;
+      const int to = (int)(bt - bi * a.To);
+      const int b = (int)bi * a.wsets + wset;
       const float* dyb = a.dy + ((long)b * a.To + to) * a.H * a.W;
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh)
@@ -2341,6 +2348,8 @@ int launch_c1_t(int which, C1Args& a, hipStream_t st) {
   const int PPB = 256 / LPP;
   const long nbw = a.B / a.wsets;
   const long npix = (which == 1 ? nbw * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * ((a.W + 3) / 4) : nbw * a.H * a.W)) * a.To;
+  if ((long)a.B * a.To * 2 * a.H * a.W + 4L * 256 * kCUs * 8 >= (1L << 31))      // the kernels index pixels (and their grid strides) in 32 bits
+    return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): more than 2^31 pixels per launch");
   const int per = which == 0 ? 1 : a.wsets;                       // dgrad / wgrad: one weight set per grid column
   const int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : 8), per));
   const dim3 grid(gx < 1 ? 1 : gx, per);
