@@ -830,11 +830,13 @@ __global__ __launch_bounds__(256) void anomaly_signs_fwd_kernel(const float* __r
   for (int i = threadIdx.x; i < E; i += 256) { s_b[i] = b_out[i]; s_c[i] = vq0[i]; }
   __syncthreads();
   float acc[2] = {0.f, 0.f};
-  const long M = (long)N * V * T * HW;
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
-    const long hw = tok % HW; long r = tok / HW;
-    const int t = (int)(r % T); r /= T;
-    const int n = (int)(r / V);
+  // 32-bit token arithmetic (the entry point checks the count): three 64-bit divisions by run-time values per token are ~450
+  // instructions, more than the rest of the token's work
+  const unsigned M = (unsigned)N * V * T * (unsigned)HW, HWu = (unsigned)HW;
+  for (unsigned tok = blockIdx.x * 256 + threadIdx.x; tok < M; tok += gridDim.x * 256) {
+    const unsigned r0 = tok / HWu, hw = tok - r0 * HWu, r1 = r0 / (unsigned)T;
+    const int t = (int)(r0 - r1 * T);
+    const int n = (int)(r1 / (unsigned)V);
     float m = mask[(long)n * HW + hw];
     if (mvalid) m = fminf(m + mvalid[((long)n * T + t) * HW + hw], 1.f);
     const float wgt = 1.f - m;
@@ -842,7 +844,7 @@ __global__ __launch_bounds__(256) void anomaly_signs_fwd_kernel(const float* __r
     if (m == 1.f) continue;   // target := prediction there (losses.py:162): exactly zero contribution
     float q[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) q[i] = signs[tok * D + i];
+    for (int i = 0; i < D; ++i) q[i] = signs[(long)tok * D + i];
     float l1 = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -873,17 +875,19 @@ __global__ __launch_bounds__(256) void anomaly_signs_bwd_kernel(const float* __r
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
   const float sc = gout[0] / denom[0];
-  const long M = (long)N * V * T * HW;
-  for (long tok = (long)blockIdx.x * 256 + threadIdx.x; tok < M; tok += (long)gridDim.x * 256) {
-    const long hw = tok % HW; long r = tok / HW;
-    const int t = (int)(r % T); r /= T;
-    const int n = (int)(r / V);
+  // 32-bit token arithmetic (the entry point checks the count): three 64-bit divisions by run-time values per token are ~450
+  // instructions, more than the rest of the token's work
+  const unsigned M = (unsigned)N * V * T * (unsigned)HW, HWu = (unsigned)HW;
+  for (unsigned tok = blockIdx.x * 256 + threadIdx.x; tok < M; tok += gridDim.x * 256) {
+    const unsigned r0 = tok / HWu, hw = tok - r0 * HWu, r1 = r0 / (unsigned)T;
+    const int t = (int)(r0 - r1 * T);
+    const int n = (int)(r1 / (unsigned)V);
     float m = mask[(long)n * HW + hw];
     if (mvalid) m = fminf(m + mvalid[((long)n * T + t) * HW + hw], 1.f);
     const float k = sc * (1.f - m);
     float q[D], dq[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { q[i] = signs[tok * D + i]; dq[i] = 0.f; }
+    for (int i = 0; i < D; ++i) { q[i] = signs[(long)tok * D + i]; dq[i] = 0.f; }
     if (m != 1.f) {
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(256) void anomaly_signs_bwd_kernel(const float* __r
       }
     }
 #pragma unroll
-    for (int i = 0; i < D; ++i) dsigns[tok * D + i] = dq[i];
+    for (int i = 0; i < D; ++i) dsigns[(long)tok * D + i] = dq[i];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1798,6 +1802,7 @@ extern "C" int idee_anomaly_l1_signs_fwd(const float* signs, const float* mask_e
   const int D = log2i(codebook_size);
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "anomaly_l1_signs: codebook size %d is not a power of two", codebook_size);
   const long M = (long)N * V * T * HW;
+  IDEE_CHECK_ARG(M + 256L * 4096 < (1L << 31), "anomaly_l1_signs_fwd: more than 2^31 tokens");      // 32-bit token index in the kernel
   const int nb = anomaly_signs_blocks(M);
   hipStream_t st = (hipStream_t)stream;
 #define CALL(E_, D_)                                                                                            \
@@ -1820,6 +1825,7 @@ extern "C" int idee_anomaly_l1_signs_bwd(const float* signs, const float* mask_e
   const int D = log2i(codebook_size);
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "anomaly_l1_signs: codebook size %d is not a power of two", codebook_size);
   const long M = (long)N * V * T * HW;
+  IDEE_CHECK_ARG(M + 256L * 4096 < (1L << 31), "anomaly_l1_signs_bwd: more than 2^31 tokens");      // 32-bit token index in the kernel
   const int nb = anomaly_signs_blocks(M);
   hipStream_t st = (hipStream_t)stream;
 #define CALL(E_, D_)                                                                                            \
