@@ -1319,11 +1319,11 @@ template <typename AT>
 __global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __restrict__ qs, AT* __restrict__ sp, int N, int V,
                                                              int T, long HW, int D, int CP) {
   const int T1 = T / 2, R = V * D + 1, Q = CP / 4;
-  const long npix = (long)N * T1 * HW;
-  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < npix * Q; u += (long)gridDim.x * 256) {
-    const long pix = u / Q; const int q = (int)(u % Q);
-    const long p = pix % HW; long r = pix / HW;
-    const int t1 = (int)(r % T1); const long n = r / T1;
+  const unsigned npix = (unsigned)N * T1 * (unsigned)HW, HWu = (unsigned)HW;      // (32-bit index arithmetic; the entry point checks the count)
+  for (unsigned u = blockIdx.x * 256 + threadIdx.x; u < npix * Q; u += gridDim.x * 256) {
+    const unsigned pix = u / (unsigned)Q; const int q = (int)(u - pix * Q);
+    const unsigned r = pix / HWu, p = pix - r * HWu;
+    const long n = r / (unsigned)T1; const int t1 = (int)(r - (unsigned)n * T1);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256) void sign_field_fwd_kernel(const float* __rest
       if (kt < 2) val = ch < V * D ? qs[(((n * V + ch / D) * T + 2 * t1 + kt) * HW + p) * D + ch % D] : 1.f;
       o[k] = val;
     }
-    stx4<AT>(sp + pix * CP + 4 * q, o);
+    stx4<AT>(sp + (long)pix * CP + 4 * q, o);
   }
 }
 // One thread per (pixel of the paired field, frame of the pair): its R - 1 = V D gradient channels are read as consecutive words
@@ -2014,6 +2014,7 @@ extern "C" int idee_anomaly_vote_finalize(const float* acc, const float* cnt, fl
 
 extern "C" int idee_lfq_sign_field_fwd(const float* signs, void* sp, int N, int V, int T, long HW, int D, int CP, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(signs && sp && N > 0 && V > 0 && T >= 2 && HW > 0 && D > 0 && CP % 16 == 0 && 2 * (V * D + 1) <= CP, "lfq_sign_field_fwd: bad argument");
+  IDEE_CHECK_ARG((long)N * (T / 2) * HW * (CP / 4) + 256L * 65536 < (1L << 32), "lfq_sign_field_fwd: more than 2^32 output quads");   // 32-bit index in the kernel
   const dim3 grid(stream_grid((long)N * (T / 2) * HW * (CP / 4)));
   if (act_dtype == IDEE_DTYPE_BF16) hipLaunchKernelGGL(sign_field_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, signs, (bf16_t*)sp, N, V, T, HW, D, CP);
   else hipLaunchKernelGGL(sign_field_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, signs, (float*)sp, N, V, T, HW, D, CP);
