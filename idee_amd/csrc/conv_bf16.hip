@@ -894,16 +894,18 @@ __global__ __launch_bounds__(256) void conv_bf16_cl_kernel(ConvArgs a) {
 
   // stage s of this workgroup = (unit, chunk); its window: frames, rows h0 - 1 .., pixels w0 - 1 ..
   struct Stage { int t, h0, w0, ck; };
-  const long nstage = (units > blockIdx.x ? (units - blockIdx.x + gridDim.x - 1) / gridDim.x : 0) * nck;
-  auto stage_of = [&](long sidx) {
+  // (32-bit stage arithmetic: two decodes per stage with 64-bit divisions by run-time values cost ~1,500 vector instructions,
+  //  a sixth of a stage's MFMA time; the host checks units * chunks < 2^31)
+  const int nstage = (int)((units > blockIdx.x ? (units - blockIdx.x + gridDim.x - 1) / gridDim.x : 0) * nck);
+  auto stage_of = [&](int sidx) {
     Stage st;
-    const long ul = sidx / nck;
-    const long un = blockIdx.x + ul * gridDim.x;
-    st.ck = (int)(sidx - ul * nck);
-    const int wt = (int)(un % wtiles);
-    const long r = un / wtiles;
-    st.h0 = (int)(r % hgroups) * 4 * RW;
-    st.t = (int)(r / hgroups);
+    const unsigned ul = (unsigned)sidx / (unsigned)nck;
+    const unsigned un = blockIdx.x + ul * gridDim.x;
+    st.ck = (int)((unsigned)sidx - ul * nck);
+    const unsigned r = un / (unsigned)wtiles;
+    const int wt = (int)(un - r * wtiles);
+    st.t = (int)(r / (unsigned)hgroups);
+    st.h0 = (int)(r - (unsigned)st.t * hgroups) * 4 * RW;
     st.w0 = wt * TW;
     return st;
   };
@@ -948,9 +950,9 @@ __global__ __launch_bounds__(256) void conv_bf16_cl_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < ND; ++i) dma_one(i, cb0, 0);
   }
-  for (long sidx = 0; sidx < nstage; ++sidx) {
+  for (int sidx = 0; sidx < nstage; ++sidx) {
     const Stage st = stage_of(sidx);
-    const int buf = (int)(sidx & 1);
+    const int buf = sidx & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the chunk has landed
     __syncthreads();                                   // the chunk is complete; the other buffer's readers are done
     // the next stage's window: its DMA instructions are issued between the taps below (one per tap, in the MFMAs' shadow)
@@ -1287,7 +1289,8 @@ int launch_conv_bf16(ConvArgs& a, hipStream_t stream) {
   // wide inputs in the zero-padding modes: channel-chunked LDS staging (IDEE_CONV_BF16=direct keeps conv_bf16_kernel)
   if constexpr (MODE == FWD_S2 || MODE == DGRAD_S2) {
     const bool chunk_ok = a.i_gpu >= a.Gk || a.i_gpu % 2 == 0;              // the two 16-channel blocks of a chunk lie i_sG apart
-    const bool off_ok = (long)a.Ti * a.i_sT < (1L << 31);                     // 32-bit window offsets
+    const bool off_ok = (long)a.Ti * a.i_sT < (1L << 31) &&                   // 32-bit window offsets and stage indices
+                        (long)a.To * ((a.Ho + 7) / 8) * ((a.Wo + 47) / 48) * (a.Gk / 2) < (1L << 31);
     if (a.Gk >= 4 && a.Gk % 2 == 0 && (a.kt == 1 || a.kt == 2) && chunk_ok && off_ok && !env_is("IDEE_CONV_BF16", "direct")) {
       const long units = (long)a.To * ((a.Ho + 7) / 8) * ((a.Wo + 47) / 48);
       const int wg_per_cu = (MODE == FWD_S2 && a.kt == 2) ? 1 : (NT >= 6 ? 1 : 2);      // LDS: 128 KB with two staged frames, else 64 KB
