@@ -1343,10 +1343,11 @@ template <typename AT>
 __global__ __launch_bounds__(256) void sign_field_bwd_kernel(const AT* __restrict__ dsp, float* __restrict__ dqs, int N, int V,
                                                              int T, long HW, int D, int CP) {
   const int T1 = T / 2, R = V * D + 1;
-  const long total = (long)N * T * HW;               // (n, t, pixel)
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long p = e % HW; long r = e / HW;
-    const int t = (int)(r % T); const long n = r / T;
+  const unsigned total = (unsigned)N * T * (unsigned)HW, HWu = (unsigned)HW;               // (n, t, pixel); 32-bit (the entry point checks the count)
+  for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const unsigned r = e / HWu;
+    const long p = e - r * HWu;
+    const long n = r / (unsigned)T; const int t = (int)(r - (unsigned)n * T);
     const AT* src = dsp + ((n * T1 + t / 2) * HW + p) * CP + (t & 1) * R;
     for (int v = 0; v < V; ++v)
       for (int i = 0; i < D; ++i)
@@ -2023,6 +2024,7 @@ extern "C" int idee_lfq_sign_field_fwd(const float* signs, void* sp, int N, int 
 }
 extern "C" int idee_lfq_sign_field_bwd(const void* dsp, float* dsigns, int N, int V, int T, long HW, int D, int CP, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(dsp && dsigns && N > 0 && V > 0 && T >= 2 && HW > 0 && D > 0 && CP % 16 == 0 && 2 * (V * D + 1) <= CP, "lfq_sign_field_bwd: bad argument");
+  IDEE_CHECK_ARG((long)N * T * HW + 256L * 4096 < (1L << 32), "lfq_sign_field_bwd: more than 2^32 pixels");   // 32-bit index in the kernel
   const dim3 grid(stream_grid((long)N * T * HW));
   if (act_dtype == IDEE_DTYPE_BF16) hipLaunchKernelGGL(sign_field_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dsp, dsigns, N, V, T, HW, D, CP);
   else hipLaunchKernelGGL(sign_field_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dsp, dsigns, N, V, T, HW, D, CP);
