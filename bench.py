@@ -56,11 +56,13 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
     ap.add_argument("--hw", type=int, default=None, help="override grid height = width")
     ap.add_argument("--encoder", default=None, help="override the config's encoder")
-    ap.add_argument("--math", default="f32", choices=["f32", "split", "fwd22"],
+    ap.add_argument("--math", default="f32", choices=["f32", "split", "fwd22", "f22"],
                     help="f32 (default): every GEMM-shaped kernel on the exact-f32 MFMA (the reference's arithmetic).  split: the "
                          "opt-in two-piece split-precision kernels, convolutions (IDEE_CONV_MATH=split) AND Swin linear layers "
                          "(IDEE_SWIN_MATH=split) — a separately labelled line, never the headline.  fwd22: only the FORWARD passes on the "
-                         "split kernels (f16 pieces: operand rounding 2^-22), every backward pass exact f32 — also a separate line")
+                         "split kernels (f16 pieces: operand rounding 2^-22), every backward pass exact f32 — also a separate line.  f22: the Swin block's "
+                         "forward AND backward on f16 pieces with power-of-two prescaled weights and a per-work-item gradient scale "
+                         "(IDEE_SWIN_MATH=f22; operand rounding 2^-22 in every GEMM), convolutions as in fwd22 — a separate line")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="activation storage between the fused units.  f32 (default): the reference's arithmetic.  bf16: BASELINE "
                          "config #4's precision — bf16 tokens, bf16 MFMA GEMMs / convolutions with f32 accumulate, f32 LFQ, losses, "
@@ -236,13 +238,18 @@ def math_label(math, cfg, dtype="f32"):
         if swin:
             d["swin_gemm"] = "exact f32 MFMA (v_mfma_f32_16x16x4_f32) for every linear layer, the attention scores and P.V, at every width"
         return d
-    if math == "fwd22":
+    if math in ("fwd22", "f22"):
         d = dict(conv="FORWARD of the 16->16 and 96-wide convs: two f16 pieces per operand, 3 piece products (operand rounding 2^-22, "
                       "weights pre-scaled by a power of two); every data and weight gradient exact f32 MFMA",
                  everything_else="f32")
         if swin:
             d["swin_gemm"] = ("forward: two f16 pieces per operand, all 4 piece products, f32 accumulate (operand rounding 2^-22), attention "
                               "scores on the f32 MFMA; backward: exact f32 MFMA")
+            if math == "f22":
+                d["swin_gemm"] = ("forward and backward: two f16 pieces per operand, all 4 piece products, f32 accumulate; weight tensors "
+                                  "prescaled by a power of two per tensor (largest |w| in [2^6, 2^7)), the incoming gradient scaled by a "
+                                  "power of two per 32-token work item (largest |dy| in [2^1, 2^8)): operand rounding max(2^-22 |x|, "
+                                  "2^-26 of the tile's / tensor's largest element); attention scores on the f32 MFMA")
         return d
     d = dict(conv="16->16 convs (all three passes) and the forward / data gradient of the 96-wide convs: two 16-bit pieces per operand, "
                   "3 piece products (f16 fwd: 2^-22 operand rounding, bf16 bwd: 2^-18); every other conv kernel exact f32 MFMA",
@@ -336,8 +343,8 @@ def main():
     a = parse()
     # the library reads these at every launch; child ranks inherit them.  The headline (--math f32) pins BOTH to the exact-f32
     # kernels whatever the caller's environment holds, so the printed `dtype` / `math` always describe what ran.
-    os.environ["IDEE_CONV_MATH"] = a.math if a.math in ("split", "fwd22") else "f32"
-    os.environ["IDEE_SWIN_MATH"] = a.math if a.math in ("split", "fwd22") else "f32"
+    os.environ["IDEE_CONV_MATH"] = {"split": "split", "fwd22": "fwd22", "f22": "fwd22"}.get(a.math, "f32")
+    os.environ["IDEE_SWIN_MATH"] = a.math if a.math in ("split", "fwd22", "f22") else "f32"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
     import torch
@@ -475,6 +482,9 @@ def main():
                dtype=("bf16" if a.dtype == "bf16" else "f32" if a.math == "f32" else
                       "f32 storage/accumulate; forward convolutions and Swin linear layers on two-piece f16 split MFMAs (operand rounding "
                       "2^-22), every backward pass exact f32" if a.math == "fwd22" else
+                      "f32 storage/accumulate; Swin linear layers forward and backward and the forward convolutions on two-piece f16 split "
+                      "MFMAs (operand rounding 2^-22; prescaled weights, per-tile gradient scale), convolution gradients exact f32"
+                      if a.math == "f22" else
                       "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs"),
                math=math_label(a.math, cfg, a.dtype),
                codebook=a.codebook,

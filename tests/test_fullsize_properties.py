@@ -103,7 +103,7 @@ def test_fullsize_forward_matches_oracle_on_crop(encoder, crop, kernel_variant):
     torch.testing.assert_close(R(torch.stack(y))[yk], torch.stack(yo)[..., rs, cs][yk], atol=5e-5, rtol=5e-4)
 
 
-@variants('default', 'swin_split')
+@variants('default', 'swin_split', 'swin_f22')
 def test_fullsize_width_swin_block_gradients_vs_oracle(kernel_variant):
     """Shifted (2,4,4) Swin block and the (8,1,1) temporal block at the frame width W = 200 (H = 8): outputs and every
     gradient against the oracle (no ReLU in the block: strict tolerance as is)."""

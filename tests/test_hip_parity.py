@@ -97,7 +97,7 @@ def test_patch_merging_golden(tag):
 
 @pytest.mark.parametrize("tag", ["w244_noshift", "w244_shift", "w244_shift_pad", "w244_noshift_pad", "w811",
                                  "w811_T16_shift", "w244_c32"])
-@variants('default', 'swin_split')
+@variants('default', 'swin_split', 'swin_f22')
 def test_swin_block_golden(tag, kernel_variant):
     ops = _ops()
     a, sd, grads = load_golden("swin_block_" + tag)
@@ -112,7 +112,94 @@ def test_swin_block_golden(tag, kernel_variant):
         gclose("d" + n, p.grad[0], grads[n])
 
 
-@variants('default', 'swin_split')
+@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows", "ragged_windows"])
+def test_swin_f22_error_against_float64(profile, monkeypatch):
+    """IDEE_SWIN_MATH=f22 (every GEMM of the block on two f16 pieces per operand, weights prescaled by powers of two, the
+    incoming gradient scaled per 32-token work item) measured against a FLOAT64 evaluation of the oracle, beside the exact-f32
+    kernels and the two-piece bf16 backward (IDEE_SWIN_MATH=split) on the same inputs.  Weights at the reference's
+    initialisation scale (trunc_normal std 0.02, Swin_3D.py:117, :533 — f16 lo pieces of unscaled weights would be subnormal);
+    upstream gradient `loss_scale`: 1e-7 (a mean-reduced loss); `ragged_rows`: per-(d,h)-row magnitudes over 15 decades with
+    all-zero frames in between (scale changes in both directions inside a wave, zero tiles, the +40 clamp); `ragged_windows`:
+    one magnitude per (batch item, pair of frames of a shifted window) over 12 decades, one pair all zero — every work item
+    of both backward kernels is then homogeneous, so each frame's gradient must come out at f32 level RELATIVE TO ITS OWN
+    MAGNITUDE (what a per-launch scale could not give).
+    Asserted: relative L2 error of y, dx and every parameter gradient within 4x the exact-f32 kernels' own error (+ 2e-7);
+    for `loss_scale` / `ragged_windows` also the branch gradient dx - dy of every frame (n, d) against that frame's largest
+    |dy|: within 4x the exact kernels' worst frame (+ 1e-7)."""
+    from oracle import idee_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed({"loss_scale": 5, "ragged_rows": 11, "ragged_windows": 13}[profile])
+    N, D, H, W, C, NH = 2, 8, 24, 40, 16, 2
+    window, shift = (2, 4, 4), (1, 2, 2)
+    x = torch.randn((N, 1, D, H, W, C), generator=g) * 1.5
+    r = torch.randn((N, 1, D, H, W, C), generator=g)
+    if profile == "loss_scale":
+        r = r * 1e-7
+    elif profile == "ragged_rows":
+        mag = 10.0 ** (torch.rand((N, 1, D, H, 1, 1), generator=g) * 15.0 - 14.0)
+        r = r * mag
+        r[:, :, 3:5] = 0.0                                           # two all-zero frames
+    else:
+        # shifted (2,4,4) windows at shift 1 in d pair the frames {1,2},{3,4},{5,6},{7,0}
+        grp = ((torch.arange(D) - 1) % D) // 2
+        mag = 10.0 ** (torch.rand((N, D // 2), generator=g) * 12.0 - 11.0)
+        mag[0, 1] = 0.0                                               # frames 3, 4 of item 0: all zero
+        r = r * mag[:, grp].reshape(N, 1, D, 1, 1, 1)
+    shapes = {"attn.qkv.weight": (48, 16), "attn.qkv.bias": (48,), "attn.proj.weight": (16, 16), "attn.proj.bias": (16,),
+              "mlp.fc1.weight": (64, 16), "mlp.fc1.bias": (64,), "mlp.fc2.weight": (16, 64), "mlp.fc2.bias": (16,),
+              "attn.relative_position_bias_table": (147, 2)}
+    sd = {k: torch.randn(sh, generator=g) * 0.02 for k, sh in shapes.items()}
+    index = O.relative_position_index(window)
+    # float64 reference
+    sd64 = {k: v.double().requires_grad_() for k, v in sd.items()}
+    sd64["attn.relative_position_index"] = index
+    x64 = x[:, 0].double().requires_grad_()
+    y64 = O.swin_block(x64, sd64, "", NH, window, shift)
+    assert y64.dtype == torch.float64
+    (y64 * r[:, 0].double()).sum().backward()
+    ref = {"y": y64.detach(), "dx": x64.grad}
+    ref.update({"d" + k: sd64[k].grad for k in shapes})
+    names = list(shapes)
+
+    def run(mode):
+        monkeypatch.setenv("IDEE_SWIN_MATH", mode)
+        params = [sd[n].unsqueeze(0).to(DEV).requires_grad_() for n in names]
+        xd = x.to(DEV).requires_grad_()
+        y = ops.SwinBlock.apply(xd, *params, index.to(DEV), NH, window, shift, None)
+        (y * r.to(DEV)).sum().backward()
+        out = {"y": y[:, 0].detach().cpu().double(), "dx": xd.grad[:, 0].cpu().double()}
+        out.update({"d" + n: p.grad[0].cpu().double() for p, n in zip(params, names)})
+        assert all(bool(torch.isfinite(v).all()) for v in out.values()), mode
+        return out
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+    def frame_err(out):    # branch gradient (dx - dy) of each frame (n, d): largest error, and the frame's largest |dy|
+        rr = r[:, 0].double()
+        e = (out["dx"] - ref["dx"]).abs().amax(dim=(-1, -2, -3))
+        return e, rr.abs().amax(dim=(-1, -2, -3))
+
+    res = {m: run(m) for m in ("f32", "f22", "split")}
+    print(f"\n[f22 vs float64, profile {profile}] relative L2 error: tensor  exact-f32  f22  bf16x2-split")
+    for k in ref:
+        e = {m: rel(res[m][k], ref[k]) for m in res}
+        print(f"  {k:38s} {e['f32']:.2e}  {e['f22']:.2e}  {e['split']:.2e}")
+        assert e["f22"] <= 4.0 * e["f32"] + 2e-7, (k, e)
+    if profile == "ragged_rows":
+        return
+    e32, scale = frame_err(res["f32"])
+    e22, _ = frame_err(res["f22"])
+    live = scale > 0
+    if (~live).any():                                               # an all-zero window pair has an exactly zero gradient
+        assert float(e22[~live].max()) == 0.0
+    q32, q22 = (e32[live] / scale[live]), (e22[live] / scale[live])
+    print(f"  dx error per frame (n, d) / frame max|dy|: exact-f32 max {float(q32.max()):.2e}, f22 max {float(q22.max()):.2e} "
+          f"({int(live.sum())} frames, dy magnitudes {float(scale[live].min()):.1e} .. {float(scale[live].max()):.1e})")
+    assert float(q22.max()) <= 4.0 * float(q32.max()) + 1e-7, (float(q22.max()), float(q32.max()))
+
+
+@variants('default', 'swin_split', 'swin_f22')
 def test_swin_block_two_variables_vs_oracle(kernel_variant):
     """V = 2 weight sets, N = 2, a grid that is not a multiple of the window and spans many
     window groups (exercises b % V weight selection and the grid-stride loops)."""
@@ -587,7 +674,7 @@ def _safe_tokens(a, sd, cfg):
 
 
 @pytest.mark.parametrize("tag", ["swin_v2_14x18", "swin_v6_8x8_c2", "cnn_v2_12x16"])
-@variants('default', 'all_split', 'fwd22')
+@variants('default', 'all_split', 'fwd22', 'swin_f22')
 def test_e2e_eval_forward_golden(tag, kernel_variant):
     from idee_amd.models.build import VQ_model
     a, sd, _ = load_golden("e2e_" + tag)
@@ -609,7 +696,7 @@ def test_e2e_eval_forward_golden(tag, kernel_variant):
 
 
 @pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16", "era5_swin_v3_c2_10x12"])
-@variants('default', 'all_split', 'fwd22')
+@variants('default', 'all_split', 'fwd22', 'swin_f22')
 def test_e2e_train_steps_golden(tag, kernel_variant):
     """3 full steps of the train_synthetic.py / train_ERA5_Land.py sequence (fused step objects) vs the reference's
     outputs, losses, all gradients and the parameters after 3 Adam steps."""
@@ -721,7 +808,7 @@ def test_vq_nearest_golden(tag):
         gclose("dembed", q._codebook.embed.grad, grads["_codebook.embed"])
 
 
-@variants('default', 'swin_split', 'conv32_generic', 'all_split')
+@variants('default', 'swin_split', 'swin_f22', 'conv32_generic', 'all_split')
 def test_small_config_c32_vs_oracle(kernel_variant):
     """Builder-defined "small" width: embed 32, head_dim 16, codebook/cls dim 32, C_in = 2,
     depths [2,2] — full model forward + one backward against the oracle (strict; tie-free, boundary-free case)."""
@@ -837,7 +924,7 @@ def test_harness_evaluators_collector_checkpoint(tmp_path):
 
 
 @pytest.mark.parametrize("tag", ["16_32", "32_16"])
-@variants('default', 'swin_split')
+@variants('default', 'swin_split', 'swin_f22')
 def test_swin_hierarchical_encoder_golden(tag, kernel_variant):
     """Swin_3D with a width change between its stages (the reference re-embeds with PatchEmbed3D(in_dim -> dim) + LN,
     Swin_3D.py:414-419): outputs and every gradient against the reference's own."""
@@ -940,7 +1027,7 @@ def test_vq_ema_kmeans_expire_golden(tag):
         assert bool(sd["_codebook.initted"])
 
 
-@variants('default', 'swin_split')
+@variants('default', 'swin_split', 'swin_f22')
 def test_swin_block_qkv_bias_false_golden(kernel_variant):
     """SwinTransformerBlock3D built with qkv_bias=False (Swin_3D.py:137): the kernels get a zero, untrained bias."""
     ops = _ops()
@@ -962,7 +1049,7 @@ def test_swin_block_qkv_bias_false_golden(kernel_variant):
 
 
 @pytest.mark.parametrize("C", [16, 32])
-@variants('default', 'swin_split')
+@variants('default', 'swin_split', 'swin_f22')
 def test_swin_block_drop_path_vs_oracle(C, kernel_variant):
     """Stochastic depth: the kernels take the per-sample DropPath factors (mask / keep_prob, incl. dropped samples = 0) of
     both residual branches; forward and every gradient against the oracle with the same factors.  C = 32 runs the exact-f32
@@ -1074,7 +1161,7 @@ def test_swin_encoder_dropout_module_flags_and_split_refusal(monkeypatch):
         enc(x)
 
 
-@variants('default', 'swin_split')
+@variants('default', 'swin_split', 'swin_f22')
 def test_swin_encoder_drop_path_rate_module(kernel_variant):
     """Swin_3D(drop_path_rate > 0): identity in eval mode, stochastic in training (the decay rule gives block 0 rate 0)."""
     from idee_amd.models.encoder.Swin_3D import Swin_3D
