@@ -343,7 +343,7 @@ def main():
     a = parse()
     # the library reads these at every launch; child ranks inherit them.  The headline (--math f32) pins BOTH to the exact-f32
     # kernels whatever the caller's environment holds, so the printed `dtype` / `math` always describe what ran.
-    os.environ["IDEE_CONV_MATH"] = {"split": "split", "fwd22": "fwd22", "f22": "fwd22"}.get(a.math, "f32")
+    os.environ["IDEE_CONV_MATH"] = a.math if a.math in ("split", "fwd22", "f22") else "f32"
     os.environ["IDEE_SWIN_MATH"] = a.math if a.math in ("split", "fwd22", "f22") else "f32"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))

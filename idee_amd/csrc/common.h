@@ -153,4 +153,67 @@ __device__ __forceinline__ Split split2(f32x4 x) {
   }
   return p;
 }
+
+// ---- f16 pieces at f32 level: exact power-of-two scale factors (swin_mfma.hip "f16 pieces at f32 level", conv_mfma.hip) ----
+__device__ __forceinline__ float pow2i(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }   // |k| <= 126
+// max over the 64 lanes, every lane gets it: four DPP row rotations (16-lane rows) and gfx950's two permlane swaps — ten VALU
+// instructions, no LDS round trips (six ds_bpermute steps cost ~800 cycles per call)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+  v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+  v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124 /*row_ror:4*/, 0xf, 0xf, false));
+  v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122 /*row_ror:2*/, 0xf, 0xf, false));
+  v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /*row_ror:1*/, 0xf, 0xf, false));
+  typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+  u32x2w r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = mx(r[0], r[1]);
+  r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return mx(r[0], r[1]);
+}
+__device__ __forceinline__ float amax4(f32x4 v) {
+  return fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+}
+// Power-of-two scale of a gradient tile, kept per wave: the tile's largest |dy| 2^k stays in [2^1, 2^8), re-centred on 2^4
+// when a tile leaves the window; k moves up by at most 40 above the smallest k the wave has used (bounds accumulators that
+// are rescaled along).
+struct GradScale {
+  int k = 0, kmin = 0;
+  bool set = false;
+  // amax: the wave's largest |dy| of this work item (any lane's copy after wave_umax).  Returns the factor the weight-gradient
+  // accumulators must be multiplied with (1 = unchanged) and moves k.
+  __device__ __forceinline__ float update(unsigned amax_bits) {
+    constexpr int LO = 1, HI = 7, MID = 4;
+    amax_bits = __builtin_amdgcn_readfirstlane(amax_bits);
+    const int e = (int)(amax_bits >> 23) - 127;
+    if (amax_bits == 0u || e > 127) return 1.f;     // zero tile / inf: keep the scale
+    if (set && e + k >= LO && e + k <= HI) return 1.f;
+    int kn = MID - e;
+    kn = kn < -63 ? -63 : (kn > 63 ? 63 : kn);
+    if (!set) { k = kmin = kn; set = true; return 1.f; }
+    if (kn > kmin + 40) kn = kmin + 40;
+    if (kn == k) return 1.f;
+    const float f = pow2i(kn - k);
+    k = kn;
+    if (kn < kmin) kmin = kn;
+    return f;
+  }
+  // Data-gradient staging (conv16_split_kernel): the scale of a work unit only moves DOWN.  exceeds(): this row would leave
+  // the window at the top (or no scale is set yet); set_from(): scale from the largest |dy| of all rows to be staged.
+  __device__ __forceinline__ bool exceeds(unsigned amax_bits) const {
+    amax_bits = __builtin_amdgcn_readfirstlane(amax_bits);
+    const int e = (int)(amax_bits >> 23) - 127;
+    return amax_bits != 0u && e <= 127 && (!set || e + k > 7);
+  }
+  __device__ __forceinline__ void set_from(unsigned amax_bits) {
+    amax_bits = __builtin_amdgcn_readfirstlane(amax_bits);
+    const int e = (int)(amax_bits >> 23) - 127;
+    if (amax_bits == 0u || e > 127) return;
+    const int kn = 4 - e;
+    k = kn < -63 ? -63 : (kn > 63 ? 63 : kn);
+    set = true;
+  }
+  __device__ __forceinline__ float s() const { return pow2i(k); }
+  __device__ __forceinline__ float inv() const { return pow2i(-k); }
+};
+
 }  // namespace idee

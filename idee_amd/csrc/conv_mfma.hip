@@ -1278,8 +1278,16 @@ __global__ __launch_bounds__(768) void dgrad_k133_to16_kernel(ConvArgs a, int ns
 // ---------------------------------------------------------------------------------------------
 constexpr int kSplitRowW = 2 * kC16Row * 4;     // 32-bit words of one staged row of ONE piece: [2 quad pairs][34 px][4 words]
 
-template <int MODE, bool F16>
+// GSC (IDEE_CONV_MATH=f22, data-gradient modes with f16 pieces): the staged dy rows carry a power-of-two factor 2^k kept per
+// WORK UNIT (32 pixels x a run of rows x the 3 source frames of one batch item) such that the unit's largest |dy| 2^k seen so
+// far lies below 2^8 (common.h GradScale): every newly staged row is tested on the staging registers (one compare and the wave's
+// vote); a row that would leave the window at the top lowers k (its largest |dy| 2^k to [2^4, 2^5); the rows already in the ring
+// were below 2^8 at the larger scale, so they stay in range), the ring is invalidated and the output row is begun again — rare:
+// the scale of a unit only moves down; the first non-zero row of a unit sets it.  The epilogue multiplies by 2^-k.
+// Operand rounding max(2^-22 |dy|, 2^-26 of the unit's largest |dy| so far); weights prescaled per set as in the forward.
+template <int MODE, bool F16, bool GSC = false>
 __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
+  static_assert(!GSC || (F16 && (MODE == DGRAD_REP || MODE == DGRAD_S2)), "gradient scale: f16 pieces, data-gradient modes");
   constexpr int MT = 2;
   constexpr bool REP = MODE == FWD_REP || MODE == DGRAD_REP;
   constexpr int TSN = REP ? 3 : (MODE == FWD_S2 ? 2 : 1);
@@ -1330,43 +1338,74 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
 #pragma unroll
     for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti, a.kt);
     const int blk1 = my_sub > 1 ? 16 : 0;
+    GradScale gs;                       // (GSC) this unit's gradient scale
 
-    for (int h = h0; h < h1; ++h) {
+    // piece k of source row hs of source frame ot -> registers (zeros outside the frame)
+    auto load_one = [&](int hs, bool inside, int ot, int k) __attribute__((always_inline)) {
+      const float* src = in_b + (long)st[ot].src * a.i_sT + (long)hs * a.i_sH;
+      const bool live = inside && st[ot].ok;
+      const int u = lane + 64 * k;
+      const int px = u >> 2, q4 = u & 3;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (u < rowlen * 4 && live) {
+        if (MODE == FWD_REP) {
+          const int w = min(max(p0 + px - 1, 0), a.Wi - 1);
+          v = ld4(src + (long)w * a.i_sW + 4 * q4);
+        } else {
+          const int w = p0 + px - (MODE == DGRAD_REP ? 2 : 1);
+          if (w >= 0 && w < a.Wi) v = ld4(src + (long)w * a.i_sW + 4 * q4);
+        }
+      }
+      return v;
+    };
+    auto load_row = [&](int hs, bool inside, f32x4 (&stg)[TSN][3]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ot = 0; ot < TSN; ++ot)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) stg[ot][k] = load_one(hs, inside, ot, k);
+    };
+    auto row_amax = [&](const f32x4 (&stg)[TSN][3]) __attribute__((always_inline)) {
+      float am = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < TSN; ++ot)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) am = fmaxf(am, amax4(stg[ot][k]));
+      return am;
+    };
+
+    for (int h = h0; h < h1;) {
       wave_fence();
       Slot sh[3];
       int slot_of[3];
+      bool redo = false;
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) sh[oh] = slot_h<MODE>(oh, h, a.Hi);
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) {
-        sh[oh] = slot_h<MODE>(oh, h, a.Hi);
         const int hs = sh[oh].src;
         const bool inside = sh[oh].ok;
         const int slot = (hs + 3) % 3;
         slot_of[oh] = slot;
         const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
         if (cur == hs + 1) continue;
-        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
         f32x4 stg[TSN][3];
-#pragma unroll
-        for (int ot = 0; ot < TSN; ++ot) {
-          const float* src = in_b + (long)st[ot].src * a.i_sT + (long)hs * a.i_sH;
-          const bool live = inside && st[ot].ok;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int u = lane + 64 * k;
-            const int px = u >> 2, q4 = u & 3;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (u < rowlen * 4 && live) {
-              if (MODE == FWD_REP) {
-                const int w = min(max(p0 + px - 1, 0), a.Wi - 1);
-                v = ld4(src + (long)w * a.i_sW + 4 * q4);
-              } else {
-                const int w = p0 + px - (MODE == DGRAD_REP ? 2 : 1);
-                if (w >= 0 && w < a.Wi) v = ld4(src + (long)w * a.i_sW + 4 * q4);
-              }
-            }
-            stg[ot][k] = v;
+        load_row(hs, inside, stg);
+        if constexpr (GSC) {
+          const float am = row_amax(stg);
+          // (a threshold test needs no reduction: one compare and the wave's vote)
+          if (gs.set ? __any(am * gs.s() >= 256.f) : __any(am > 0.f)) {
+            gs.set_from(wave_umax(__float_as_uint(am)));
+            res0 = res1 = res2 = -1;
+            redo = true;
+            break;
           }
+          const float gsc = gs.s();
+#pragma unroll
+          for (int ot = 0; ot < TSN; ++ot)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) stg[ot][k] *= gsc;
         }
+        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
 #pragma unroll
         for (int ot = 0; ot < TSN; ++ot) {
           unsigned* dst = s_x + (ot * 3 + slot) * kSplitRowW;
@@ -1383,6 +1422,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
           }
         }
       }
+      if (GSC && redo) continue;          // (h not advanced: the row is staged again at the new scale)
       wave_fence();
       {
         const int key = ((((st[0].tap * 3 + st[1].tap) * 3 + st[2].tap) * 3 + sh[0].tap) * 3 + sh[1].tap) * 3 + sh[2].tap;
@@ -1449,7 +1489,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
         int wdst = p;
         bool atomic = false;
         if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
-        f32x4 v = F16 ? acc[m] * winv : acc[m];
+        f32x4 v = F16 ? acc[m] * (GSC ? winv * gs.inv() : winv) : acc[m];
         if (a.bias) v += ld4(a.bias + (long)wset * 16 + 4 * kq);
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const long o = (long)wdst * a.o_sW + 4 * kq;
@@ -1466,6 +1506,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
           st4(out_r + o, v);
         }
       }
+      ++h;
     }
   }
 }
@@ -1782,7 +1823,10 @@ __global__ __launch_bounds__(256, 2) void wgrad16_glds_kernel(WgradArgs a, int n
 // group g) gets pixels 8g..8g+7 of channel i, shifted by the tap); dy comes from global memory as before and is split in
 // registers.  16 -> 16 channels only (NB = 1).
 // ---------------------------------------------------------------------------------------------
-template <int MODE /*FWD_REP | FWD_S2*/, int TSL>
+// F16 (IDEE_CONV_MATH=f22): f16 pieces; the dy row of every output row (16 channels x 32 pixels, in registers) is multiplied by
+// a power of two kept per wave with common.h GradScale — the row's largest |dy| 2^k in [2^1, 2^8), the 9 TSL tap accumulators
+// multiplied along when k moves, by 2^-k at the flush; x (activations, O(1)) is split unscaled as in the forward kernels.
+template <int MODE /*FWD_REP | FWD_S2*/, int TSL, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
   constexpr int NTAPS = TSL * 9;
   constexpr int ROWW = kC16Row * 16;              // 32-bit words per staged row: 34 pixels x (8 words hi + 8 words lo)
@@ -1793,6 +1837,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
   unsigned* s_x = s_xw[wave];
   f32x4 acc[NTAPS];
   float bsum = 0.f;
+  GradScale gs;
 #pragma unroll
   for (int tp = 0; tp < NTAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nsub = (a.W + 15) / 16;
@@ -1836,7 +1881,16 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
         if (jj < 4) d0[jj] = v; else d1[jj - 4] = v;
         bsum += v;
       }
-      const Split s0 = split2<false>(d0), s1 = split2<false>(d1);
+      if constexpr (F16) {
+        const float f = gs.update(wave_umax(__float_as_uint(fmaxf(amax4(d0), amax4(d1)))));
+        if (f != 1.f) {
+#pragma unroll
+          for (int tp = 0; tp < NTAPS; ++tp) acc[tp] *= f;
+        }
+        const float gsc = gs.s();
+        d0 *= gsc; d1 *= gsc;
+      }
+      const Split s0 = split2<F16>(d0), s1 = split2<F16>(d1);
       const u32x4 Bh = {s0.h01, s0.h23, s1.h01, s1.h23}, Bl = {s0.l01, s0.l23, s1.l01, s1.l23};
       int slot_of[3];
 #pragma unroll
@@ -1871,7 +1925,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
           for (int k = 0; k < 3; ++k) {
             const int u = lane + 64 * k;
             if (u < kC16Row * 4) {          // pixels past a one-block strip are written as zeros
-              const Split p = split2<false>(stg[ot][k]);
+              const Split p = split2<F16>(stg[ot][k]);
               typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
               *reinterpret_cast<u32x2v*>(dst + (u >> 2) * 16 + (u & 3) * 2) = u32x2v{p.h01, p.h23};
               *reinterpret_cast<u32x2v*>(dst + (u >> 2) * 16 + 8 + (u & 3) * 2) = u32x2v{p.l01, p.l23};
@@ -1892,18 +1946,19 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
             const u32x4 Ah = {(unsigned)h0_, (unsigned)(h0_ >> 32), (unsigned)h1_, (unsigned)(h1_ >> 32)};
             const u32x4 Al = {(unsigned)l0_, (unsigned)(l0_ >> 32), (unsigned)l1_, (unsigned)(l1_ >> 32)};
             const int tp = (ot * 3 + oh) * 3 + ow;
-            acc[tp] = mfma_s<false>(Ah, Bh, acc[tp]);
-            acc[tp] = mfma_s<false>(Ah, Bl, acc[tp]);
-            acc[tp] = mfma_s<false>(Al, Bh, acc[tp]);
+            acc[tp] = mfma_s<F16>(Ah, Bh, acc[tp]);
+            acc[tp] = mfma_s<F16>(Ah, Bl, acc[tp]);
+            acc[tp] = mfma_s<F16>(Al, Bh, acc[tp]);
           }
     }
   }
   float* dw = a.dwp + (long)wset * NTAPS * 16 * a.CoutPad;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
+  const float un = F16 ? gs.inv() : 1.f;
 #pragma unroll
   for (int tp = 0; tp < NTAPS; ++tp)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + col, acc[tp][r]);
+    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + col, F16 ? acc[tp][r] * un : acc[tp][r]);
   if (a.dbias) {
     float v = bsum;
     v += __shfl_xor(v, 16, 64);
@@ -2449,7 +2504,13 @@ void split_tiles(ConvArgs& a, int Wframe) {
 
 // IDEE_CONV_MATH=split selects the split-precision 16 -> 16 kernels (default: exact f32 MFMA)
 // (IDEE_CONV_MATH=fwd22: only the forward passes, whose f16 pieces round operands at 2^-22; see swin_mfma.hip split_math)
-bool conv_split_math(bool forward) { return env_is("IDEE_CONV_MATH", "split") || (forward && env_is("IDEE_CONV_MATH", "fwd22")); }
+// (IDEE_CONV_MATH=f22: the forward passes as fwd22; the 16 -> 16 data and weight gradients on f16 pieces with a power-of-two
+//  gradient scale per work unit / per row — conv16_split_kernel<.., GSC>, wgrad16_split_kernel<.., F16>; the other gradient
+//  kernels stay exact f32)
+bool conv_f22_math() { return env_is("IDEE_CONV_MATH", "f22"); }
+bool conv_split_math(bool forward) {
+  return env_is("IDEE_CONV_MATH", "split") || (forward && (env_is("IDEE_CONV_MATH", "fwd22") || conv_f22_math()));
+}
 
 template <int MODE>
 int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
@@ -2494,6 +2555,16 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       const int hrun = pick_hrun(a.Ho, bt * nstrip, a.wsets, 2);
       const int nhrun = cdiv(a.Ho, hrun);
       const long nunits = bt * nhrun * nstrip;
+      if constexpr (MODE == DGRAD_REP || MODE == DGRAD_S2) {
+        // f16 pieces with the per-unit gradient scale (not the 2 x 2 sub-problems of a 32 -> 32 conv: the split kernels read
+        // the packed weights without a tap stride)
+        if (conv_f22_math() && !a.w_tap_stride && !a.addend_first) {
+          auto kern = conv16_split_kernel<MODE, true, true>;
+          const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
+          hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
+          return IDEE_OK;
+        }
+      }
       if (conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) {      // opt-in split-precision path: f16 pieces forward, bf16 pieces in the data gradient
         auto kern = conv16_split_kernel<MODE, (MODE == FWD_REP || MODE == FWD_S2)>;
         const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
@@ -2788,7 +2859,10 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
                        dim3(256), 0, st, a, nstrip, hr2, nhr2);                                               \
   } while (0)
     const bool split = conv_split_math(false) && Gb == 1 && Ga == 1;
-    if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
+    const bool f22 = conv_f22_math() && Gb == 1 && Ga == 1;
+    if (rep && f22) LSTRIP((wgrad16_split_kernel<FWD_REP, 3, true>));
+    else if (d->mode == IDEE_CONV_K233_S2_ZERO && f22) LSTRIP((wgrad16_split_kernel<FWD_S2, 2, true>));
+    else if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSTRIP((wgrad16_split_kernel<FWD_S2, 2>));
     else if (rep && !env_is("IDEE_WGRAD16_REGS", "1")) {
       // LDS-DMA staged kernel, cost-axis partition (see conv16_glds_kernel); a one-block last strip's rows weigh by their K-chunks

@@ -38,6 +38,8 @@ KERNEL_VARIANTS = {
     "default": {},                                                   # exact-f32 MFMA everywhere (the headline arithmetic)
     "swin_split": {"IDEE_SWIN_MATH": "split"},                       # two-piece split GEMMs in the Swin block (opt-in)
     "swin_f22": {"IDEE_SWIN_MATH": "f22"},                           # f16 pieces fwd + bwd, prescaled weights, per-tile gradient scale
+    "conv_f22": {"IDEE_CONV_MATH": "f22"},                           # f16 pieces: forward convs, 16->16 data / weight gradients (scaled dy)
+    "all_f22": {"IDEE_SWIN_MATH": "f22", "IDEE_CONV_MATH": "f22"},   # bench.py --math f22
     "conv_split": {"IDEE_CONV_MATH": "split"},                       # split-precision convolutions (opt-in)
     "all_split": {"IDEE_SWIN_MATH": "split", "IDEE_CONV_MATH": "split"},
     "fwd22": {"IDEE_SWIN_MATH": "fwd22", "IDEE_CONV_MATH": "fwd22"},   # split kernels in the forward only, exact backward

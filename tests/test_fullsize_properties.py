@@ -51,7 +51,7 @@ CROPS = {
 
 @pytest.mark.parametrize("crop", list(CROPS))
 @pytest.mark.parametrize("encoder", ["Swin_3D", "CNN_3D"])
-@variants('default', 'all_split')
+@variants('default', 'all_split', 'all_f22')
 def test_fullsize_forward_matches_oracle_on_crop(encoder, crop, kernel_variant):
     """Full-size (V=6, T=8, 200x200) forward vs the ORACLE on a crop, element by element, no conditional skips:
     the continuous encoder output everywhere in the region; `anomaly` and z_q at every token that is not an LFQ
@@ -141,7 +141,7 @@ def test_fullsize_width_swin_block_gradients_vs_oracle(kernel_variant):
             gclose("d" + n, p_.grad, torch.stack([sds[v][n].grad for v in range(V)]))
 
 
-@variants('default', 'conv_split', 'conv16_regs', 'wgrad16_regs')
+@variants('default', 'conv_split', 'conv_f22', 'conv16_regs', 'wgrad16_regs')
 def test_fullsize_conv_linearity_and_wgrad_identity(kernel_variant):
     """conv(a x1 + b x2) = a conv(x1) + b conv(x2) (bias off) for the 3^3 replicate conv at full size, and
     <conv(x), r> = <x, conv^T(r)> = <w, wgrad(x, r)> (adjoint identities tie fwd, dgrad and wgrad together)."""

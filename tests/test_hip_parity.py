@@ -232,7 +232,7 @@ def test_swin_block_two_variables_vs_oracle(kernel_variant):
         gclose("d" + n, p.grad, torch.stack([sds[v][n].grad for v in range(V)]))
 
 
-@variants('default', 'conv_split', 'conv16_regs', 'wgrad16_regs')
+@variants('default', 'conv_split', 'conv_f22', 'conv16_regs', 'wgrad16_regs')
 def test_proj_var_golden(kernel_variant):
     ops = _ops()
     a, sd, grads = load_golden("proj_var")
@@ -247,7 +247,7 @@ def test_proj_var_golden(kernel_variant):
 
 
 @pytest.mark.parametrize("tag,cin", [("1_16", 1), ("16_16", 16)])
-@variants('default', 'conv_split', 'wgrad16_regs')
+@variants('default', 'conv_split', 'conv_f22', 'wgrad16_regs')
 def test_conv_block_golden(tag, cin, kernel_variant):
     """CNN_3D encoder block: [PatchEmbed+LN] -> 2 x (x + ReLU(LN_affine(conv3^3 replicate(x))))."""
     ops = _ops()
@@ -278,7 +278,7 @@ def test_conv_block_golden(tag, cin, kernel_variant):
 
 
 @pytest.mark.parametrize("T,H,W", [(8, 9, 72), (3, 5, 200), (8, 6, 200), (1, 1, 1), (2, 2, 17), (3, 21, 40)])
-@variants('default', 'conv_split', 'conv16_regs', 'wgrad16_regs')
+@variants('default', 'conv_split', 'conv_f22', 'conv16_regs', 'wgrad16_regs')
 def test_proj_var_vs_oracle(T, H, W, monkeypatch, kernel_variant):
     """Multi-tile widths (72 = 3+2 column blocks, 200 = 4+3+3+3 incl. both frame edges), thin extents
     (clamp-everything cases).  Strict gradient tolerance on a tie-free case."""
@@ -313,7 +313,7 @@ def test_proj_var_vs_oracle(T, H, W, monkeypatch, kernel_variant):
 
 
 @pytest.mark.parametrize("T,H,W", [(3, 5, 200), (8, 7, 40)])
-@variants('default', 'conv_split')
+@variants('default', 'conv_split', 'conv_f22')
 def test_conv_ln_unit_vs_oracle(T, H, W, kernel_variant):
     """CNN_3D encoder unit x + ReLU(LN(conv3^3 replicate(x))) twice at a frame-wide W (both edge columns, partial
     column blocks) against the oracle, strict tolerance on a tie-free case."""
@@ -388,7 +388,7 @@ def _classifier(sd, V):
 
 
 @pytest.mark.parametrize("tag", ["classifier_v2", "classifier_v2_k3"])       # _k3: n_classes = 3 (joint head only, as the reference)
-@variants('default', 'conv_split')
+@variants('default', 'conv_split', 'conv_f22')
 def test_classifier_golden(tag, kernel_variant):
     a, sd, grads = load_golden(tag)
     c = _classifier(sd, 2)
@@ -409,7 +409,7 @@ def test_classifier_golden(tag, kernel_variant):
 
 @pytest.mark.parametrize("V,H,W,E", [(3, 7, 72, 16), (6, 5, 40, 16), (1, 3, 3, 16), (5, 4, 20, 16), (6, 6, 200, 16), (2, 3, 200, 16),
                                      (6, 4, 24, 32), (3, 3, 20, 32), (2, 19, 40, 16), (3, 5, 24, 16)])
-@variants('default', 'conv_split')
+@variants('default', 'conv_split', 'conv_f22')
 def test_classifier_vs_oracle(V, H, W, E, monkeypatch, kernel_variant):
     """Plain path (convolutions on z_q).  W = 200: the frame-wide row-wrapping column-block numbering of conv_wide,
     its zero borders, the wide weight-gradient kernel and the heads' strip kernels at both frame edges.  E = 32 (config #4's
@@ -456,7 +456,7 @@ def test_classifier_vs_oracle(V, H, W, E, monkeypatch, kernel_variant):
 
 @pytest.mark.parametrize("V,D,H,W", [(3, 1, 7, 72), (6, 1, 5, 40), (1, 1, 3, 3), (5, 2, 4, 20), (8, 2, 3, 19), (6, 1, 6, 200),
                                      (2, 2, 3, 200), (6, 1, 19, 40)])
-@variants('default', 'conv_split', 'dgrad_to16_wide')
+@variants('default', 'conv_split', 'conv_f22', 'dgrad_to16_wide')
 def test_classifier_sign_field_vs_oracle(V, D, H, W, monkeypatch, kernel_variant):
     """The rank-d input path (ops.ClassifierHeadsSigns: convs on the sign field with folded weights) against
     the oracle's classifier applied to z_q = project_out(signs): outputs and every gradient (strict, tie-free case)."""
@@ -674,7 +674,7 @@ def _safe_tokens(a, sd, cfg):
 
 
 @pytest.mark.parametrize("tag", ["swin_v2_14x18", "swin_v6_8x8_c2", "cnn_v2_12x16"])
-@variants('default', 'all_split', 'fwd22', 'swin_f22')
+@variants('default', 'all_split', 'fwd22', 'all_f22')
 def test_e2e_eval_forward_golden(tag, kernel_variant):
     from idee_amd.models.build import VQ_model
     a, sd, _ = load_golden("e2e_" + tag)
@@ -696,7 +696,7 @@ def test_e2e_eval_forward_golden(tag, kernel_variant):
 
 
 @pytest.mark.parametrize("tag", ["swin_v2_14x18", "cnn_v2_12x16", "era5_swin_v3_c2_10x12"])
-@variants('default', 'all_split', 'fwd22', 'swin_f22')
+@variants('default', 'all_split', 'fwd22', 'all_f22')
 def test_e2e_train_steps_golden(tag, kernel_variant):
     """3 full steps of the train_synthetic.py / train_ERA5_Land.py sequence (fused step objects) vs the reference's
     outputs, losses, all gradients and the parameters after 3 Adam steps."""
@@ -808,7 +808,7 @@ def test_vq_nearest_golden(tag):
         gclose("dembed", q._codebook.embed.grad, grads["_codebook.embed"])
 
 
-@variants('default', 'swin_split', 'swin_f22', 'conv32_generic', 'all_split')
+@variants('default', 'swin_split', 'swin_f22', 'conv32_generic', 'all_split', 'all_f22')
 def test_small_config_c32_vs_oracle(kernel_variant):
     """Builder-defined "small" width: embed 32, head_dim 16, codebook/cls dim 32, C_in = 2,
     depths [2,2] — full model forward + one backward against the oracle (strict; tie-free, boundary-free case)."""
@@ -1179,7 +1179,7 @@ def test_swin_encoder_drop_path_rate_module(kernel_variant):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
 
 
-@variants('default', 'conv_split')
+@variants('default', 'conv_split', 'conv_f22')
 def test_conv_block_drop_path_vs_oracle(kernel_variant):
     """CNN_3D encoder unit with stochastic depth: y = x + s_b * ReLU(LN(conv(x))) with the per-item factor s_b (0 = dropped),
     forward and gradients against the oracle formula."""
