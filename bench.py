@@ -62,7 +62,8 @@ def parse():
                          "(IDEE_SWIN_MATH=split) — a separately labelled line, never the headline.  fwd22: only the FORWARD passes on the "
                          "split kernels (f16 pieces: operand rounding 2^-22), every backward pass exact f32 — also a separate line.  f22: the Swin block's "
                          "forward AND backward on f16 pieces with power-of-two prescaled weights and a per-work-item gradient scale "
-                         "(IDEE_SWIN_MATH=f22; operand rounding 2^-22 in every GEMM), convolutions as in fwd22 — a separate line")
+                         "(IDEE_SWIN_MATH=f22; operand rounding 2^-22 in every GEMM), convolutions: forward as in fwd22, 16->16 gradients on f16 "
+                         "pieces with per-tile gradient scales (IDEE_CONV_MATH=f22) — a separate line")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="activation storage between the fused units.  f32 (default): the reference's arithmetic.  bf16: BASELINE "
                          "config #4's precision — bf16 tokens, bf16 MFMA GEMMs / convolutions with f32 accumulate, f32 LFQ, losses, "
@@ -246,6 +247,10 @@ def math_label(math, cfg, dtype="f32"):
             d["swin_gemm"] = ("forward: two f16 pieces per operand, all 4 piece products, f32 accumulate (operand rounding 2^-22), attention "
                               "scores on the f32 MFMA; backward: exact f32 MFMA")
             if math == "f22":
+                d["conv"] = ("forward of the 16->16 and 96-wide convs and the 16->16 data / weight gradients: two f16 pieces per operand, 3 piece "
+                             "products; weights prescaled by a power of two per set, dy scaled by a power of two per work unit (data "
+                             "gradient: 32 pixels x a run of rows, the scale only moving down) / per 32-pixel row (weight gradient, "
+                             "accumulators rescaled along); the 96-wide and (1,3,3) gradient kernels exact f32 MFMA")
                 d["swin_gemm"] = ("forward and backward: two f16 pieces per operand, all 4 piece products, f32 accumulate; weight tensors "
                                   "prescaled by a power of two per tensor (largest |w| in [2^6, 2^7)), the incoming gradient scaled by a "
                                   "power of two per 32-token work item (largest |dy| in [2^1, 2^8)): operand rounding max(2^-22 |x|, "
@@ -482,8 +487,9 @@ def main():
                dtype=("bf16" if a.dtype == "bf16" else "f32" if a.math == "f32" else
                       "f32 storage/accumulate; forward convolutions and Swin linear layers on two-piece f16 split MFMAs (operand rounding "
                       "2^-22), every backward pass exact f32" if a.math == "fwd22" else
-                      "f32 storage/accumulate; Swin linear layers forward and backward and the forward convolutions on two-piece f16 split "
-                      "MFMAs (operand rounding 2^-22; prescaled weights, per-tile gradient scale), convolution gradients exact f32"
+                      "f32 storage/accumulate; Swin linear layers (forward and backward), forward convolutions and the 16->16 convolution "
+                      "gradients on two-piece f16 split MFMAs at f32 level (operand rounding 2^-22: power-of-two prescaled weights, "
+                      "per-tile power-of-two gradient scales); the other convolution gradients exact f32"
                       if a.math == "f22" else
                       "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs"),
                math=math_label(a.math, cfg, a.dtype),

@@ -466,10 +466,17 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 // weight slab is converted to piece fragments [w(group a) | w(group b)] (hi and lo) while it is staged into LDS, double
 // buffered as before; the activations of the two groups are split in registers right after their loads.  Gk even.
 // ---------------------------------------------------------------------------------------------
-template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT>
+// f16 pieces (forward; data gradient under IDEE_CONV_MATH=f22, GSC): the weight set is prescaled by a power of two found in the
+// kernel prologue (largest |w| of the set in [2^13, 2^14): both pieces of every weight that matters are normal numbers; the
+// epilogue multiplies by its inverse).  GSC: the dy operands of a wave's chunk (4 column blocks x all taps x all channel groups)
+// carry a power-of-two factor 2^k kept per wave and chunk (common.h GradScale, moving down only): every (tap, group pair)
+// operand is tested before it is split (one compare and the wave's vote); an operand that would leave the window at the top
+// lowers k, the chunk's accumulators are multiplied along (exact), and the epilogue multiplies by 2^-k.
+template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT, bool GSC = false>
 __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
+  static_assert(!GSC || MODE == DGRAD_S2, "gradient scale: data-gradient mode");
   constexpr int MT = 4, WAVES = 8;
-  constexpr bool F16 = MODE == FWD_S2;
+  constexpr bool F16 = MODE == FWD_S2 || GSC;
   extern __shared__ __attribute__((aligned(16))) unsigned s_ws[];   // [2][Gk/2 * NT * 2 pieces * 256 words]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -478,6 +485,24 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
   const int GP = a.Gk / 2;                                // channel-group pairs
   const int slab = a.Gk * NT * 256;                       // f32 floats per tap in the packed buffer == words per split slab
   const float* wp = a.wp + (long)wset * a.ntaps * slab;
+  float wscale = 1.f, winv = 1.f;
+  if constexpr (F16) {
+    __shared__ unsigned s_wmax[WAVES];
+    float mx = 0.f;
+    for (long i = 4L * tid; i < (long)a.ntaps * slab; i += 4 * 512) mx = fmaxf(mx, amax4(ld4(wp + i)));
+    const unsigned wm_ = wave_umax(__float_as_uint(mx));
+    if (lane == 0) s_wmax[wave] = wm_;
+    __syncthreads();
+    unsigned bm = 0u;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) bm = bm > s_wmax[w] ? bm : s_wmax[w];
+    bm = __builtin_amdgcn_readfirstlane(bm);
+    const int e = (int)(bm >> 23) - 127;
+    if (bm != 0u && e <= 127) {
+      const int k = 13 - e < -60 ? -60 : (13 - e > 60 ? 60 : 13 - e);
+      wscale = pow2i(k); winv = pow2i(-k);
+    }
+  }
   const int npu = GP * NT * 64;                           // (pair, output block, lane) units per tap
   const int NOT = (MODE == FWD_S2) ? a.kt : 1;
   const int nblk = a.Ho * a.nsub;
@@ -489,7 +514,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
     fb = ld4(src + ((2 * gp + 1) * NT + n) * 256 + l * 4);
   };
   auto store_unit = [&](unsigned* dst, int u, f32x4 fa, f32x4 fb) __attribute__((always_inline)) {
-    const Split sa = split2<F16>(fa), sb = split2<F16>(fb);
+    const Split sa = split2<F16>(F16 ? fa * wscale : fa), sb = split2<F16>(F16 ? fb * wscale : fb);
     const int l = u & 63, r = u >> 6;
     *reinterpret_cast<u32x4*>(dst + ((r * 2 + 0) * 64 + l) * 4) = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
     *reinterpret_cast<u32x4*>(dst + ((r * 2 + 1) * 64 + l) * 4) = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
@@ -512,6 +537,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       vm[m] = vm[m] && wm[m] < a.Wo;
     }
     f32x4 acc[MT][NT];
+    GradScale gs;                                        // (GSC) this wave's scale for this chunk
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -577,9 +603,28 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
         }
         if (row_ok) {
           u32x4 bh[MT], bl[MT];
+          float gsc = 1.f;
+          if constexpr (GSC) {
+            float am = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) am = fmaxf(am, fmaxf(amax4(xa[m]), amax4(xb[m])));
+            if (gs.set ? __any(am * gs.s() >= 256.f) : __any(am > 0.f)) {
+              const int k0 = gs.k;
+              const bool was = gs.set;
+              gs.set_from(wave_umax(__float_as_uint(am)));
+              if (was && gs.k != k0) {
+                const float f = pow2i(gs.k - k0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                  for (int n = 0; n < NT; ++n) acc[m][n] *= f;
+              }
+            }
+            gsc = gs.s();
+          }
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const Split sa = split2<F16>(xa[m]), sb = split2<F16>(xb[m]);
+            const Split sa = split2<F16>(GSC ? xa[m] * gsc : xa[m]), sb = split2<F16>(GSC ? xb[m] * gsc : xb[m]);
             bh[m] = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
             bl[m] = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
           }
@@ -615,7 +660,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       const float* ref_r = a.relu_ref ? a.relu_ref + ro : nullptr;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        f32x4 v = acc[m][n];
+        f32x4 v = F16 ? acc[m][n] * (GSC ? winv * gs.inv() : winv) : acc[m][n];
         if (a.bias) v += ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq);
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const long o = goff(n, a.o_gpu, a.o_sU, a.o_sG);
@@ -2624,11 +2669,12 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         a.hgroups = imin(imax(g_b / a.To, 1), cdiv((long)a.Ho * a.nsub, 32));
         a.tiles = a.To * a.hgroups;
       }
-      if (conv_split_math(MODE == FWD_REP || MODE == FWD_S2) && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2)) {
+      const bool wide_f22 = (MODE == DGRAD_S2) && conv_f22_math();    // f16 pieces with the per-chunk gradient scale
+      if ((wide_f22 || conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2)) {
         const long lds2 = 2 * slab_bytes;
 #define LCS(NT_)                                                                                               \
   do {                                                                                                         \
-    auto kern = conv_wide_split_kernel<MODE, NT_>;                                                             \
+    auto kern = wide_f22 ? conv_wide_split_kernel<MODE, NT_, MODE == DGRAD_S2> : conv_wide_split_kernel<MODE, NT_>; \
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) \
       return idee::fail(IDEE_ERR_LAUNCH, "conv: cannot reserve %ld bytes of LDS", lds2);                         \
     const dim3 grid(one_round(a.tiles, a.B, 1), a.B);                                                          \

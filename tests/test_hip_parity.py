@@ -312,6 +312,64 @@ def test_proj_var_vs_oracle(T, H, W, monkeypatch, kernel_variant):
         gclose(n, a_.grad, b_.grad)
 
 
+@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows"])
+def test_conv_f22_error_against_float64(profile, monkeypatch):
+    """IDEE_CONV_MATH=f22 (3^3 replicate convs: forward, data gradient and weight gradient on two f16 pieces per operand; weights
+    prescaled per set, dy scaled by a power of two per work unit / per row) against a FLOAT64 evaluation of the oracle's
+    proj_var, beside the exact-f32 kernels and the bf16-piece backward (IDEE_CONV_MATH=split) on the same inputs.
+    `loss_scale`: upstream gradient 1e-7; `ragged_rows`: one magnitude per (n, v, t, h) row over 12 decades, two all-zero
+    frames (the data gradient's scale moves down inside a unit and rows are begun again; the weight gradient's accumulators
+    are rescaled in both directions).  Asserted: relative L2 error of y, dx and the four parameter gradients within 4x the
+    exact kernels' own error (+ 2e-7).  The case is ReLU-tie-free (float64 and f32 masks agree)."""
+    from oracle import idee_oracle as O
+    ops = _ops()
+    N, V, C, T, H, W = 2, 2, 16, 4, 21, 72
+
+    def build(seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn((N, V, T, H, W, C), generator=g)
+        r = torch.randn((N, V, T, H, W, C), generator=g)
+        if profile == "loss_scale":
+            r = r * 1e-7
+        else:
+            r = r * 10.0 ** (torch.rand((N, V, T, H, 1, 1), generator=g) * 12.0 - 11.0)
+            r[0, 0, 1] = 0.0
+            r[1, 1, 2] = 0.0
+        w1, w2 = (torch.randn((V, C, C, 3, 3, 3), generator=g) * 0.05 for _ in range(2))
+        b1, b2 = (torch.randn((V, C), generator=g) * 0.1 for _ in range(2))
+        leaves = [t.double().requires_grad_() for t in (x, w1, b1, w2, b2)]
+        outs = []
+        with relu_record() as rec:
+            for v in range(V):
+                sd = {"0.weight": leaves[1][v], "0.bias": leaves[2][v], "2.weight": leaves[3][v], "2.bias": leaves[4][v]}
+                outs.append(O.proj_var(leaves[0][:, v].permute(0, 4, 1, 2, 3), sd, "").permute(0, 2, 3, 4, 1))
+        return ((x, w1, b1, w2, b2), r, leaves, torch.stack(outs, 1)), rec
+
+    (x, w1, b1, w2, b2), r, leaves, y64 = tie_free_case(build, range(500, 508), f"proj_var f64 {profile}")
+    assert y64.dtype == torch.float64
+    (y64 * r.double()).sum().backward()
+    names = ("dx", "dw1", "db1", "dw2", "db2")
+    ref = {"y": y64.detach()}
+    ref.update({n: l.grad for n, l in zip(names, leaves)})
+
+    def run(mode):
+        monkeypatch.setenv("IDEE_CONV_MATH", mode)
+        dl = [t.to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
+        y = ops.ProjVar.apply(*dl)
+        (y * r.to(DEV)).sum().backward()
+        out = {"y": y.detach().cpu().double()}
+        out.update({n: t.grad.cpu().double() for n, t in zip(names, dl)})
+        assert all(bool(torch.isfinite(v).all()) for v in out.values()), mode
+        return out
+
+    res = {m: run(m) for m in ("f32", "f22", "split")}
+    print(f"\n[conv f22 vs float64, profile {profile}] relative L2 error: tensor  exact-f32  f22  split (f16 fwd / bf16 bwd)")
+    for k in ref:
+        e = {m: float((res[m][k] - ref[k]).norm() / ref[k].norm()) for m in res}
+        print(f"  {k:6s} {e['f32']:.2e}  {e['f22']:.2e}  {e['split']:.2e}")
+        assert e["f22"] <= 4.0 * e["f32"] + 2e-7, (k, e)
+
+
 @pytest.mark.parametrize("T,H,W", [(3, 5, 200), (8, 7, 40)])
 @variants('default', 'conv_split', 'conv_f22')
 def test_conv_ln_unit_vs_oracle(T, H, W, kernel_variant):
