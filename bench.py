@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")             # --math f32
+PMC_SUMMARY_F22 = os.path.join(ROOT, "profiles", "r03_pmc_traffic_f22.json")     # --math f22 (the default line)
 PMC_SUMMARY_BF16 = os.path.join(ROOT, "profiles", "r03_pmc_traffic_config4_bf16.json")
 
 CONFIGS = {
@@ -56,8 +57,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
     ap.add_argument("--hw", type=int, default=None, help="override grid height = width")
     ap.add_argument("--encoder", default=None, help="override the config's encoder")
-    ap.add_argument("--math", default="f32", choices=["f32", "split", "fwd22", "f22"],
-                    help="f32 (default): every GEMM-shaped kernel on the exact-f32 MFMA (the reference's arithmetic).  split: the "
+    ap.add_argument("--math", default="f22", choices=["f32", "split", "fwd22", "f22"],
+                    help="f22 (default; see below): f32 storage and accumulation, GEMM operands as two f16 pieces at f32 level.  With "
+                         "--dtype f32 the exact-f32 line is measured in the same run and printed beside it (`exact_f32`).  "
+                         "f32: every GEMM-shaped kernel on the exact-f32 MFMA (the reference's arithmetic, the library's own default).  split: the "
                          "opt-in two-piece split-precision kernels, convolutions (IDEE_CONV_MATH=split) AND Swin linear layers "
                          "(IDEE_SWIN_MATH=split) — a separately labelled line, never the headline.  fwd22: only the FORWARD passes on the "
                          "split kernels (f16 pieces: operand rounding 2^-22), every backward pass exact f32 — also a separate line.  f22: the Swin block's "
@@ -68,6 +71,7 @@ def parse():
                     help="activation storage between the fused units.  f32 (default): the reference's arithmetic.  bf16: BASELINE "
                          "config #4's precision — bf16 tokens, bf16 MFMA GEMMs / convolutions with f32 accumulate, f32 LFQ, losses, "
                          "master weights and optimizer (Swin_3D encoder)")
+    ap.add_argument("--no-exact-line", action="store_true", help="--math f22: skip the exact-f32 measurement printed beside the line")
     ap.add_argument("--codebook", default="LFQ", choices=["LFQ", "VQ"],
                     help="LFQ: what the reference's build.py wires.  VQ: the nearest-neighbour codebook of models/codebook/VQ.py in its "
                          "place (BASELINE config #4's '+ VQ codebook' variant line)")
@@ -346,8 +350,10 @@ def cpu_baseline(cfg, kind, model, T, H, W):
 
 def main():
     a = parse()
-    # the library reads these at every launch; child ranks inherit them.  The headline (--math f32) pins BOTH to the exact-f32
-    # kernels whatever the caller's environment holds, so the printed `dtype` / `math` always describe what ran.
+    if a.dtype == "bf16":
+        a.math = "f32"          # (the bf16 activation path has its own kernels; the f32-path switches are pinned to their defaults)
+    # the library reads these at every launch; child ranks inherit them.  BOTH switches are pinned to the chosen arithmetic
+    # whatever the caller's environment holds, so the printed `dtype` / `math` always describe what ran.
     os.environ["IDEE_CONV_MATH"] = a.math if a.math in ("split", "fwd22", "f22") else "f32"
     os.environ["IDEE_SWIN_MATH"] = a.math if a.math in ("split", "fwd22", "f22") else "f32"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -454,10 +460,12 @@ def main():
                     launches_per_step=n // a.steps, share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
     elif mfma_fams:
         k, (ms, n, fl, by) = mfma_fams[0]      # the entry point (all its shapes) with the largest total time in the timed region
-        traffic, src = pmc_traffic(k, n // a.steps, headline)
+        traffic, src = pmc_traffic(k, n // a.steps, headline and a.math in ("f32", "f22"), PMC_SUMMARY_F22 if a.math == "f22" else PMC_SUMMARY)
         # what actually limits the family (profiles/r03_sq_counters.txt): the convolution kernels are paced by the f32 MFMA pipe
         # (MFMA-busy ~80 %); the fused Swin kernels by VALU issue (LayerNorm / softmax / GELU share the issue slots with the f32
         # MFMA, which does not co-execute with VALU work on gfx950) — their peak is the same 157.3 TFLOP/s f32 vector rate
+        # (f22: the f16 MFMA overlaps the VALU stream, the Swin kernels stay VALU-issue bound; FLOPs are the reference
+        # formulation's, so `achieved` is an f32-equivalent rate against the f32 vector peak)
         bound = "valu" if k.startswith("idee_swin") else "mfma"
         roof = dict(kernel=k + " (all launches of this entry point in the step)", bound=bound, achieved=round(fl / ms / 1e9, 3),
                     peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
@@ -479,6 +487,24 @@ def main():
             fwd_ms_clip = (time.perf_counter() - f0) / 5 / batch * 1e3
         ts.model.train()
 
+    # ---- --math f22: the exact-f32 line of the same workload, measured in this run and printed beside the headline ----
+    exact = None
+    if a.math == "f22" and a.dtype == "f32" and world == 1 and not a.no_exact_line:
+        os.environ["IDEE_CONV_MATH"] = os.environ["IDEE_SWIN_MATH"] = "f32"      # read by the library at every launch
+        for _ in range(min(a.warmup, 5)):
+            ts.step(x, *masks)
+        barrier()
+        e0 = time.perf_counter()
+        for _ in range(a.steps):
+            ts.step(x, *masks)
+        barrier()
+        edt = time.perf_counter() - e0
+        os.environ["IDEE_CONV_MATH"] = os.environ["IDEE_SWIN_MATH"] = "f22"
+        exact = dict(value=round(batch * a.steps / edt, 3), unit="samples/s", ms_per_step=round(edt / a.steps * 1e3, 3), steps=a.steps,
+                     dtype="f32", math=math_label("f32", cfg, a.dtype),
+                     note="same process, model, batch and step count, IDEE_SWIN_MATH = IDEE_CONV_MATH = f32 (the library's default "
+                          "arithmetic: every GEMM-shaped kernel on the exact-f32 MFMA), timed after the headline region")
+
     if rank != 0:
         return
     out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * batch * a.steps / dt, 3),
@@ -498,7 +524,9 @@ def main():
                config=dict(workload=f"#{a.config}: {label}, V={cfg.in_channels_dynamic}, batch {batch}/GPU" +
                                     (f", grid overridden to {H}x{W}" if a.hw else ""), global_batch=world * batch,
                            parallelism=f"dp{world}"),
-               roofline=roof, fwd_ms_per_clip=None if a.no_fwd_eval else round(fwd_ms_clip, 3), peak_hbm_alloc_gb=round(torch.cuda.max_memory_allocated() / 1e9, 2))
+               exact_f32=exact, roofline=roof, fwd_ms_per_clip=None if a.no_fwd_eval else round(fwd_ms_clip, 3), peak_hbm_alloc_gb=round(torch.cuda.max_memory_allocated() / 1e9, 2))
+    if exact is None:
+        del out["exact_f32"]
     if world > 1:
         out["backend"] = torch.distributed.get_backend()
         out["ranks"] = ranks_report

@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/pmc_sq.sh [bench args...] > gpurun_out/<tag>_sq_counters.txt   (SQ counters per kernel, two passes)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT -d gpurun_out/pmc_sq -o s --output-format csv -- python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_sq.log 2>&1
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE -d gpurun_out/pmc_sq2 -o s --output-format csv -- python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_sq2.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT -d gpurun_out/pmc_sq -o s --output-format csv -- python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-fwd-eval --no-exact-line > gpurun_out/pmc_sq.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE -d gpurun_out/pmc_sq2 -o s --output-format csv -- python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-fwd-eval --no-exact-line > gpurun_out/pmc_sq2.log 2>&1
 python3 - <<PY
 import csv, collections, re
 for d in ("pmc_sq","pmc_sq2"):
