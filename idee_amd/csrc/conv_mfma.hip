@@ -2147,6 +2147,241 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad_wide_lds_kernel on f16 pieces at f32 level (IDEE_CONV_MATH=f22): the same work decomposition (a workgroup owns one
+// (batch item, t_out, kt) and a run of rows of one 64-pixel segment; the 9 GA (tap, input block) fragments dealt round-robin to
+// the 8 waves, every wave forming all GB output blocks for its fragments), K = 32 PIXELS per v_mfma_f32_16x16x32_f16 and three
+// piece products per tile: 126 MFMAs of 16 cycles per wave and 32 pixels where the f32 kernel issues 336 of 32.  The x rows and
+// the dy row live in LDS as pixel-major f16 piece images [pixel][block][16 ch hi | 16 ch lo] (64 B per pixel and block); BOTH
+// K = pixels operands come out of them with the transposing read (ds_read_b64_tr_b16: lane (channel i, group g) gets pixels
+// 8g..8g+7 of channel i).  x (activations, O(1)) is split unscaled; the dy row carries a power of two chosen per ROW for the whole
+// workgroup (largest |dy| of the row over all threads: wave max, LDS, barrier; common.h GradScale — every wave follows the same
+// sequence, so each rescales its own accumulators when the scale moves) and the flush multiplies by 2^-k.  The bias gradient is
+// summed from the unscaled f32 values in the staging threads' registers (a thread stages the same channel quads in every row).
+// ---------------------------------------------------------------------------------------------
+template <int GA, int GB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs a, int seg /*multiple of 32, <= 64*/, int nseg, int hrun,
+                                                                      int nhrun) {
+  constexpr int CI = 16 * GA, CO = 16 * GB;
+  // 32-bit words per pixel of the x / dy piece images: 16 per channel block + 8 of padding — with a stride of 96 words the 4
+  // pixels a 16-lane group of the transposing read touches fall on 2 bank groups (96 = 32 mod 64); 104 = 40 mod 64 spreads them
+  constexpr int PX = 16 * GA + 8, PY = 16 * GB + 8;
+  constexpr int NFRAG = 9 * GA;
+  constexpr int FPW = (NFRAG + WAVES - 1) / WAVES;
+  constexpr int NTH = 64 * WAVES;
+  constexpr int DYU = (64 * (CO / 4) + NTH - 1) / NTH;   // dy staging units (16 bytes) per thread and row
+  extern __shared__ __attribute__((aligned(16))) unsigned s_dynu[];
+  __shared__ unsigned s_red[WAVES];
+  const int rowlen = seg + 2;
+  unsigned* s_x = s_dynu;                            // [3][rowlen][PX]
+  unsigned* s_dy = s_dynu + 3 * rowlen * PX;         // [seg][PY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  typedef short s16x4t __attribute__((ext_vector_type(4)));
+  auto tr = [&](const unsigned* p) __attribute__((always_inline)) {
+    const s16x4t t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4t __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(unsigned long long, t);
+  };
+  auto pack2 = [](unsigned long long lo_, unsigned long long hi_) {
+    return u32x4{(unsigned)lo_, (unsigned)(lo_ >> 32), (unsigned)hi_, (unsigned)(hi_ >> 32)};
+  };
+
+  f32x4 acc[FPW][GB];
+  GradScale gs;
+#pragma unroll
+  for (int f = 0; f < FPW; ++f)
+#pragma unroll
+    for (int n = 0; n < GB; ++n) acc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient: unit i of a thread is the same (pixel, channel quad) of every row, so its partial sums stay in registers
+  f32x4 bsum[DYU];
+#pragma unroll
+  for (int i = 0; i < DYU; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kt = blockIdx.z % a.kt;
+  const int nys = a.CoutPad / CO;
+  const int xg0 = ((blockIdx.z / a.kt) / nys) * GA, yg0 = ((blockIdx.z / a.kt) % nys) * GB;
+  const bool do_bias = a.dbias && kt == 0 && xg0 == 0;
+  const int nb = a.B / a.wsets;
+  const long nchunks = (long)nb * a.To * nhrun * nseg;
+  // transposed-read word offset of this lane inside an image row block, pixel shift 0, hi piece
+  const int tr_px = 8 * kq + (r16 >> 2), tr_w = 2 * (r16 & 3);
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    long r = ch;
+    const int sg = (int)(r % nseg); r /= nseg;
+    const int hr = (int)(r % nhrun); r /= nhrun;
+    const int t = (int)(r % a.To);
+    const int b = (int)(r / a.To) * a.wsets + wset;
+    const int w0 = sg * seg;
+    const int nvalid = min(seg, a.W - w0);
+    const int ksteps = (nvalid + 31) >> 5;
+    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
+    const float* x_bt = a.x + (long)b * a.x_sB + (long)(a.kt * t + kt) * a.x_sT;
+    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
+    // x row hs -> registers (zeros outside the frame), registers -> piece image slot hs mod 3; dy row likewise.  The rows of the
+    // NEXT iteration are requested right before this iteration's MFMAs (a workgroup is alone on its CU: nothing else hides the
+    // memory latency between the barriers).
+    constexpr int XU = (66 * (CI / 4) + NTH - 1) / NTH;
+    auto load_x = [&](int hs, f32x4 (&xr)[XU]) __attribute__((always_inline)) {
+      const float* src = x_bt + (long)hs * a.x_sH;
+      const bool row_in = hs >= 0 && hs < a.H;
+#pragma unroll
+      for (int i = 0; i < XU; ++i) {
+        const int u = tid + i * NTH;
+        const int px = u / (CI / 4), q = u % (CI / 4);
+        const int w = w0 + px - 1;
+        const bool in = row_in && u < rowlen * (CI / 4) && w >= 0 && w < a.W;
+        xr[i] = in ? ld4(src + (long)w * a.x_sW + goff(xg0 + (q >> 2), a.x_gpu, a.x_sU, a.x_sG) + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto store_x = [&](int hs, const f32x4 (&xr)[XU]) __attribute__((always_inline)) {
+      unsigned* dst = s_x + (long)(((hs % 3) + 3) % 3) * rowlen * PX;
+#pragma unroll
+      for (int i = 0; i < XU; ++i) {
+        const int u = tid + i * NTH;
+        if (u >= rowlen * (CI / 4)) continue;
+        const int px = u / (CI / 4), q = u % (CI / 4);
+        const Split p = split2<PM_F16X2>(xr[i]);
+        unsigned* d = dst + px * PX + (q >> 2) * 16 + (q & 3) * 2;
+        *reinterpret_cast<u32x2v*>(d) = u32x2v{p.h01, p.h23};
+        *reinterpret_cast<u32x2v*>(d + 8) = u32x2v{p.l01, p.l23};
+      }
+    };
+    auto load_dy = [&](int h, f32x4 (&dv)[DYU]) __attribute__((always_inline)) {
+      const float* src = dy_b + (long)h * a.y_sH;
+#pragma unroll
+      for (int i = 0; i < DYU; ++i) {
+        const int u = tid + i * NTH;
+        const int px = u / (CO / 4), q = u % (CO / 4);
+        const int w = w0 + px;
+        const bool in = h < a.H && u < seg * (CO / 4) && w < a.W;
+        dv[i] = in ? ld4(src + (long)w * a.y_sW + goff(yg0 + (q >> 2), a.y_gpu, a.y_sU, a.y_sG) + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    f32x4 xr[XU], dv[DYU];
+    {   // unit start: rows h0 - 1 and h0 straight into the ring, row h0 + 1 and dy row h0 into the staging registers
+      __syncthreads();                               // the previous unit's readers are done
+      load_x(h0 - 1, xr); store_x(h0 - 1, xr);
+      load_x(h0, xr);     store_x(h0, xr);
+      load_x(h0 + 1, xr);
+      load_dy(h0, dv);
+    }
+    // the row's largest |dy| goes to s_red right after the MFMAs of the row before (its loads have landed by then), so ONE
+    // barrier both retires the previous row's readers and publishes it: two barriers per row
+    auto post_amax = [&]() __attribute__((always_inline)) {
+      float am = 0.f;
+#pragma unroll
+      for (int i = 0; i < DYU; ++i) am = fmaxf(am, amax4(dv[i]));
+      const unsigned wm = wave_umax(__float_as_uint(am));
+      if (lane == 0) s_red[wave] = wm;
+    };
+    post_amax();
+    for (int h = h0; h < h1; ++h) {
+      __syncthreads();                               // the previous row's readers are done; s_red holds this row's maxima
+      int slot_of[3];
+      bool ok_h[3];
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const int hs = h + oh - 1;
+        ok_h[oh] = hs >= 0 && hs < a.H;
+        slot_of[oh] = ((hs % 3) + 3) % 3;
+      }
+      store_x(h + 1, xr);                            // (row h + 1 replaces row h - 2 in the ring)
+      {
+        unsigned m = 0u;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) m = m > s_red[w] ? m : s_red[w];
+        const float f = gs.update(m);
+        if (f != 1.f) {
+#pragma unroll
+          for (int ff = 0; ff < FPW; ++ff)
+#pragma unroll
+            for (int n = 0; n < GB; ++n) acc[ff][n] *= f;
+        }
+        const float gsc = gs.s();
+#pragma unroll
+        for (int i = 0; i < DYU; ++i) {
+          const int u = tid + i * NTH;
+          if (u >= seg * (CO / 4)) continue;
+          const int px = u / (CO / 4), q = u % (CO / 4);
+          bsum[i] += dv[i];                       // (unit i of this thread is channel quad (tid + i NTH) % (CO / 4) in every row)
+          const Split p = split2<PM_F16X2>(dv[i] * gsc);
+          unsigned* d = s_dy + px * PY + (q >> 2) * 16 + (q & 3) * 2;
+          *reinterpret_cast<u32x2v*>(d) = u32x2v{p.h01, p.h23};
+          *reinterpret_cast<u32x2v*>(d + 8) = u32x2v{p.l01, p.l23};
+        }
+      }
+      __syncthreads();
+      if (h + 1 < h1) { load_x(h + 2, xr); load_dy(h + 1, dv); }     // next iteration's rows, in flight under the MFMAs below
+
+      const unsigned* abase[FPW];
+      bool okf[FPW];
+#pragma unroll
+      for (int f = 0; f < FPW; ++f) {
+        const int fr = wave + f * WAVES;            // fragment id = tap9 * GA + ga
+        const int tap9 = fr / GA, ga = fr % GA;
+        const int oh = (tap9 / 3) % 3, ow = tap9 % 3;
+        okf[f] = fr < NFRAG && ok_h[oh];
+        abase[f] = s_x + ((long)slot_of[oh] * rowlen + ow + tr_px) * PX + ga * 16 + tr_w;
+      }
+      const unsigned* bbase = s_dy + tr_px * PY + tr_w;
+      // (the output blocks in passes of at most 3: 168 accumulator registers leave room for 3 B fragment pairs, not 6; the A
+      //  fragments are read once per pass)
+      constexpr int NBP = GB > 3 ? 3 : GB;
+      for (int s = 0; s < ksteps; ++s) {
+#pragma unroll
+        for (int n0 = 0; n0 < GB; n0 += NBP) {
+          u32x4 Bh[NBP], Bl[NBP];
+#pragma unroll
+          for (int n = 0; n < NBP; ++n) {
+            const unsigned* bp = bbase + (long)(32 * s) * PY + (n0 + n) * 16;
+            Bh[n] = pack2(tr(bp), tr(bp + 4 * PY));
+            Bl[n] = pack2(tr(bp + 8), tr(bp + 4 * PY + 8));
+          }
+#pragma unroll
+          for (int f = 0; f < FPW; ++f) {
+            if (!okf[f]) continue;
+            const unsigned* ap = abase[f] + (long)(32 * s) * PX;
+            const u32x4 Ah = pack2(tr(ap), tr(ap + 4 * PX)), Al = pack2(tr(ap + 8), tr(ap + 4 * PX + 8));
+#pragma unroll
+            for (int n = 0; n < NBP; ++n) {
+              acc[f][n0 + n] = mfma_s<PM_F16X2>(Ah, Bh[n], acc[f][n0 + n]);
+              acc[f][n0 + n] = mfma_s<PM_F16X2>(Ah, Bl[n], acc[f][n0 + n]);
+              acc[f][n0 + n] = mfma_s<PM_F16X2>(Al, Bh[n], acc[f][n0 + n]);
+            }
+          }
+        }
+      }
+      if (h + 1 < h1) post_amax();
+    }
+  }
+  float* dw = a.dwp + (long)wset * a.ntaps * a.Cin * a.CoutPad;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+  const float un = gs.inv();
+#pragma unroll
+  for (int f = 0; f < FPW; ++f) {
+    const int fr = wave + f * WAVES;
+    if (fr >= NFRAG) continue;
+    const int tap = kt * 9 + fr / GA, ga = fr % GA;
+#pragma unroll
+    for (int n = 0; n < GB; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(dw + ((long)tap * a.Cin + 16 * (xg0 + ga) + r0 + r) * a.CoutPad + 16 * (yg0 + n) + col, acc[f][n][r] * un);
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < DYU; ++i) {
+      const int u = tid + i * NTH;
+      if (u >= seg * (CO / 4)) continue;
+      const int q = u % (CO / 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(a.dbias + (long)wset * a.CoutPad + 16 * yg0 + 4 * q + r, bsum[i][r]);
+    }
+  }
+}
+
 // the replicate-mode data gradient accumulates its two edge columns (w = 0, W-1) with atomics: they start from zero,
 // or from the addend's edge columns
 __global__ void init_w_edges_kernel(float* __restrict__ dx, const float* __restrict__ addend, int B, int T, int H, int W, int Cin,
@@ -2953,6 +3188,31 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
       return idee::fail(IDEE_ERR_LAUNCH, "conv_wgrad: cannot reserve %zu bytes of LDS", lds);                          \
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_), lds, st, a, seg, nseg, hrun, nhrun);                            \
   } while (0)
+    if (conv_f22_math() && Ga == Gb && (ga_k == 6 || Ga == 3 || Ga == 2) && !bf) {
+      // f16 pieces at f32 level: 32- or 64-pixel segments (K = 32 pixels per MFMA), piece images of 64 B per pixel and channel
+      // block.  6 x 6 blocks run as two 6 x 3 halves (84 accumulator registers instead of 168).  (32-pixel segments — 49 KB of LDS,
+      // more workgroups per CU — measured slower, 1.26 vs 0.93 ms: the per-row barriers and latencies dominate, not the MFMAs)
+      const int gb2 = ga_k == 6 ? 3 : gb_k, nsubz2 = (Ga / ga_k) * (Gb / gb2);
+      int seg2 = 64;
+      if (const char* e = getenv("IDEE_WGRAD_WIDE_SEG")) { const int v = atoi(e); if (v == 32 || v == 64) seg2 = v; }   // (test / tuning knob)
+      const int nseg2 = cdiv(d->W, seg2);
+      int hrun2 = d->H;
+      while (hrun2 > 8 && btk * cdiv(d->H, hrun2) * nseg2 * d->wsets * nsubz2 < 6L * kCUs) hrun2 = (hrun2 + 1) / 2;
+      const int nhrun2 = cdiv(d->H, hrun2);
+      const long nchunks2 = (long)(d->B / d->wsets) * a.To * nhrun2 * nseg2;
+      const size_t lds2 = (size_t)(3L * (seg2 + 2) * (16 * ga_k + 8) + (long)seg2 * (16 * gb2 + 8)) * 4;
+      const int wgcu = imax(1, imin(3, (int)(150 * 1024 / (lds2 + 64))));
+      const dim3 grid2(one_round(nchunks2, (long)a.kt * d->wsets * nsubz2, wgcu), d->wsets, a.kt * nsubz2);
+#define LWS(GA_, GB_)                                                                                                 \
+  do {                                                                                                                \
+    auto kern = wgrad_wide_split_kernel<GA_, GB_, 8>;                                                                 \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)  \
+      return idee::fail(IDEE_ERR_LAUNCH, "conv_wgrad: cannot reserve %zu bytes of LDS", lds2);                         \
+    hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, st, a, seg2, nseg2, hrun2, nhrun2);                              \
+  } while (0)
+      if (ga_k == 6) LWS(6, 3); else if (Ga == 3) LWS(3, 3); else LWS(2, 2);
+#undef LWS
+    } else
     // 16 input channels (the sign field): one tap per wave, 9 waves
     if (Ga == 1) { if (Gb == 6) LWW(1, 6, 9); else if (Gb == 3) LWW(1, 3, 9); else LWW(1, 2, 9); }
     else if (ga_k == 6) LWW(6, 6, 8); else if (Ga == 3) LWW(3, 3, 8); else LWW(2, 2, 8);
