@@ -1871,20 +1871,27 @@ __global__ __launch_bounds__(256, 2) void wgrad16_glds_kernel(WgradArgs a, int n
 // F16 (IDEE_CONV_MATH=f22): f16 pieces; the dy row of every output row (16 channels x 32 pixels, in registers) is multiplied by
 // a power of two kept per wave with common.h GradScale — the row's largest |dy| 2^k in [2^1, 2^8), the 9 TSL tap accumulators
 // multiplied along when k moves, by 2^-k at the flush; x (activations, O(1)) is split unscaled as in the forward kernels.
-template <int MODE /*FWD_REP | FWD_S2*/, int TSL, bool F16 = false>
+// NB output blocks per wave (blockIdx.z picks the group; 16 input channels): NB = 3 for the (1,3,3) sign-field convs 16 -> 48 k.
+template <int MODE /*FWD_REP | FWD_S2*/, int TSL, bool F16 = false, int NB = 1>
 __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
   constexpr int NTAPS = TSL * 9;
+  static_assert(NTAPS * NB <= 27, "accumulator tiles must fit the register file");
+  const int gb0 = blockIdx.z * NB;                 // first output block of this workgroup (one input block: Cin = 16)
   constexpr int ROWW = kC16Row * 16;              // 32-bit words per staged row: 34 pixels x (8 words hi + 8 words lo)
   __shared__ __attribute__((aligned(16))) unsigned s_xw[4][TSL * 3 * ROWW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
   unsigned* s_x = s_xw[wave];
-  f32x4 acc[NTAPS];
-  float bsum = 0.f;
+  f32x4 acc[NTAPS][NB];
+  float bsum[NB];
   GradScale gs;
 #pragma unroll
-  for (int tp = 0; tp < NTAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < NB; ++n) {
+    bsum[n] = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < NTAPS; ++tp) acc[tp][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int nsub = (a.W + 15) / 16;
   const int nb = a.B / a.wsets;
   const long nunits = (long)nb * a.To * nhrun * nstrip;
@@ -1917,26 +1924,39 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
     for (int h = h0; h < h1; ++h) {
       wave_fence();
       // dy of this row: lane (cout = r16, pixels p0 + 8 kq + {0..7}); pixels past the row end contribute zero
-      f32x4 d0, d1;
+      f32x4 d0[NB], d1[NB];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const int p = p0 + 8 * kq + jj;
-        const bool on = 8 * kq + jj < 16 * my_sub && p < a.W;
-        const float v = on ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW + goff(0, a.y_gpu, a.y_sU, a.y_sG) + r16] : 0.f;
-        if (jj < 4) d0[jj] = v; else d1[jj - 4] = v;
-        bsum += v;
-      }
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int p = p0 + 8 * kq + jj;
+          const bool on = 8 * kq + jj < 16 * my_sub && p < a.W;
+          const float v = on ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW + goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16] : 0.f;
+          if (jj < 4) d0[n][jj] = v; else d1[n][jj - 4] = v;
+          bsum[n] += v;
+        }
       if constexpr (F16) {
-        const float f = gs.update(wave_umax(__float_as_uint(fmaxf(amax4(d0), amax4(d1)))));
+        float am = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) am = fmaxf(am, fmaxf(amax4(d0[n]), amax4(d1[n])));
+        const float f = gs.update(wave_umax(__float_as_uint(am)));
         if (f != 1.f) {
 #pragma unroll
-          for (int tp = 0; tp < NTAPS; ++tp) acc[tp] *= f;
+          for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[tp][n] *= f;
         }
         const float gsc = gs.s();
-        d0 *= gsc; d1 *= gsc;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) { d0[n] *= gsc; d1[n] *= gsc; }
       }
-      const Split s0 = split2<F16>(d0), s1 = split2<F16>(d1);
-      const u32x4 Bh = {s0.h01, s0.h23, s1.h01, s1.h23}, Bl = {s0.l01, s0.l23, s1.l01, s1.l23};
+      u32x4 Bh[NB], Bl[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const Split s0 = split2<F16>(d0[n]), s1 = split2<F16>(d1[n]);
+        Bh[n] = u32x4{s0.h01, s0.h23, s1.h01, s1.h23};
+        Bl[n] = u32x4{s0.l01, s0.l23, s1.l01, s1.l23};
+      }
       int slot_of[3];
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) {
@@ -1991,9 +2011,12 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
             const u32x4 Ah = {(unsigned)h0_, (unsigned)(h0_ >> 32), (unsigned)h1_, (unsigned)(h1_ >> 32)};
             const u32x4 Al = {(unsigned)l0_, (unsigned)(l0_ >> 32), (unsigned)l1_, (unsigned)(l1_ >> 32)};
             const int tp = (ot * 3 + oh) * 3 + ow;
-            acc[tp] = mfma_s<F16>(Ah, Bh, acc[tp]);
-            acc[tp] = mfma_s<F16>(Ah, Bl, acc[tp]);
-            acc[tp] = mfma_s<F16>(Al, Bh, acc[tp]);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+              acc[tp][n] = mfma_s<F16>(Ah, Bh[n], acc[tp][n]);
+              acc[tp][n] = mfma_s<F16>(Ah, Bl[n], acc[tp][n]);
+              acc[tp][n] = mfma_s<F16>(Al, Bh[n], acc[tp][n]);
+            }
           }
     }
   }
@@ -2003,12 +2026,18 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
 #pragma unroll
   for (int tp = 0; tp < NTAPS; ++tp)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + col, F16 ? acc[tp][r] * un : acc[tp][r]);
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + (gb0 + n) * 16 + col, F16 ? acc[tp][n][r] * un : acc[tp][n][r]);
   if (a.dbias) {
-    float v = bsum;
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + lane, v);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      float v = bsum[n];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + (gb0 + n) * 16 + lane, v);
+    }
   }
 }
 
@@ -3141,7 +3170,9 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
   } while (0)
     const bool split = conv_split_math(false) && Gb == 1 && Ga == 1;
     const bool f22 = conv_f22_math() && Gb == 1 && Ga == 1;
-    if (rep && f22) LSTRIP((wgrad16_split_kernel<FWD_REP, 3, true>));
+    const bool f22_k133 = conv_f22_math() && Ga == 1 && d->mode == IDEE_CONV_K133_ZERO && Gb > 1 && Gb % 3 == 0 && !bf;
+    if (f22_k133) LSTRIP((wgrad16_split_kernel<FWD_S2, 1, true, 3>));     // the sign-field convs 16 -> 48 k (gz = Gb / 3 groups)
+    else if (rep && f22) LSTRIP((wgrad16_split_kernel<FWD_REP, 3, true>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO && f22) LSTRIP((wgrad16_split_kernel<FWD_S2, 2, true>));
     else if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
     else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSTRIP((wgrad16_split_kernel<FWD_S2, 2>));
