@@ -251,10 +251,10 @@ def math_label(math, cfg, dtype="f32"):
             d["swin_gemm"] = ("forward: two f16 pieces per operand, all 4 piece products, f32 accumulate (operand rounding 2^-22), attention "
                               "scores on the f32 MFMA; backward: exact f32 MFMA")
             if math == "f22":
-                d["conv"] = ("forward of the 16->16 and 96-wide convs and the 16->16 data / weight gradients: two f16 pieces per operand, 3 piece "
-                             "products; weights prescaled by a power of two per set, dy scaled by a power of two per work unit (data "
-                             "gradient: 32 pixels x a run of rows, the scale only moving down) / per 32-pixel row (weight gradient, "
-                             "accumulators rescaled along); the 96-wide and (1,3,3) gradient kernels exact f32 MFMA")
+                d["conv"] = ("16->16 and 96-wide convs, forward, data gradient and weight gradient, and the (1,3,3) weight gradient: two f16 "
+                             "pieces per operand, 3 piece products; weights prescaled by a power of two per set, dy scaled by a power of two "
+                             "per work unit / chunk (data gradients, the scale only moving down) or per row (weight gradients, accumulators "
+                             "rescaled along); forward and data gradient of the (1,3,3) sign-field convs and the Cout = 1 convs exact f32")
                 d["swin_gemm"] = ("forward and backward: two f16 pieces per operand, all 4 piece products, f32 accumulate; weight tensors "
                                   "prescaled by a power of two per tensor (largest |w| in [2^6, 2^7)), the incoming gradient scaled by a "
                                   "power of two per 32-token work item (largest |dy| in [2^1, 2^8)): operand rounding max(2^-22 |x|, "
@@ -513,9 +513,9 @@ def main():
                dtype=("bf16" if a.dtype == "bf16" else "f32" if a.math == "f32" else
                       "f32 storage/accumulate; forward convolutions and Swin linear layers on two-piece f16 split MFMAs (operand rounding "
                       "2^-22), every backward pass exact f32" if a.math == "fwd22" else
-                      "f32 storage/accumulate; Swin linear layers (forward and backward), forward convolutions and the 16->16 convolution "
-                      "gradients on two-piece f16 split MFMAs at f32 level (operand rounding 2^-22: power-of-two prescaled weights, "
-                      "per-tile power-of-two gradient scales); the other convolution gradients exact f32"
+                      "f32 storage and accumulation; GEMM operands as two f16 pieces at f32 level (operand rounding 2^-22: weights prescaled by "
+                      "exact powers of two per tensor, gradients per tile) in the Swin block and the 16->16 / 96-wide convolutions, all passes; "
+                      "attention scores, the (1,3,3) forward / data gradient and the Cout = 1 convolutions exact f32 (see `math`, `exact_f32`)"
                       if a.math == "f22" else
                       "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs"),
                math=math_label(a.math, cfg, a.dtype),
