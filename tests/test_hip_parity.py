@@ -370,6 +370,70 @@ def test_conv_f22_error_against_float64(profile, monkeypatch):
         assert e["f22"] <= 4.0 * e["f32"] + 2e-7, (k, e)
 
 
+@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows"])
+def test_classifier_f22_error_against_float64(profile, monkeypatch):
+    """The classifier on z_q (plain path) at V = 6: the 96 -> 96 joint head — conv_wide_split_kernel forward / data gradient and
+    wgrad_wide_split_kernel (two 6 x 3 block halves, workgroup-wide row scale) — and the heads' 16 -> 16 (2,3,3) convs under
+    IDEE_CONV_MATH=f22, against the oracle's classifier evaluated in FLOAT64, beside the exact-f32 kernels on the same inputs.
+    Asserted: relative L2 error of the logits, dx and every parameter gradient within 4x the exact kernels' (+ 2e-7).  Tie-free case."""
+    from oracle import idee_oracle as O
+    from idee_amd.models.classifier.CNN_3D import CNN_3D
+    N, V, E, T, H, W = 2, 6, 16, 8, 6, 72
+
+    def build(seed):
+        torch.manual_seed(seed)
+        c = CNN_3D(in_var=V, embed_dim=E, dim=E, drop_rate=0.0)
+        sd = {k: v.clone() for k, v in c.state_dict().items()}
+        x = torch.randn(N, V, E, T, H, W)
+        rz, ry = torch.randn(N, 1, H, W), torch.randn(V, N, 1, H, W)
+        if profile == "loss_scale":
+            rz, ry = rz * 1e-7, ry * 1e-7
+        else:
+            mag = 10.0 ** (torch.rand(N, 1, H, 1) * 12.0 - 11.0)
+            rz, ry = rz * mag, ry * mag
+        sdl = {k: v.double().requires_grad_() for k, v in sd.items()}
+        xo = x.double().requires_grad_()
+        with relu_record() as rec:
+            zo, yo = O.classifier(xo, sdl, pre="")
+        return (c, sd, x, rz, ry, sdl, xo, zo, yo), rec
+
+    c, sd, x, rz, ry, sdl, xo, zo, yo = tie_free_case(build, range(900, 912), f"classifier f64 {profile}")
+    assert zo.dtype == torch.float64
+    ((zo * rz.double()).sum() + sum((yo[v] * ry[v].double()).sum() for v in range(V))).backward()
+    ref = {"z": zo.detach(), "y": torch.stack(yo).detach(), "dx": xo.grad}
+    ref.update({"d" + k: sdl[k].grad for k in sd})
+    c = c.to(DEV)
+
+    def run(mode):
+        monkeypatch.setenv("IDEE_CONV_MATH", mode)
+        for p_ in c.parameters():
+            p_.grad = None
+        xd = x.to(DEV).requires_grad_()
+        z, y = c(xd)
+        ((z * rz.to(DEV)).sum() + sum((y[v] * ry[v].to(DEV)).sum() for v in range(V))).backward()
+        out = {"z": z.detach().cpu().double(), "y": torch.stack(y).detach().cpu().double(), "dx": xd.grad.cpu().double()}
+        named = dict(c.named_parameters())
+        for key, name, idx in c._key_map():
+            g = named[name].grad
+            out["d" + key] = (g if idx is None else g[idx]).detach().cpu().double().reshape(ref["d" + key].shape)
+        assert all(bool(torch.isfinite(v).all()) for v in out.values()), mode
+        return out
+
+    res = {m: run(m) for m in ("f32", "f22")}
+    worst = (0.0, None)
+    print(f"\n[classifier f22 vs float64, profile {profile}] relative L2 error: tensor  exact-f32  f22")
+    for k in ref:
+        e = {m: float((res[m][k] - ref[k]).norm() / ref[k].norm().clamp_min(1e-300)) for m in res}
+        if k in ("z", "y", "dx") or e["f22"] > worst[0]:
+            print(f"  {k:40s} {e['f32']:.2e}  {e['f22']:.2e}")
+        worst = max(worst, (e["f22"], k))
+        if ref[k].numel() == 1:      # conv3.bias: ONE atomically accumulated f32 sum over 12 decades of signed terms, computed by the
+            assert e["f22"] <= 1e-5, (k, e)      # same exact streaming kernel in both modes — its error is summation-order noise
+            continue
+        assert e["f22"] <= 4.0 * e["f32"] + 2e-7, (k, e)
+    print(f"  worst f22 tensor: {worst[1]} {worst[0]:.2e} ({len(ref)} tensors)")
+
+
 @pytest.mark.parametrize("T,H,W", [(3, 5, 200), (8, 7, 40)])
 @variants('default', 'conv_split', 'conv_f22')
 def test_conv_ln_unit_vs_oracle(T, H, W, kernel_variant):
