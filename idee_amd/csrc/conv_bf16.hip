@@ -1401,6 +1401,7 @@ int bf16_wgrad(const idee_conv_desc* d, const void* x, const void* dy, float* dw
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.x = (const float*)x; a.dy = (const float*)dy; a.dwp = dw_packed; a.dbias = dbias;
+  a.copy_stride = 0;      // (these kernels flush into copy 0)
   a.B = d->B; a.wsets = d->wsets; a.T = d->T; a.H = d->H; a.W = d->W; a.To = out_T(d);
   a.Cin = d->Cin; a.CoutPad = ((d->Cout + 15) / 16) * 16; a.cout_real = d->Cout; a.ntaps = n_taps(d); a.kt = mode_kt(d);
   a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;

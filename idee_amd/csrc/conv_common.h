@@ -77,10 +77,18 @@ __device__ __forceinline__ int src_w(int o, int p, int Wi, bool& ok) {
   return q;
 }
 
+// The packed weight-gradient buffer holds kWgradCopies partial copies of (wsets, ntaps, Cin, CoutPad): a workgroup may flush
+// its register accumulators into copy blockIdx.x % kWgradCopies, idee_conv_unpack_wgrad sums the copies.  Measured on the
+// 96 -> 96 weight gradient with 8 copies: NO gain (0.691 ms either way) — the tile flush (11 M float atomics onto 166 k
+// addresses, 64 workgroups per address) is not what was slow; what was, 0.29 of 0.69 ms, were 4,096 per-thread atomics per
+// workgroup onto the 48 bias-gradient addresses (now reduced in LDS first).  Hence ONE copy; the mechanism stays for shapes
+// where few addresses take many flushes.
+constexpr int kWgradCopies = 1;
 struct WgradArgs {
   const float* x;
   const float* dy;
-  float* dwp;     // (wsets, ntaps, Cin, CoutPad)
+  float* dwp;     // kWgradCopies x (wsets, ntaps, Cin, CoutPad); kernels that do not spread their flush use copy 0
+  long copy_stride;   // floats per copy
   float* dbias;   // (wsets, CoutPad) or null
   int B, wsets;
   int T, H, W;    // x extent

@@ -2020,7 +2020,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
           }
     }
   }
-  float* dw = a.dwp + (long)wset * NTAPS * 16 * a.CoutPad;
+  float* dw = a.dwp + (long)(blockIdx.x % kWgradCopies) * a.copy_stride + (long)wset * NTAPS * 16 * a.CoutPad;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
   const float un = F16 ? gs.inv() : 1.f;
 #pragma unroll
@@ -2201,6 +2201,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
   constexpr int DYU = (64 * (CO / 4) + NTH - 1) / NTH;   // dy staging units (16 bytes) per thread and row
   extern __shared__ __attribute__((aligned(16))) unsigned s_dynu[];
   __shared__ unsigned s_red[WAVES];
+  __shared__ float s_bs[CO];
   const int rowlen = seg + 2;
   unsigned* s_x = s_dynu;                            // [3][rowlen][PX]
   unsigned* s_dy = s_dynu + 3 * rowlen * PX;         // [seg][PY]
@@ -2252,27 +2253,41 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
     // NEXT iteration are requested right before this iteration's MFMAs (a workgroup is alone on its CU: nothing else hides the
     // memory latency between the barriers).
     constexpr int XU = (66 * (CI / 4) + NTH - 1) / NTH;
+    // per-thread staging units: their in-row source offsets (elements; -1 = outside the frame or past the row) and LDS word
+    // offsets are the same for every row of the chunk — computed once (the per-row index arithmetic, with its divisions by the
+    // run-time channel-group layout, was ~1,800 instructions per row and wave: most of this kernel's time)
+    int xo[XU], xd[XU], yo[DYU], yd[DYU];
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      const int u = tid + i * NTH;
+      const int px = u / (CI / 4), q = u % (CI / 4);
+      const int w = w0 + px - 1;
+      const bool st_ = u < rowlen * (CI / 4);
+      xd[i] = st_ ? px * PX + (q >> 2) * 16 + (q & 3) * 2 : -1;
+      xo[i] = (st_ && w >= 0 && w < a.W) ? (int)((long)w * a.x_sW + goff(xg0 + (q >> 2), a.x_gpu, a.x_sU, a.x_sG) + 4 * (q & 3)) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < DYU; ++i) {
+      const int u = tid + i * NTH;
+      const int px = u / (CO / 4), q = u % (CO / 4);
+      const int w = w0 + px;
+      const bool st_ = u < seg * (CO / 4);
+      yd[i] = st_ ? px * PY + (q >> 2) * 16 + (q & 3) * 2 : -1;
+      yo[i] = (st_ && w < a.W) ? (int)((long)w * a.y_sW + goff(yg0 + (q >> 2), a.y_gpu, a.y_sU, a.y_sG) + 4 * (q & 3)) : -1;
+    }
     auto load_x = [&](int hs, f32x4 (&xr)[XU]) __attribute__((always_inline)) {
       const float* src = x_bt + (long)hs * a.x_sH;
       const bool row_in = hs >= 0 && hs < a.H;
 #pragma unroll
-      for (int i = 0; i < XU; ++i) {
-        const int u = tid + i * NTH;
-        const int px = u / (CI / 4), q = u % (CI / 4);
-        const int w = w0 + px - 1;
-        const bool in = row_in && u < rowlen * (CI / 4) && w >= 0 && w < a.W;
-        xr[i] = in ? ld4(src + (long)w * a.x_sW + goff(xg0 + (q >> 2), a.x_gpu, a.x_sU, a.x_sG) + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int i = 0; i < XU; ++i) xr[i] = (row_in && xo[i] >= 0) ? ld4(src + xo[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto store_x = [&](int hs, const f32x4 (&xr)[XU]) __attribute__((always_inline)) {
       unsigned* dst = s_x + (long)(((hs % 3) + 3) % 3) * rowlen * PX;
 #pragma unroll
       for (int i = 0; i < XU; ++i) {
-        const int u = tid + i * NTH;
-        if (u >= rowlen * (CI / 4)) continue;
-        const int px = u / (CI / 4), q = u % (CI / 4);
+        if (xd[i] < 0) continue;
         const Split p = split2<PM_F16X2>(xr[i]);
-        unsigned* d = dst + px * PX + (q >> 2) * 16 + (q & 3) * 2;
+        unsigned* d = dst + xd[i];
         *reinterpret_cast<u32x2v*>(d) = u32x2v{p.h01, p.h23};
         *reinterpret_cast<u32x2v*>(d + 8) = u32x2v{p.l01, p.l23};
       }
@@ -2280,21 +2295,18 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
     auto load_dy = [&](int h, f32x4 (&dv)[DYU]) __attribute__((always_inline)) {
       const float* src = dy_b + (long)h * a.y_sH;
 #pragma unroll
-      for (int i = 0; i < DYU; ++i) {
-        const int u = tid + i * NTH;
-        const int px = u / (CO / 4), q = u % (CO / 4);
-        const int w = w0 + px;
-        const bool in = h < a.H && u < seg * (CO / 4) && w < a.W;
-        dv[i] = in ? ld4(src + (long)w * a.y_sW + goff(yg0 + (q >> 2), a.y_gpu, a.y_sU, a.y_sG) + 4 * (q & 3)) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int i = 0; i < DYU; ++i) dv[i] = (h < a.H && yo[i] >= 0) ? ld4(src + yo[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    f32x4 xr[XU], dv[DYU];
-    {   // unit start: rows h0 - 1 and h0 straight into the ring, row h0 + 1 and dy row h0 into the staging registers
+    // staging registers, TWO rows deep: (xr, dv) = x row h + 1 and dy row h for the top of iteration h, (xr2, dv2) the pair for
+    // iteration h + 1, requested a full iteration before they are needed (one row deep, a row's loads had only the ~1 us of its
+    // MFMA loop to land before the row maximum needed them: 0.67 -> see DESIGN ms)
+    f32x4 xr[XU], dv[DYU], xr2[XU], dv2[DYU];
+    {   // unit start: rows h0 - 1 and h0 straight into the ring
       __syncthreads();                               // the previous unit's readers are done
       load_x(h0 - 1, xr); store_x(h0 - 1, xr);
       load_x(h0, xr);     store_x(h0, xr);
-      load_x(h0 + 1, xr);
-      load_dy(h0, dv);
+      load_x(h0 + 1, xr);  load_dy(h0, dv);
+      load_x(h0 + 2, xr2); load_dy(h0 + 1, dv2);
     }
     // the row's largest |dy| goes to s_red right after the MFMAs of the row before (its loads have landed by then), so ONE
     // barrier both retires the previous row's readers and publishes it: two barriers per row
@@ -2331,18 +2343,20 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
         const float gsc = gs.s();
 #pragma unroll
         for (int i = 0; i < DYU; ++i) {
-          const int u = tid + i * NTH;
-          if (u >= seg * (CO / 4)) continue;
-          const int px = u / (CO / 4), q = u % (CO / 4);
+          if (yd[i] < 0) continue;
           bsum[i] += dv[i];                       // (unit i of this thread is channel quad (tid + i NTH) % (CO / 4) in every row)
           const Split p = split2<PM_F16X2>(dv[i] * gsc);
-          unsigned* d = s_dy + px * PY + (q >> 2) * 16 + (q & 3) * 2;
+          unsigned* d = s_dy + yd[i];
           *reinterpret_cast<u32x2v*>(d) = u32x2v{p.h01, p.h23};
           *reinterpret_cast<u32x2v*>(d + 8) = u32x2v{p.l01, p.l23};
         }
       }
       __syncthreads();
-      if (h + 1 < h1) { load_x(h + 2, xr); load_dy(h + 1, dv); }     // next iteration's rows, in flight under the MFMAs below
+#pragma unroll
+      for (int i = 0; i < XU; ++i) xr[i] = xr2[i];
+#pragma unroll
+      for (int i = 0; i < DYU; ++i) dv[i] = dv2[i];
+      if (h + 2 < h1) { load_x(h + 3, xr2); load_dy(h + 2, dv2); }   // the rows of iteration h + 2
 
       const unsigned* abase[FPW];
       bool okf[FPW];
@@ -2351,7 +2365,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
         const int fr = wave + f * WAVES;            // fragment id = tap9 * GA + ga
         const int tap9 = fr / GA, ga = fr % GA;
         const int oh = (tap9 / 3) % 3, ow = tap9 % 3;
-        okf[f] = fr < NFRAG && ok_h[oh];
+        okf[f] = fr < NFRAG;                     // (a row outside the frame sits in the ring as zeros: no per-row validity)
         abase[f] = s_x + ((long)slot_of[oh] * rowlen + ow + tr_px) * PX + ga * 16 + tr_w;
       }
       const unsigned* bbase = s_dy + tr_px * PY + tr_w;
@@ -2368,16 +2382,25 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
             Bh[n] = pack2(tr(bp), tr(bp + 4 * PY));
             Bl[n] = pack2(tr(bp + 8), tr(bp + 4 * PY + 8));
           }
+          // the A fragment of f + 1 is read while the MFMAs of f run (left alone the compiler emits ds_read, s_waitcnt
+          // lgkmcnt(0), v_mfma per fragment: one exposed LDS round trip each, at two waves per SIMD)
+          u32x4 Ah[2], Al[2];
+          auto rdA = [&](int f, u32x4& h_, u32x4& l_) __attribute__((always_inline)) {
+            const unsigned* ap = abase[f] + (long)(32 * s) * PX;
+            h_ = pack2(tr(ap), tr(ap + 4 * PX));
+            l_ = pack2(tr(ap + 8), tr(ap + 4 * PX + 8));
+          };
+          rdA(0, Ah[0], Al[0]);
 #pragma unroll
           for (int f = 0; f < FPW; ++f) {
+            if (f + 1 < FPW) rdA(f + 1, Ah[(f + 1) & 1], Al[(f + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
             if (!okf[f]) continue;
-            const unsigned* ap = abase[f] + (long)(32 * s) * PX;
-            const u32x4 Ah = pack2(tr(ap), tr(ap + 4 * PX)), Al = pack2(tr(ap + 8), tr(ap + 4 * PX + 8));
 #pragma unroll
             for (int n = 0; n < NBP; ++n) {
-              acc[f][n0 + n] = mfma_s<PM_F16X2>(Ah, Bh[n], acc[f][n0 + n]);
-              acc[f][n0 + n] = mfma_s<PM_F16X2>(Ah, Bl[n], acc[f][n0 + n]);
-              acc[f][n0 + n] = mfma_s<PM_F16X2>(Al, Bh[n], acc[f][n0 + n]);
+              acc[f][n0 + n] = mfma_s<PM_F16X2>(Ah[f & 1], Bh[n], acc[f][n0 + n]);
+              acc[f][n0 + n] = mfma_s<PM_F16X2>(Ah[f & 1], Bl[n], acc[f][n0 + n]);
+              acc[f][n0 + n] = mfma_s<PM_F16X2>(Al[f & 1], Bh[n], acc[f][n0 + n]);
             }
           }
         }
@@ -2385,7 +2408,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
       if (h + 1 < h1) post_amax();
     }
   }
-  float* dw = a.dwp + (long)wset * a.ntaps * a.Cin * a.CoutPad;
+  float* dw = a.dwp + (long)(blockIdx.x % kWgradCopies) * a.copy_stride + (long)wset * a.ntaps * a.Cin * a.CoutPad;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
   const float un = gs.inv();
 #pragma unroll
@@ -2399,15 +2422,20 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
       for (int r = 0; r < 4; ++r)
         atomicAdd(dw + ((long)tap * a.Cin + 16 * (xg0 + ga) + r0 + r) * a.CoutPad + 16 * (yg0 + n) + col, acc[f][n][r] * un);
   }
-  if (do_bias) {
+  if (do_bias) {      // workgroup-uniform.  The 512 threads' partial sums meet in LDS first: ONE global atomic per channel and
+    __syncthreads();  // workgroup (per-thread global atomics — 4,096 per workgroup onto 48 addresses — were 0.29 of the kernel's 0.69 ms)
+    for (int i = tid; i < CO; i += NTH) s_bs[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < DYU; ++i) {
       const int u = tid + i * NTH;
       if (u >= seg * (CO / 4)) continue;
       const int q = u % (CO / 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(a.dbias + (long)wset * a.CoutPad + 16 * yg0 + 4 * q + r, bsum[i][r]);
+      for (int r = 0; r < 4; ++r) atomicAdd(&s_bs[4 * q + r], bsum[i][r]);
     }
+    __syncthreads();
+    for (int i = tid; i < CO; i += NTH) atomicAdd(a.dbias + (long)wset * a.CoutPad + 16 * yg0 + i, s_bs[i]);
   }
 }
 
@@ -2460,13 +2488,18 @@ __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pf,
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int wsets, int Cout, int Cin,
                                     int ntaps, int CoutPad) {
   const long total = (long)wsets * Cout * Cin * ntaps;
+  const long copy_stride = (long)wsets * ntaps * Cin * CoutPad;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int tap = (int)(e % ntaps);
     long r = e / ntaps;
     const int ci = (int)(r % Cin); r /= Cin;
     const int co = (int)(r % Cout);
     const int ws = (int)(r / Cout);
-    dw[e] = dwp[(((long)ws * ntaps + tap) * Cin + ci) * CoutPad + co];
+    const float* src = dwp + (((long)ws * ntaps + tap) * Cin + ci) * CoutPad + co;
+    float v = src[0];
+#pragma unroll
+    for (int c = 1; c < kWgradCopies; ++c) v += src[c * copy_stride];      // the partial copies (conv_common.h kWgradCopies)
+    dw[e] = v;
   }
 }
 
@@ -2989,7 +3022,7 @@ extern "C" long idee_conv_packed_floats(const idee_conv_desc* d) {
 }
 extern "C" long idee_conv_wgrad_floats(const idee_conv_desc* d) {
   if (!d) return -1;
-  return (long)d->wsets * n_taps(d) * d->Cin * (((d->Cout + 15) / 16) * 16);
+  return (long)kWgradCopies * d->wsets * n_taps(d) * d->Cin * (((d->Cout + 15) / 16) * 16);      // see conv_common.h kWgradCopies
 }
 
 extern "C" int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, void* packed_fwd_, void* packed_dgrad_,
@@ -3134,6 +3167,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.dy = dy; a.dwp = dw_packed; a.dbias = dbias;
+  a.copy_stride = (long)d->wsets * n_taps(d) * d->Cin * (((d->Cout + 15) / 16) * 16);
   a.B = d->B; a.wsets = d->wsets; a.T = d->T; a.H = d->H; a.W = d->W; a.To = out_T(d);
   a.Cin = d->Cin; a.CoutPad = ((d->Cout + 15) / 16) * 16; a.cout_real = d->Cout; a.ntaps = n_taps(d); a.kt = mode_kt(d);
   a.x_sB = d->x_sB; a.x_sT = d->x_sT; a.x_sH = d->x_sH; a.x_sW = d->x_sW; a.x_sG = d->x_sG;
@@ -3219,7 +3253,10 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
       return idee::fail(IDEE_ERR_LAUNCH, "conv_wgrad: cannot reserve %zu bytes of LDS", lds);                          \
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_), lds, st, a, seg, nseg, hrun, nhrun);                            \
   } while (0)
-    if (conv_f22_math() && Ga == Gb && (ga_k == 6 || Ga == 3 || Ga == 2) && !bf) {
+    // (the f16 kernel keeps its in-row source offsets as 32-bit element counts)
+    const bool off32 = (long)d->W * a.x_sW + (long)(Ga + 1) * (a.x_sU > a.x_sG ? a.x_sU : a.x_sG) < (1L << 31) &&
+                       (long)d->W * a.y_sW + (long)(Gb + 1) * (a.y_sU > a.y_sG ? a.y_sU : a.y_sG) < (1L << 31);
+    if (conv_f22_math() && Ga == Gb && (ga_k == 6 || Ga == 3 || Ga == 2) && !bf && off32) {
       // f16 pieces at f32 level: 32- or 64-pixel segments (K = 32 pixels per MFMA), piece images of 64 B per pixel and channel
       // block.  6 x 6 blocks run as two 6 x 3 halves (84 accumulator registers instead of 168).  (32-pixel segments — 49 KB of LDS,
       // more workgroups per CU — measured slower, 1.26 vs 0.93 ms: the per-row barriers and latencies dominate, not the MFMAs)

@@ -174,7 +174,8 @@ typedef struct {
   int act_dtype;
 } idee_conv_desc;
 
-/* floats in a packed (fragment-ordered) weight buffer / in a packed weight-gradient buffer */
+/* floats in a packed (fragment-ordered) weight buffer / in a packed weight-gradient buffer (the latter holds several partial
+ * copies over which the kernels spread their atomic flushes; zero it before idee_conv_wgrad, idee_conv_unpack_wgrad sums them) */
 long idee_conv_packed_floats(const idee_conv_desc* d);
 long idee_conv_wgrad_floats(const idee_conv_desc* d);
 /* w: reference layout (wsets, Cout, Cin, kt, kh, kw) -> fragment order for fwd and/or dgrad */
