@@ -2731,9 +2731,12 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
         }
       }
     }
-  if (a.dbias) {
+  if (a.dbias) {      // (uniform) one atomic per WORKGROUP: per-wave atomics onto this single address form a chain of ~17 ns each
     bsum = wave_sum(bsum);
-    if ((threadIdx.x & 63) == 0) atomicAdd(a.dbias + (long)wset * 16, bsum);
+    __syncthreads();
+    if (lane == 0) red[wave] = bsum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.dbias + (long)wset * 16, (red[0] + red[1]) + (red[2] + red[3]));
   }
 }
 

@@ -159,16 +159,26 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
     for (int o = QE; o < 64; o <<= 1) val += __shfl_xor(val, o, 64);
     return val;
   };
-  const int lane = threadIdx.x & 63;
+  // the workgroup's 4 waves meet in LDS, one global atomic per value and workgroup (see lfq_bwd_kernel: same-address float
+  // atomics retire one every ~17 ns)
+  constexpr int NV = E * (CIN + 1);              // [db: E][dw: E x CIN]
+  __shared__ float s_fl[4][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float sb = same_q_sum(gb[k]);
-    if (lane < QE && db) atomicAdd(db + v * E + 4 * q + k, sb);
+    if (lane < QE) s_fl[wave][4 * q + k] = sb;
 #pragma unroll
     for (int c = 0; c < CIN; ++c) {
       const float sw = same_q_sum(gw[k][c]);
-      if (lane < QE) atomicAdd(dw + ((long)v * E + 4 * q + k) * CIN + c, sw);
+      if (lane < QE) s_fl[wave][E + (4 * q + k) * CIN + c] = sw;
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV; i += 256) {
+    const float val = (s_fl[0][i] + s_fl[1][i]) + (s_fl[2][i] + s_fl[3][i]);
+    if (i < E) { if (db) atomicAdd(db + v * E + i, val); }
+    else atomicAdd(dw + (long)v * E * CIN + (i - E), val);
   }
 }
 
@@ -600,27 +610,38 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, 
     stx4<AT>(dz + tok * E + 4 * q, o);
    }
   }
-  // lanes with equal q hold partials of the same 4 channels: reduce over them, lanes 0..QE-1 publish
+  // lanes with equal q hold partials of the same 4 channels: reduce over them; the workgroup's 4 waves then meet in LDS and ONE
+  // thread per value issues the global atomic.  (Per-wave atomics — 8,192 waves onto each of ~50 addresses — were 0.138 of this
+  // kernel's 0.324 ms: same-address float atomics retire one every ~17 ns, whatever the line layout.)
   auto same_q_sum = [](float v) {
 #pragma unroll
     for (int o = QE; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
   };
-  const int lane = threadIdx.x & 63;
+  constexpr int NV = D + 2 * D * E + E;          // [db_in: D][dw_in: D x E][dw_out: E x D][db_out: E]
+  __shared__ float s_fl[4][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* fl = s_fl[wave];
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     const float bi = same_q_sum(gbi[i]);
-    if (lane == 0) atomicAdd(db_in + i, bi);
+    if (lane == 0) fl[i] = bi;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float a = same_q_sum(gwi[i][c]), b2 = same_q_sum(gwo[i][c]);
-      if (lane < QE) { atomicAdd(dw_in + i * E + 4 * q + c, a); atomicAdd(dw_out + (4 * q + c) * D + i, b2); }
+      if (lane < QE) { fl[D + i * E + 4 * q + c] = a; fl[D + D * E + (4 * q + c) * D + i] = b2; }
     }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float a = same_q_sum(gbo[c]);
-    if (lane < QE) atomicAdd(db_out + 4 * q + c, a);
+    if (lane < QE) fl[D + 2 * D * E + 4 * q + c] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV; i += 256) {
+    const float v = (s_fl[0][i] + s_fl[1][i]) + (s_fl[2][i] + s_fl[3][i]);
+    float* dst = i < D ? db_in + i : i < D + D * E ? dw_in + (i - D) : i < D + 2 * D * E ? dw_out + (i - D - D * E) : db_out + (i - D - 2 * D * E);
+    atomicAdd(dst, v);
   }
 }
 
@@ -1018,11 +1039,18 @@ __global__ __launch_bounds__(256) void ln_relu_res_bwd_kernel(const float* __res
     for (int o = QE; o < 64; o <<= 1) val += __shfl_xor(val, o, 64);
     return val;
   };
-  const int lane = threadIdx.x & 63;
+  // the workgroup's 4 waves meet in LDS: one global atomic per value and workgroup (see lfq_bwd_kernel)
+  __shared__ float s_fl[4][2 * E];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float a = same_q_sum(gg[k]), bb = same_q_sum(gb[k]);
-    if (lane < QE) { atomicAdd(dgamma + v * E + 4 * q + k, a); atomicAdd(dbeta + v * E + 4 * q + k, bb); }
+    if (lane < QE) { s_fl[wave][4 * q + k] = a; s_fl[wave][E + 4 * q + k] = bb; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * E; i += 256) {
+    const float val = (s_fl[0][i] + s_fl[1][i]) + (s_fl[2][i] + s_fl[3][i]);
+    atomicAdd((i < E ? dgamma : dbeta) + v * E + (i < E ? i : i - E), val);
   }
 }
 
