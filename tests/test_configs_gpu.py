@@ -5,10 +5,12 @@
   #4  ERA5-Land-shaped 412x424, T=16, V=6, C=2, Swin "small" (embed [32,32], depths [2,2], head_dim 16, codebook/cls
       dim 32), f32: forward against the oracle on crops incl. the true frame corners, the (N,1,2,H,W) output shape,
       and one ERA5 train step (finite, every parameter moves)."""
+import os
+
 import pytest
 import torch
 
-from conftest import tie_relu, interval_close, adam_params_close
+from conftest import tie_relu, interval_close, adam_params_close, variants, KERNEL_VARIANTS
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -49,7 +51,8 @@ def _lively(model, seed, proj_scale):
         model.vq.project_in.weight.mul_(proj_scale)
 
 
-def test_config1_cnn_64x64_batch2_train_step_vs_oracle():
+@variants('default', 'all_f22')
+def test_config1_cnn_64x64_batch2_train_step_vs_oracle(kernel_variant):
     from oracle import idee_oracle as O
     from idee_amd.config import default_config
     from idee_amd.models.build import VQ_model
@@ -146,10 +149,24 @@ C4_CROPS = {     # (rows, cols) of the crop, then of the compared region; 412 = 
 }
 
 
-@pytest.fixture(scope="module")
-def c4_forward():
+@pytest.fixture(scope="module", params=["default", "all_f22"])
+def c4_forward(request):
+    """The config-#4 forward, once on the exact-f32 kernels and once on the f16-piece f32-level kernels (the library reads its
+    switches at every launch; a module-scoped fixture sets them around its own launches)."""
     from idee_amd.config import default_config
     from idee_amd.models.build import VQ_model
+    saved = {k: os.environ.pop(k, None) for k in ("IDEE_SWIN_MATH", "IDEE_CONV_MATH")}
+    os.environ.update(KERNEL_VARIANTS[request.param])
+    try:
+        return _c4_forward(default_config, VQ_model)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def _c4_forward(default_config, VQ_model):
     cfg = default_config(**C4)
     torch.manual_seed(7)
     m = VQ_model(cfg)
