@@ -12,6 +12,17 @@ from .. import _stacked
 from ... import ops
 
 
+
+class HeadLogits(list):
+    """The per-variable heads' logits as the reference returns them — a list of V tensors (N,1,H,W) — made of VIEWS of the one
+    (N,V,...) tensor the kernels write (`.stacked`).  torch.split instead of V slices: its backward is one concatenation (V
+    slices cost V zero-fills of the whole tensor, V copies and V - 1 adds per step); a consumer that wants all heads at once
+    (train.py's loss rows) reads `.stacked` and skips V reshape copies."""
+
+    def __init__(self, y):
+        super().__init__(torch.split(y, 1, dim=1))
+        self.stacked = y
+
 class CNN_3D(_stacked.StackedModule):
     def __init__(self, in_var: int = 6, embed_dim: int = 16, dim: int = 16, n_classes: int = 1, drop_rate: int = 0.2):
         super().__init__()
@@ -74,7 +85,7 @@ class CNN_3D(_stacked.StackedModule):
         """zq (N,V,T,H,W,C) channels-last -> (z (N,1,H,W), [y_v (N,1,H,W)] * V)."""
         z, y = ops.ClassifierHeads.apply(zq, self.j_w1, self.j_b1, self.j_w2, self.j_b2, *self._joint_out(), self.h_w1,
                                          self.h_b1, self.h_w2, self.h_b2, self.h_w3, self.h_b3, *self._dropout_args())
-        return self._joint_logits(z), [y[:, v:v + 1] for v in range(self.in_var)]      # (N,1,H,W) each; (N,1,T/8,H,W) when T > 8, as the reference
+        return self._joint_logits(z), HeadLogits(y)      # (N,1,H,W) each; (N,1,T/8,H,W) when T > 8, as the reference
 
     def _joint_out(self):
         """conv3 of the joint head as the kernels take it: one class -> the streaming Cout = 1 kernels; n_classes > 1 -> zero-padded
@@ -98,7 +109,7 @@ class CNN_3D(_stacked.StackedModule):
         z, y = ops.ClassifierHeadsSigns.apply(signs, project_out.weight, project_out.bias, self.j_w1, self.j_b1, self.j_w2,
                                               self.j_b2, *self._joint_out(), self.h_w1, self.h_b1, self.h_w2, self.h_b2,
                                               self.h_w3, self.h_b3, *self._dropout_args(), act_dtype)
-        return self._joint_logits(z), [y[:, v:v + 1] for v in range(self.in_var)]
+        return self._joint_logits(z), HeadLogits(y)
 
     def forward(self, x):
         """x (N,V,C,T,H,W) as CNN_3D.forward (classifier/CNN_3D.py:112-139)."""

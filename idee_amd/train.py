@@ -39,6 +39,9 @@ class _TrainStep:
         T3 > 1 only at T = 16, where the reference's own loss is ill-defined: each temporal
         slice is then scored against the same target and the slices are averaged."""
         if pred.dim() == 4:
+            y = getattr(pred_y, "stacked", None)       # classifier.HeadLogits: all V heads as one (N,V,H,W) tensor
+            if y is not None and y.dim() == 4 and pred.shape[1] == 1:
+                return torch.cat([pred.reshape(1, -1), y.permute(1, 0, 2, 3).reshape(y.shape[1], -1)], 0), 1
             return torch.cat([pred.reshape(1, -1)] + [p.reshape(1, -1) for p in pred_y], 0), 1
         T3 = pred.shape[2]
         rows = [p[:, 0].permute(1, 0, 2, 3).reshape(T3, -1) for p in [pred] + list(pred_y)]
