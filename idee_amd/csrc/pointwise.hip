@@ -656,12 +656,23 @@ __global__ void bce_counts_kernel(const float* __restrict__ target, const float*
   // one workgroup (the two passes are dependent and M is a mask-sized array): 16-byte loads when the layout allows
   const bool vec = (M % 4 == 0) && (((size_t)target | (size_t)(valid ? valid : target)) % 16 == 0);
   if (vec) {
-    for (long i = threadIdx.x; i < M / 4; i += blockDim.x) {
-      const f32x4 t4 = ld4(target + 4 * i);
-      const f32x4 m4 = valid ? ld4(valid + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f};
+    // (one workgroup, two dependent passes: UN independent 16-byte loads in flight per thread — one at a time, each trip paid a
+    //  full memory round trip: 50 us for 160 k elements)
+    constexpr int UN = 8;
+    for (long i0 = threadIdx.x; i0 < M / 4; i0 += (long)UN * blockDim.x) {
+      f32x4 t4[UN], m4[UN];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (m4[k] != 0.f) { v[0] = fminf(v[0], t4[k]); v[1] = fmaxf(v[1], t4[k]); }
+      for (int u = 0; u < UN; ++u) {
+        const long i = i0 + (long)u * blockDim.x;
+        const bool in = i < M / 4;
+        t4[u] = in ? ld4(target + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        m4[u] = in ? (valid ? ld4(valid + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f}) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (m4[u][k] != 0.f) { v[0] = fminf(v[0], t4[u][k]); v[1] = fmaxf(v[1], t4[u][k]); }
     }
   } else {
     for (long i = threadIdx.x; i < M; i += blockDim.x) {
@@ -684,12 +695,21 @@ __global__ void bce_counts_kernel(const float* __restrict__ target, const float*
     if (bin == 1) c1 += 1.f; else c0 += 1.f;
   };
   if (vec) {
-    for (long i = threadIdx.x; i < M / 4; i += blockDim.x) {
-      const f32x4 t4 = ld4(target + 4 * i);
-      const f32x4 m4 = valid ? ld4(valid + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f};
+    constexpr int UN = 8;
+    for (long i0 = threadIdx.x; i0 < M / 4; i0 += (long)UN * blockDim.x) {
+      f32x4 t4[UN], m4[UN];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (m4[k] != 0.f) count(t4[k]);
+      for (int u = 0; u < UN; ++u) {
+        const long i = i0 + (long)u * blockDim.x;
+        const bool in = i < M / 4;
+        t4[u] = in ? ld4(target + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        m4[u] = in ? (valid ? ld4(valid + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f}) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (m4[u][k] != 0.f) count(t4[u][k]);
     }
   } else {
     for (long i = threadIdx.x; i < M; i += blockDim.x) {
