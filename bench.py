@@ -352,14 +352,15 @@ def main():
     a = parse()
     if a.dtype == "bf16":
         a.math = "f32"          # (the bf16 activation path has its own kernels; the f32-path switches are pinned to their defaults)
-    # the library reads these at every launch; child ranks inherit them.  BOTH switches are pinned to the chosen arithmetic
-    # whatever the caller's environment holds, so the printed `dtype` / `math` always describe what ran.
-    os.environ["IDEE_CONV_MATH"] = a.math if a.math in ("split", "fwd22", "f22") else "f32"
-    os.environ["IDEE_SWIN_MATH"] = a.math if a.math in ("split", "fwd22", "f22") else "f32"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
     import torch
     from idee_amd import _lib, parallel
+    # the library looks these options up at every launch.  BOTH are pinned (idee_set_option, in every rank process) to the
+    # chosen arithmetic whatever the caller's environment holds, so the printed `dtype` / `math` always describe what ran.
+    math_opt = a.math if a.math in ("split", "fwd22", "f22") else "f32"
+    _lib.set_option("IDEE_CONV_MATH", math_opt)
+    _lib.set_option("IDEE_SWIN_MATH", math_opt)
     from idee_amd.config import default_config
     from idee_amd.train import SyntheticTrainStep, ERA5TrainStep
     rank, world, local = parallel.init_from_env()
@@ -490,7 +491,8 @@ def main():
     # ---- --math f22: the exact-f32 line of the same workload, measured in this run and printed beside the headline ----
     exact = None
     if a.math == "f22" and a.dtype == "f32" and world == 1 and not a.no_exact_line:
-        os.environ["IDEE_CONV_MATH"] = os.environ["IDEE_SWIN_MATH"] = "f32"      # read by the library at every launch
+        _lib.set_option("IDEE_CONV_MATH", "f32")      # looked up by the library at every launch
+        _lib.set_option("IDEE_SWIN_MATH", "f32")
         for _ in range(min(a.warmup, 5)):
             ts.step(x, *masks)
         barrier()
@@ -499,7 +501,8 @@ def main():
             ts.step(x, *masks)
         barrier()
         edt = time.perf_counter() - e0
-        os.environ["IDEE_CONV_MATH"] = os.environ["IDEE_SWIN_MATH"] = "f22"
+        _lib.set_option("IDEE_CONV_MATH", "f22")
+        _lib.set_option("IDEE_SWIN_MATH", "f22")
         exact = dict(value=round(batch * a.steps / edt, 3), unit="samples/s", ms_per_step=round(edt / a.steps * 1e3, 3), steps=a.steps,
                      dtype="f32", math=math_label("f32", cfg, a.dtype),
                      note="same process, model, batch and step count, IDEE_SWIN_MATH = IDEE_CONV_MATH = f32 (the library's default "

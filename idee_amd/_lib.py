@@ -59,6 +59,8 @@ _SIGS = {
     "idee_version": (C.c_char_p, []),
     "idee_last_error": (C.c_char_p, []),
     "idee_check_device": (_I, [_I]),
+    "idee_set_option": (_I, [C.c_char_p, C.c_char_p]),
+    "idee_get_option": (_I, [C.c_char_p, C.c_char_p, _I]),
     "idee_patch_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P]),
     "idee_patch_embed_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P]),
     "idee_stage_embed_ln_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
@@ -148,6 +150,36 @@ def last_error() -> str:
 def check(rc: int, what: str):
     if rc != 0:
         raise IdeeHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def set_option(name: str, value=None):
+    """Set a kernel-selection option of the library (include/idee_hip.h: idee_set_option); None / "" = default."""
+    check(load().idee_set_option(name.encode(), None if value is None else str(value).encode()), "idee_set_option")
+
+
+def get_option(name: str) -> str:
+    buf = C.create_string_buffer(64)
+    check(load().idee_get_option(name.encode(), buf, 64), "idee_get_option")
+    return buf.value.decode()
+
+
+class options:
+    """Context manager: set options for the duration of a block and restore the previous values.
+    `with _lib.options(IDEE_SWIN_MATH="f22"): ...`"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            set_option(k, v)
+        return False
 
 
 def ptr(t):

@@ -31,12 +31,12 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int imin(long a, long b) { return (int)(a < b ? a : b); }
 static inline int imax(long a, long b) { return (int)(a > b ? a : b); }
 
-// Kernel-selection switches (IDEE_*) are read from the environment at EVERY launch (no cached statics), so a test can toggle
-// them between calls of one process.
-static inline bool env_is(const char* name, const char* value) {
-  const char* e = getenv(name);
-  return e && strcmp(e, value) == 0;
-}
+// Kernel-selection switches (IDEE_*): a process-wide option table (api.cpp) read at EVERY launch under a reader lock.  The
+// environment variable of the same name is only the table's initial value; hosts change a switch between launches with
+// idee_set_option (include/idee_hip.h) — no getenv() on the launch path.
+bool opt_is(const char* name, const char* value);
+int opt_int(const char* name);      // 0 when unset
+static inline bool env_is(const char* name, const char* value) { return opt_is(name, value); }
 
 // number of workgroups that fills the chip a few times over (256 CUs)
 constexpr int kCUs = 256;
@@ -170,6 +170,8 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
   r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
   return mx(r[0], r[1]);
 }
+__device__ __forceinline__ int imax_dev(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 __device__ __forceinline__ float amax4(f32x4 v) {
   return fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
 }
@@ -212,6 +214,35 @@ struct GradScale {
     k = kn < -63 ? -63 : (kn > 63 ? 63 : kn);
     set = true;
   }
+  __device__ __forceinline__ float s() const { return pow2i(k); }
+  __device__ __forceinline__ float inv() const { return pow2i(-k); }
+};
+
+// Activation guard of the f16-piece kernels whose ACTIVATION operand is not bounded by construction (convolution inputs: the
+// residual stream, ReLU outputs): a power of two 2^k, k <= 0, kept per wave / workgroup and work unit, moving DOWN only inside
+// a unit.  k = 0 — operands split as they are, bit-identical to an unguarded kernel — until a staged tile's largest |x| 2^k
+// reaches 2^15 (an f16 hi piece overflows at 65520); then k is lowered so that this tile's largest element lands in
+// [2^11, 2^12), tiles staged at the old scale are staged again and accumulators that carry the factor are multiplied along
+// (exact).  Elements of a guarded tile are rounded at max(2^-22 |x|, 2^-36 of the tile's largest).  A non-finite element
+// never triggers the guard: it stays non-finite through the pieces, as it does through the exact kernels.
+struct ActGuard {
+  int k = 0;
+  float thr = 32768.f;       // 2^(15 - k)
+  // am: this lane's largest |x| of the tile just staged into registers (called by the whole wave)
+  __device__ __forceinline__ bool exceeds(float am) const { return __any(am >= thr && am <= 3.0e38f) != 0; }
+  // lower k for a tile whose wave- (or workgroup-) wide largest |x| has the bit pattern amax_bits; returns new k - old k (<= 0)
+  __device__ __forceinline__ int lower(unsigned amax_bits) {
+    amax_bits = __builtin_amdgcn_readfirstlane(amax_bits);
+    const int e = (int)(amax_bits >> 23) - 127;
+    int kn = 11 - e;
+    kn = kn > k ? k : (kn < -116 ? -116 : kn);
+    const int d = kn - k;
+    k = kn;
+    thr = 15 - kn > 127 ? __builtin_inff() : pow2i(15 - kn);
+    return d;
+  }
+  // finite part of a lane maximum (a non-finite element must not set the scale)
+  static __device__ __forceinline__ float finite(float am) { return am <= 3.0e38f ? am : 0.f; }
   __device__ __forceinline__ float s() const { return pow2i(k); }
   __device__ __forceinline__ float inv() const { return pow2i(-k); }
 };

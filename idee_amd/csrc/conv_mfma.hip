@@ -472,9 +472,14 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 // carry a power-of-two factor 2^k kept per wave and chunk (common.h GradScale, moving down only): every (tap, group pair)
 // operand is tested before it is split (one compare and the wave's vote); an operand that would leave the window at the top
 // lowers k, the chunk's accumulators are multiplied along (exact), and the epilogue multiplies by 2^-k.
-template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT, bool GSC = false>
+// SC_ACT (forward): the ACTIVATION operands of a wave's chunk are range-guarded the same way (common.h ActGuard): split as they are
+// until an operand's largest |x| reaches 2^15, then scaled by 2^k, k < 0, the chunk's accumulators multiplied along.
+enum { SC_NONE = 0, SC_GRAD = 1, SC_ACT = 2 };   // scale carried by the f16-piece operand that has no a-priori range
+template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT, int SC = SC_NONE>
 __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
+  constexpr bool GSC = SC == SC_GRAD, ASC = SC == SC_ACT;
   static_assert(!GSC || MODE == DGRAD_S2, "gradient scale: data-gradient mode");
+  static_assert(!ASC || MODE == FWD_S2, "activation guard: forward mode");
   constexpr int MT = 4, WAVES = 8;
   constexpr bool F16 = MODE == FWD_S2 || GSC;
   extern __shared__ __attribute__((aligned(16))) unsigned s_ws[];   // [2][Gk/2 * NT * 2 pieces * 256 words]
@@ -538,6 +543,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
     }
     f32x4 acc[MT][NT];
     GradScale gs;                                        // (GSC) this wave's scale for this chunk
+    ActGuard ag;                                         // (ASC) this wave's activation guard for this chunk
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -622,6 +628,24 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
             }
             gsc = gs.s();
           }
+          if constexpr (ASC) {
+            float am = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) am = fmaxf(am, fmaxf(amax4(xa[m]), amax4(xb[m])));
+            if (ag.exceeds(am)) {         // (rare: |x| >= 2^15 at the chunk's scale)
+              const int dk = ag.lower(wave_umax(__float_as_uint(ActGuard::finite(am))));
+              const float f = pow2i(dk < -126 ? -126 : dk);
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] *= f;
+            }
+            if (ag.k != 0) {              // wave-uniform
+              gsc = ag.s();
+#pragma unroll
+              for (int m = 0; m < MT; ++m) { xa[m] *= gsc; xb[m] *= gsc; }
+            }
+          }
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             const Split sa = split2<F16>(GSC ? xa[m] * gsc : xa[m]), sb = split2<F16>(GSC ? xb[m] * gsc : xb[m]);
@@ -660,7 +684,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       const float* ref_r = a.relu_ref ? a.relu_ref + ro : nullptr;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        f32x4 v = F16 ? acc[m][n] * (GSC ? winv * gs.inv() : winv) : acc[m][n];
+        f32x4 v = F16 ? acc[m][n] * (GSC ? winv * gs.inv() : ASC ? winv * ag.inv() : winv) : acc[m][n];
         if (a.bias) v += ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq);
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const long o = goff(n, a.o_gpu, a.o_sU, a.o_sG);
@@ -1330,9 +1354,14 @@ constexpr int kSplitRowW = 2 * kC16Row * 4;     // 32-bit words of one staged ro
 // were below 2^8 at the larger scale, so they stay in range), the ring is invalidated and the output row is begun again — rare:
 // the scale of a unit only moves down; the first non-zero row of a unit sets it.  The epilogue multiplies by 2^-k.
 // Operand rounding max(2^-22 |dy|, 2^-26 of the unit's largest |dy| so far); weights prescaled per set as in the forward.
-template <int MODE, bool F16, bool GSC = false>
+// SC = SC_ACT (f16 pieces, forward modes): the staged ACTIVATION rows are range-guarded instead (common.h ActGuard): split as they
+// are (k = 0) until a staged row's largest |x| reaches 2^15, then the unit's rows carry 2^k, k < 0, through the same restaging
+// path — an input of any finite magnitude keeps two normal f16 pieces.
+template <int MODE, bool F16, int SC = SC_NONE>
 __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
+  constexpr bool GSC = SC == SC_GRAD, ASC = SC == SC_ACT;
   static_assert(!GSC || (F16 && (MODE == DGRAD_REP || MODE == DGRAD_S2)), "gradient scale: f16 pieces, data-gradient modes");
+  static_assert(!ASC || (F16 && (MODE == FWD_REP || MODE == FWD_S2)), "activation guard: f16 pieces, forward modes");
   constexpr int MT = 2;
   constexpr bool REP = MODE == FWD_REP || MODE == DGRAD_REP;
   constexpr int TSN = REP ? 3 : (MODE == FWD_S2 ? 2 : 1);
@@ -1384,6 +1413,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
     for (int ot = 0; ot < 3; ++ot) st[ot] = slot_t<MODE>(ot, t, a.Ti, a.kt);
     const int blk1 = my_sub > 1 ? 16 : 0;
     GradScale gs;                       // (GSC) this unit's gradient scale
+    ActGuard ag;                        // (ASC) this unit's activation guard
 
     // piece k of source row hs of source frame ot -> registers (zeros outside the frame)
     auto load_one = [&](int hs, bool inside, int ot, int k) __attribute__((always_inline)) {
@@ -1450,6 +1480,22 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
 #pragma unroll
             for (int k = 0; k < 3; ++k) stg[ot][k] *= gsc;
         }
+        if constexpr (ASC) {
+          const float am = row_amax(stg);
+          if (ag.exceeds(am)) {           // (rare: |x| >= 2^15 at the unit's scale)
+            ag.lower(wave_umax(__float_as_uint(ActGuard::finite(am))));
+            res0 = res1 = res2 = -1;
+            redo = true;
+            break;
+          }
+          if (ag.k != 0) {                // wave-uniform
+            const float gsc = ag.s();
+#pragma unroll
+            for (int ot = 0; ot < TSN; ++ot)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) stg[ot][k] *= gsc;
+          }
+        }
         if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
 #pragma unroll
         for (int ot = 0; ot < TSN; ++ot) {
@@ -1467,7 +1513,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
           }
         }
       }
-      if (GSC && redo) continue;          // (h not advanced: the row is staged again at the new scale)
+      if ((GSC || ASC) && redo) continue;   // (h not advanced: the row is staged again at the new scale)
       wave_fence();
       {
         const int key = ((((st[0].tap * 3 + st[1].tap) * 3 + st[2].tap) * 3 + sh[0].tap) * 3 + sh[1].tap) * 3 + sh[2].tap;
@@ -1534,7 +1580,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
         int wdst = p;
         bool atomic = false;
         if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
-        f32x4 v = F16 ? acc[m] * (GSC ? winv * gs.inv() : winv) : acc[m];
+        f32x4 v = F16 ? acc[m] * (GSC ? winv * gs.inv() : ASC ? winv * ag.inv() : winv) : acc[m];
         if (a.bias) v += ld4(a.bias + (long)wset * 16 + 4 * kq);
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const long o = (long)wdst * a.o_sW + 4 * kq;
@@ -1870,7 +1916,9 @@ __global__ __launch_bounds__(256, 2) void wgrad16_glds_kernel(WgradArgs a, int n
 // ---------------------------------------------------------------------------------------------
 // F16 (IDEE_CONV_MATH=f22): f16 pieces; the dy row of every output row (16 channels x 32 pixels, in registers) is multiplied by
 // a power of two kept per wave with common.h GradScale — the row's largest |dy| 2^k in [2^1, 2^8), the 9 TSL tap accumulators
-// multiplied along when k moves, by 2^-k at the flush; x (activations, O(1)) is split unscaled as in the forward kernels.
+// multiplied along when k moves, by 2^-k at the flush; the x rows (activations) are split as they are under a range guard
+// (common.h ActGuard: per work unit, k = 0 until a staged row's largest |x| reaches 2^15; then the unit's rows are staged again
+// with 2^k, k < 0, and the accumulators, which carry 2^(k_dy + k_x), are multiplied along).
 // NB output blocks per wave (blockIdx.z picks the group; 16 input channels): NB = 3 for the (1,3,3) sign-field convs 16 -> 48 k.
 template <int MODE /*FWD_REP | FWD_S2*/, int TSL, bool F16 = false, int NB = 1>
 __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
@@ -1886,6 +1934,13 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
   f32x4 acc[NTAPS][NB];
   float bsum[NB];
   GradScale gs;
+  ActGuard ag;                                     // (F16) range guard of the x rows, per work unit
+  auto scale_acc = [&](float f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[tp][n] *= f;
+  };
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
     bsum[n] = 0.f;
@@ -1920,8 +1975,12 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
     int tsrc[TSL];
 #pragma unroll
     for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : a.kt * t + ot;
+    if (F16 && ag.k != 0) {          // a new unit starts unguarded again (wave-uniform; rare)
+      scale_acc(pow2i(-ag.k < 126 ? -ag.k : 126));
+      ag = ActGuard();
+    }
 
-    for (int h = h0; h < h1; ++h) {
+    for (int h = h0; h < h1;) {
       wave_fence();
       // dy of this row: lane (cout = r16, pixels p0 + 8 kq + {0..7}); pixels past the row end contribute zero
       f32x4 d0[NB], d1[NB];
@@ -1933,31 +1992,9 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
           const bool on = 8 * kq + jj < 16 * my_sub && p < a.W;
           const float v = on ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW + goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16] : 0.f;
           if (jj < 4) d0[n][jj] = v; else d1[n][jj - 4] = v;
-          bsum[n] += v;
         }
-      if constexpr (F16) {
-        float am = 0.f;
-#pragma unroll
-        for (int n = 0; n < NB; ++n) am = fmaxf(am, fmaxf(amax4(d0[n]), amax4(d1[n])));
-        const float f = gs.update(wave_umax(__float_as_uint(am)));
-        if (f != 1.f) {
-#pragma unroll
-          for (int tp = 0; tp < NTAPS; ++tp)
-#pragma unroll
-            for (int n = 0; n < NB; ++n) acc[tp][n] *= f;
-        }
-        const float gsc = gs.s();
-#pragma unroll
-        for (int n = 0; n < NB; ++n) { d0[n] *= gsc; d1[n] *= gsc; }
-      }
-      u32x4 Bh[NB], Bl[NB];
-#pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const Split s0 = split2<F16>(d0[n]), s1 = split2<F16>(d1[n]);
-        Bh[n] = u32x4{s0.h01, s0.h23, s1.h01, s1.h23};
-        Bl[n] = u32x4{s0.l01, s0.l23, s1.l01, s1.l23};
-      }
       int slot_of[3];
+      bool redo = false;
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) {
         const int hs = MODE == FWD_REP ? min(max(h + oh - 1, 0), a.H - 1) : h + oh - 1;
@@ -1983,6 +2020,27 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
             stg[ot][k] = v;
           }
         }
+        if constexpr (F16) {
+          float am = 0.f;
+#pragma unroll
+          for (int ot = 0; ot < TSL; ++ot)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) am = fmaxf(am, amax4(stg[ot][k]));
+          if (ag.exceeds(am)) {             // (rare: |x| >= 2^15 at the unit's scale) lower the scale, stage the ring again
+            const int dk = ag.lower(wave_umax(__float_as_uint(ActGuard::finite(am))));
+            scale_acc(pow2i(dk < -126 ? -126 : dk));
+            res0 = res1 = res2 = -1;
+            redo = true;
+            break;
+          }
+          if (ag.k != 0) {                  // wave-uniform
+            const float xsc = ag.s();
+#pragma unroll
+            for (int ot = 0; ot < TSL; ++ot)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) stg[ot][k] *= xsc;
+          }
+        }
 #pragma unroll
         for (int ot = 0; ot < TSL; ++ot) {
           unsigned* dst = s_x + (ot * 3 + slot) * ROWW;
@@ -1997,6 +2055,26 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
             }
           }
         }
+      }
+      if (F16 && redo) continue;          // (h not advanced: the row's ring is staged again at the new scale)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) bsum[n] += hsum4(d0[n]) + hsum4(d1[n]);
+      if constexpr (F16) {
+        float am = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) am = fmaxf(am, fmaxf(amax4(d0[n]), amax4(d1[n])));
+        const float f = gs.update(wave_umax(__float_as_uint(am)));
+        if (f != 1.f) scale_acc(f);
+        const float gsc = gs.s();
+#pragma unroll
+        for (int n = 0; n < NB; ++n) { d0[n] *= gsc; d1[n] *= gsc; }
+      }
+      u32x4 Bh[NB], Bl[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const Split s0 = split2<F16>(d0[n]), s1 = split2<F16>(d1[n]);
+        Bh[n] = u32x4{s0.h01, s0.h23, s1.h01, s1.h23};
+        Bl[n] = u32x4{s0.l01, s0.l23, s1.l01, s1.l23};
       }
       wave_fence();
       // acc[tap][cin][cout] += sum over the strip's 32 pixels of x[pixel + tap offset][cin] dy[pixel][cout]
@@ -2018,18 +2096,19 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
               acc[tp][n] = mfma_s<F16>(Al, Bh[n], acc[tp][n]);
             }
           }
+      ++h;
     }
   }
   float* dw = a.dwp + (long)(blockIdx.x % kWgradCopies) * a.copy_stride + (long)wset * NTAPS * 16 * a.CoutPad;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
-  const float un = F16 ? gs.inv() : 1.f;
+  const float un = F16 ? gs.inv() : 1.f, unx = F16 ? ag.inv() : 1.f;   // (two factors: their product may leave f32's range)
 #pragma unroll
   for (int tp = 0; tp < NTAPS; ++tp)
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + (gb0 + n) * 16 + col, F16 ? acc[tp][n][r] * un : acc[tp][n][r]);
+        atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + (gb0 + n) * 16 + col, F16 ? acc[tp][n][r] * un * unx : acc[tp][n][r]);
   if (a.dbias) {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -2187,6 +2266,9 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
 // workgroup (largest |dy| of the row over all threads: wave max, LDS, barrier; common.h GradScale — every wave follows the same
 // sequence, so each rescales its own accumulators when the scale moves) and the flush multiplies by 2^-k.  The bias gradient is
 // summed from the unscaled f32 values in the staging threads' registers (a thread stages the same channel quads in every row).
+// The x rows are range-guarded per work unit (common.h ActGuard, workgroup-wide through the same LDS exchange as the dy maximum):
+// k = 0 until a row's largest |x| reaches 2^15; then the two rows already in the ring are staged again at the lower scale and
+// every wave multiplies its accumulators along.
 // ---------------------------------------------------------------------------------------------
 template <int GA, int GB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs a, int seg /*multiple of 32, <= 64*/, int nseg, int hrun,
@@ -2200,7 +2282,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
   constexpr int NTH = 64 * WAVES;
   constexpr int DYU = (64 * (CO / 4) + NTH - 1) / NTH;   // dy staging units (16 bytes) per thread and row
   extern __shared__ __attribute__((aligned(16))) unsigned s_dynu[];
-  __shared__ unsigned s_red[WAVES];
+  __shared__ unsigned s_red[WAVES], s_redx[WAVES], s_redx0[WAVES];
   __shared__ float s_bs[CO];
   const int rowlen = seg + 2;
   unsigned* s_x = s_dynu;                            // [3][rowlen][PX]
@@ -2220,6 +2302,13 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
 
   f32x4 acc[FPW][GB];
   GradScale gs;
+  ActGuard ag;                                       // range guard of the x rows (workgroup-uniform), per work unit
+  auto scale_acc = [&](float f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ff = 0; ff < FPW; ++ff)
+#pragma unroll
+      for (int n = 0; n < GB; ++n) acc[ff][n] *= f;
+  };
 #pragma unroll
   for (int f = 0; f < FPW; ++f)
 #pragma unroll
@@ -2283,10 +2372,11 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
     };
     auto store_x = [&](int hs, const f32x4 (&xr)[XU]) __attribute__((always_inline)) {
       unsigned* dst = s_x + (long)(((hs % 3) + 3) % 3) * rowlen * PX;
+      const float xsc = ag.s();                      // (1 unless the guard has fired in this unit)
 #pragma unroll
       for (int i = 0; i < XU; ++i) {
         if (xd[i] < 0) continue;
-        const Split p = split2<PM_F16X2>(xr[i]);
+        const Split p = split2<PM_F16X2>(ag.k != 0 ? xr[i] * xsc : xr[i]);
         unsigned* d = dst + xd[i];
         *reinterpret_cast<u32x2v*>(d) = u32x2v{p.h01, p.h23};
         *reinterpret_cast<u32x2v*>(d + 8) = u32x2v{p.l01, p.l23};
@@ -2301,25 +2391,48 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
     // iteration h + 1, requested a full iteration before they are needed (one row deep, a row's loads had only the ~1 us of its
     // MFMA loop to land before the row maximum needed them: 0.67 -> see DESIGN ms)
     f32x4 xr[XU], dv[DYU], xr2[XU], dv2[DYU];
-    {   // unit start: rows h0 - 1 and h0 straight into the ring
-      __syncthreads();                               // the previous unit's readers are done
-      load_x(h0 - 1, xr); store_x(h0 - 1, xr);
-      load_x(h0, xr);     store_x(h0, xr);
+    auto x_amax = [&](const f32x4 (&xv)[XU]) __attribute__((always_inline)) {
+      float am = 0.f;
+#pragma unroll
+      for (int i = 0; i < XU; ++i) am = fmaxf(am, amax4(xv[i]));
+      return ActGuard::finite(am);
+    };
+    auto wg_max = [&](const unsigned (&red)[WAVES]) __attribute__((always_inline)) {
+      unsigned m = 0u;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) m = m > red[w] ? m : red[w];
+      return m;
+    };
+    {   // unit start: rows h0 - 1 and h0 into the ring, at the unit's own guard scale (k = 0 unless they hold |x| >= 2^15)
+      if (ag.k != 0) {                               // (workgroup-uniform) a new unit starts unguarded again
+        scale_acc(pow2i(-ag.k < 126 ? -ag.k : 126));
+        ag = ActGuard();
+      }
+      load_x(h0 - 1, xr); load_x(h0, xr2);
+      const unsigned wm0 = wave_umax(__float_as_uint(fmaxf(x_amax(xr), x_amax(xr2))));
+      if (lane == 0) s_redx0[wave] = wm0;
+      __syncthreads();                               // the previous unit's readers are done; s_redx0 holds the two rows' maxima
+      const unsigned m0 = wg_max(s_redx0);
+      if (__uint_as_float(m0) >= ag.thr) scale_acc(pow2i(imax_dev(ag.lower(m0), -126)));
+      store_x(h0 - 1, xr);
+      store_x(h0, xr2);
       load_x(h0 + 1, xr);  load_dy(h0, dv);
       load_x(h0 + 2, xr2); load_dy(h0 + 1, dv2);
     }
-    // the row's largest |dy| goes to s_red right after the MFMAs of the row before (its loads have landed by then), so ONE
-    // barrier both retires the previous row's readers and publishes it: two barriers per row
+    // the row's largest |dy| (and the largest |x| of the x row staged with it) goes to s_red / s_redx right after the MFMAs of
+    // the row before (its loads have landed by then), so ONE barrier both retires the previous row's readers and publishes
+    // them: two barriers per row
     auto post_amax = [&]() __attribute__((always_inline)) {
       float am = 0.f;
 #pragma unroll
       for (int i = 0; i < DYU; ++i) am = fmaxf(am, amax4(dv[i]));
       const unsigned wm = wave_umax(__float_as_uint(am));
-      if (lane == 0) s_red[wave] = wm;
+      const unsigned wx = wave_umax(__float_as_uint(x_amax(xr)));
+      if (lane == 0) { s_red[wave] = wm; s_redx[wave] = wx; }
     };
     post_amax();
     for (int h = h0; h < h1; ++h) {
-      __syncthreads();                               // the previous row's readers are done; s_red holds this row's maxima
+      __syncthreads();                               // the previous row's readers are done; s_red / s_redx hold this row's maxima
       int slot_of[3];
       bool ok_h[3];
 #pragma unroll
@@ -2328,18 +2441,19 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
         ok_h[oh] = hs >= 0 && hs < a.H;
         slot_of[oh] = ((hs % 3) + 3) % 3;
       }
+      {
+        const unsigned mx = wg_max(s_redx);
+        if (__uint_as_float(mx) >= ag.thr) {         // (workgroup-uniform, rare) row h + 1 holds |x| >= 2^15 at the unit's scale:
+          scale_acc(pow2i(imax_dev(ag.lower(mx), -126)));   // lower it, stage rows h - 1 and h again (xr2 lends its registers)
+          load_x(h - 1, xr2); store_x(h - 1, xr2);
+          load_x(h, xr2);     store_x(h, xr2);
+          load_x(h + 2, xr2);
+        }
+      }
       store_x(h + 1, xr);                            // (row h + 1 replaces row h - 2 in the ring)
       {
-        unsigned m = 0u;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) m = m > s_red[w] ? m : s_red[w];
-        const float f = gs.update(m);
-        if (f != 1.f) {
-#pragma unroll
-          for (int ff = 0; ff < FPW; ++ff)
-#pragma unroll
-            for (int n = 0; n < GB; ++n) acc[ff][n] *= f;
-        }
+        const float f = gs.update(wg_max(s_red));
+        if (f != 1.f) scale_acc(f);
         const float gsc = gs.s();
 #pragma unroll
         for (int i = 0; i < DYU; ++i) {
@@ -2410,7 +2524,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
   }
   float* dw = a.dwp + (long)(blockIdx.x % kWgradCopies) * a.copy_stride + (long)wset * a.ntaps * a.Cin * a.CoutPad;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
-  const float un = gs.inv();
+  const float un = gs.inv(), unx = ag.inv();         // (two factors: their product may leave f32's range)
 #pragma unroll
   for (int f = 0; f < FPW; ++f) {
     const int fr = wave + f * WAVES;
@@ -2420,7 +2534,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
     for (int n = 0; n < GB; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(dw + ((long)tap * a.Cin + 16 * (xg0 + ga) + r0 + r) * a.CoutPad + 16 * (yg0 + n) + col, acc[f][n][r] * un);
+        atomicAdd(dw + ((long)tap * a.Cin + 16 * (xg0 + ga) + r0 + r) * a.CoutPad + 16 * (yg0 + n) + col, acc[f][n][r] * un * unx);
   }
   if (do_bias) {      // workgroup-uniform.  The 512 threads' partial sums meet in LDS first: ONE global atomic per channel and
     __syncthreads();  // workgroup (per-thread global atomics — 4,096 per workgroup onto 48 addresses — were 0.29 of the kernel's 0.69 ms)
@@ -2819,8 +2933,7 @@ inline int one_round(long work_items, long others, int per_cu) {
 // — minimised over the number of runs (runs of at least 8 rows).  (A fixed "about 5 units per wave" rule cost 12 % at the
 // headline shape: 5.27 units per wave means some waves run 6.)
 inline int pick_hrun(int H, long base_units, long slices, int per_cu) {
-  if (const char* e = getenv("IDEE_CONV_HRUN")) {       // test knob: force short runs so small shapes cross run boundaries
-    const int v = atoi(e);
+  if (const int v = opt_int("IDEE_CONV_HRUN")) {        // test knob: force short runs so small shapes cross run boundaries
     if (v > 0) return v < H ? v : H;
   }
   long gx_full = ((long)kCUs * per_cu) / (slices > 0 ? slices : 1);
@@ -2904,14 +3017,15 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         // f16 pieces with the per-unit gradient scale (not the 2 x 2 sub-problems of a 32 -> 32 conv: the split kernels read
         // the packed weights without a tap stride)
         if (conv_f22_math() && !a.w_tap_stride && !a.addend_first) {
-          auto kern = conv16_split_kernel<MODE, true, true>;
+          auto kern = conv16_split_kernel<MODE, true, SC_GRAD>;
           const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
           hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
           return IDEE_OK;
         }
       }
       if (conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) {      // opt-in split-precision path: f16 pieces forward, bf16 pieces in the data gradient
-        auto kern = conv16_split_kernel<MODE, (MODE == FWD_REP || MODE == FWD_S2)>;
+        // (forward: f16 pieces with the activation range guard; data gradient: bf16 pieces)
+        auto kern = conv16_split_kernel<MODE, (MODE == FWD_REP || MODE == FWD_S2), (MODE == FWD_REP || MODE == FWD_S2) ? SC_ACT : SC_NONE>;
         const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
         hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
         return IDEE_OK;
@@ -2926,7 +3040,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
           const long rows = (long)(a.B / a.wsets) * ((a.To & 3) ? a.To * 4L : a.To) / 4 * a.Ho * nstrip;   // per workgroup-slot
           long g = imax(((long)kCUs * wg_per_cu(kern, 256)) / a.wsets, 1);
           long cap = imax(rows / 8, 1);
-          if (const char* e = getenv("IDEE_CONV_HRUN")) { const int v = atoi(e); if (v > 0) { cap = cdiv(rows, v); g = cap; } }
+          if (const int v = opt_int("IDEE_CONV_HRUN")) { if (v > 0) { cap = cdiv(rows, v); g = cap; } }
           if (rows * 10 >= (1L << 31)) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv: %ld strip rows exceed the 32-bit work partition", rows);
           const dim3 grid((unsigned)imax(imin(g, cap), 1), a.wsets);
           hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, nfull);
@@ -2955,7 +3069,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       if (rows * 10 >= (1L << 31)) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv_dgrad: %ld strip rows exceed the 32-bit work partition", rows);
       long g = imax(((long)kCUs * per_cu) / a.wsets, 1);
       long cap = imax(rows / 8, 1);
-      if (const char* e = getenv("IDEE_CONV_HRUN")) { const int v = atoi(e); if (v > 0) { cap = cdiv(rows, v); g = cap; } }
+      if (const int v = opt_int("IDEE_CONV_HRUN")) { if (v > 0) { cap = cdiv(rows, v); g = cap; } }
       hipLaunchKernelGGL(kern, dim3((unsigned)imax(imin(g, cap), 1), a.wsets), dim3(64 * a.Gk), lds, stream, a, nstrip, nfull);
       return IDEE_OK;
     }
@@ -2974,7 +3088,8 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         const long lds2 = 2 * slab_bytes;
 #define LCS(NT_)                                                                                               \
   do {                                                                                                         \
-    auto kern = wide_f22 ? conv_wide_split_kernel<MODE, NT_, MODE == DGRAD_S2> : conv_wide_split_kernel<MODE, NT_>; \
+    auto kern = wide_f22 ? conv_wide_split_kernel<MODE, NT_, MODE == DGRAD_S2 ? SC_GRAD : SC_ACT> \
+                         : conv_wide_split_kernel<MODE, NT_, MODE == FWD_S2 ? SC_ACT : SC_NONE>; \
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) \
       return idee::fail(IDEE_ERR_LAUNCH, "conv: cannot reserve %ld bytes of LDS", lds2);                         \
     const dim3 grid(one_round(a.tiles, a.B, 1), a.B);                                                          \
@@ -3223,7 +3338,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
       if (rows_s * 10 >= (1L << 31)) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv_wgrad: %ld strip rows exceed the 32-bit work partition", rows_s);
       long g = imax(((long)kCUs * wg_per_cu(kern, 256)) / ((long)d->wsets * gz), 1);
       long cap = imax(rows_s / 8, 1);
-      if (const char* e = getenv("IDEE_CONV_HRUN")) { const int v = atoi(e); if (v > 0) { cap = cdiv(rows_s, v); g = cap; } }
+      if (const int v = opt_int("IDEE_CONV_HRUN")) { if (v > 0) { cap = cdiv(rows_s, v); g = cap; } }
       hipLaunchKernelGGL(kern, dim3((unsigned)imax(imin(g, cap), 1), d->wsets, gz), dim3(256), 0, st, a, nstrip, nfull, wl);
     }
     else if (rep) LSTRIP((wgrad16_strip_kernel<FWD_REP, 3, 1>));
@@ -3265,7 +3380,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
       // more workgroups per CU — measured slower, 1.26 vs 0.93 ms: the per-row barriers and latencies dominate, not the MFMAs)
       const int gb2 = ga_k == 6 ? 3 : gb_k, nsubz2 = (Ga / ga_k) * (Gb / gb2);
       int seg2 = 64;
-      if (const char* e = getenv("IDEE_WGRAD_WIDE_SEG")) { const int v = atoi(e); if (v == 32 || v == 64) seg2 = v; }   // (test / tuning knob)
+      if (const int v = opt_int("IDEE_WGRAD_WIDE_SEG")) { if (v == 32 || v == 64) seg2 = v; }   // (test / tuning knob)
       const int nseg2 = cdiv(d->W, seg2);
       int hrun2 = d->H;
       while (hrun2 > 8 && btk * cdiv(d->H, hrun2) * nseg2 * d->wsets * nsubz2 < 6L * kCUs) hrun2 = (hrun2 + 1) / 2;

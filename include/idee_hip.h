@@ -19,7 +19,8 @@
  *   - return value 0 = ok; non-zero = IDEE_ERR_*; message via idee_last_error() (thread-local);
  *   - gradient outputs named d* that are documented "accumulate" must be zero-initialised by
  *     the caller (they are added to with float atomics); all others are overwritten;
- *   - re-entrant: no global mutable state.
+ *   - re-entrant: no global mutable state on the data path; the only process-wide state is the
+ *     kernel-selection option table (idee_set_option), read under a reader lock at each launch.
  */
 #ifndef IDEE_HIP_H
 #define IDEE_HIP_H
@@ -45,6 +46,19 @@ const char* idee_version(void);
 const char* idee_last_error(void);
 /* IDEE_OK iff HIP device `dev` is a gfx950. */
 int idee_check_device(int dev);
+
+/* Kernel-selection options.  Every GEMM-shaped unit exists in more than one arithmetic form / staging variant; which one a
+ * launch uses is looked up in a process-wide table at that launch.  The environment variable of the same name gives an
+ * option its INITIAL value only (read once); afterwards the table changes through idee_set_option alone, which is safe
+ * against concurrent launches from other host threads.  value == NULL or "" resets an option to its default.
+ *   IDEE_SWIN_MATH, IDEE_CONV_MATH : "f32" (default: exact-f32 MFMA, the reference's arithmetic) | "f22" (two f16 pieces per
+ *       operand at f32 level, range-guarded) | "fwd22" (f22 in forward passes only) | "split" (bf16 pieces in the backward)
+ *   IDEE_CONV16 "regs", IDEE_WGRAD16_REGS "1", IDEE_CONV32 "generic", IDEE_DGRAD_TO16 "wide", IDEE_CONV_BF16 "direct" | "lds" :
+ *       alternative staging variants of single kernels (kept for A/B timing; each is covered by the parity suite)
+ *   IDEE_CONV_HRUN, IDEE_WGRAD_WIDE_SEG : integer test / tuning knobs
+ * Unknown names return IDEE_ERR_INVALID_ARG.  idee_get_option copies the current value ("" = default) into buf. */
+int idee_set_option(const char* name, const char* value);
+int idee_get_option(const char* name, char* buf, int buflen);
 
 /* ------------------------------------------------------------------------------------------
  * PatchEmbed3D with patch_size (1,1,1) + non-affine LayerNorm over channels.

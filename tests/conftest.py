@@ -30,12 +30,13 @@ def golden():
 
 
 # ---------------------------------------------------------------------------------------------
-# Kernel variants.  libidee_hip.so reads its IDEE_* kernel-selection switches from the environment at EVERY launch, so the
-# `-m gpu` suite runs the parity tests once per variant that ships: every kernel in the library is reached by a driver-run
-# test id (e.g. test_swin_block_golden[swin_split-w244_shift]), not by scratch logs.
+# Kernel variants.  libidee_hip.so looks its IDEE_* kernel-selection options up at EVERY launch (a process-wide table set
+# through idee_set_option; the environment only supplies initial values), so the `-m gpu` suite runs the parity tests once
+# per variant that ships: every kernel in the library is reached by a driver-run test id
+# (e.g. test_swin_block_golden[swin_split-w244_shift]), not by scratch logs.
 # ---------------------------------------------------------------------------------------------
 KERNEL_VARIANTS = {
-    "default": {},                                                   # exact-f32 MFMA everywhere (the headline arithmetic)
+    "default": {},                                                   # exact-f32 MFMA everywhere (the library's default arithmetic)
     "swin_split": {"IDEE_SWIN_MATH": "split"},                       # two-piece split GEMMs in the Swin block (opt-in)
     "swin_f22": {"IDEE_SWIN_MATH": "f22"},                           # f16 pieces fwd + bwd, prescaled weights, per-tile gradient scale
     "conv_f22": {"IDEE_CONV_MATH": "f22"},                           # f16 pieces: forward convs, 16->16 data / weight gradients (scaled dy)
@@ -58,14 +59,31 @@ def variants(*names):
     return pytest.mark.parametrize("kernel_variant", names, indirect=True)
 
 
+VARIANT_OPTIONS = ("IDEE_SWIN_MATH", "IDEE_CONV_MATH", "IDEE_CONV16", "IDEE_WGRAD16_REGS", "IDEE_CONV32", "IDEE_DGRAD_TO16",
+                   "IDEE_CONV_BF16")
+
+
 @pytest.fixture
-def kernel_variant(request, monkeypatch):
+def set_opt():
+    """set_opt(name, value): idee_set_option for the duration of the test (previous values restored at teardown)."""
+    from idee_amd import _lib
+    saved = {}
+
+    def _set(name, value):
+        saved.setdefault(name, _lib.get_option(name))
+        _lib.set_option(name, value)
+    yield _set
+    for k, v in saved.items():
+        _lib.set_option(k, v)
+
+
+@pytest.fixture
+def kernel_variant(request, set_opt):
     name = getattr(request, "param", "default")
-    for k in ("IDEE_SWIN_MATH", "IDEE_CONV_MATH", "IDEE_CONV16", "IDEE_WGRAD16_REGS", "IDEE_CONV32", "IDEE_DGRAD_TO16",
-              "IDEE_CONV_BF16"):
-        monkeypatch.delenv(k, raising=False)
+    for k in VARIANT_OPTIONS:
+        set_opt(k, "")
     for k, v in KERNEL_VARIANTS[name].items():
-        monkeypatch.setenv(k, v)
+        set_opt(k, v)
     return name
 
 

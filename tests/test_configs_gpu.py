@@ -155,15 +155,11 @@ def c4_forward(request):
     switches at every launch; a module-scoped fixture sets them around its own launches)."""
     from idee_amd.config import default_config
     from idee_amd.models.build import VQ_model
-    saved = {k: os.environ.pop(k, None) for k in ("IDEE_SWIN_MATH", "IDEE_CONV_MATH")}
-    os.environ.update(KERNEL_VARIANTS[request.param])
-    try:
+    from idee_amd import _lib
+    opts = {"IDEE_SWIN_MATH": "", "IDEE_CONV_MATH": ""}
+    opts.update(KERNEL_VARIANTS[request.param])
+    with _lib.options(**opts):
         return _c4_forward(default_config, VQ_model)
-    finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
 
 
 def _c4_forward(default_config, VQ_model):

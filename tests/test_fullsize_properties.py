@@ -166,9 +166,9 @@ def test_fullsize_conv_linearity_and_wgrad_identity(kernel_variant):
     # the three inner products are sums of ~6e7 signed terms: the exact-f32 kernels agree to 1e-5 of the result; the opt-in
     # split-precision kernels (IDEE_CONV_MATH=split: bf16 pieces in dgrad / wgrad, 2^-17 per product, unbiased) are allowed
     # that per-term error accumulated as a random walk
-    import os
+    from idee_amd import _lib
     noise = 0.0
-    if os.environ.get("IDEE_CONV_MATH") == "split":
+    if _lib.get_option("IDEE_CONV_MATH") == "split":
         noise = 4 * 2.0 ** -17 * float((y1.double() * r.double()).square().sum().sqrt())
     assert abs(lhs - float((x1.double() * dx.double()).sum())) <= 1e-5 * abs(lhs) + 1e-2 + noise
     assert abs(lhs - float((w.double() * dw.double()).sum())) <= 1e-4 * abs(lhs) + 1e-2 + noise

@@ -21,6 +21,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _L():
+    from idee_amd import _lib
+    return _lib
+
+
 def _ops():
     from idee_amd import ops
     return ops
@@ -113,7 +118,7 @@ def test_swin_block_golden(tag, kernel_variant):
 
 
 @pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows", "ragged_windows"])
-def test_swin_f22_error_against_float64(profile, monkeypatch):
+def test_swin_f22_error_against_float64(profile, set_opt):
     """IDEE_SWIN_MATH=f22 (every GEMM of the block on two f16 pieces per operand, weights prescaled by powers of two, the
     incoming gradient scaled per 32-token work item) measured against a FLOAT64 evaluation of the oracle, beside the exact-f32
     kernels and the two-piece bf16 backward (IDEE_SWIN_MATH=split) on the same inputs.  Weights at the reference's
@@ -162,7 +167,7 @@ def test_swin_f22_error_against_float64(profile, monkeypatch):
     names = list(shapes)
 
     def run(mode):
-        monkeypatch.setenv("IDEE_SWIN_MATH", mode)
+        set_opt("IDEE_SWIN_MATH", mode)
         params = [sd[n].unsqueeze(0).to(DEV).requires_grad_() for n in names]
         xd = x.to(DEV).requires_grad_()
         y = ops.SwinBlock.apply(xd, *params, index.to(DEV), NH, window, shift, None)
@@ -279,14 +284,14 @@ def test_conv_block_golden(tag, cin, kernel_variant):
 
 @pytest.mark.parametrize("T,H,W", [(8, 9, 72), (3, 5, 200), (8, 6, 200), (1, 1, 1), (2, 2, 17), (3, 21, 40)])
 @variants('default', 'conv_split', 'conv_f22', 'conv16_regs', 'wgrad16_regs')
-def test_proj_var_vs_oracle(T, H, W, monkeypatch, kernel_variant):
+def test_proj_var_vs_oracle(T, H, W, set_opt, kernel_variant):
     """Multi-tile widths (72 = 3+2 column blocks, 200 = 4+3+3+3 incl. both frame edges), thin extents
     (clamp-everything cases).  Strict gradient tolerance on a tie-free case."""
     from oracle import idee_oracle as O
     ops = _ops()
     N, V, C = 2, 2, 16
     if H == 21:      # rows walked in runs of 8, 8, 5: the strip kernels' run starts away from row 0 (the headline shape's 67-row
-        monkeypatch.setenv("IDEE_CONV_HRUN", "8")    # runs are otherwise only reached by the full-size tests)
+        set_opt("IDEE_CONV_HRUN", "8")    # runs are otherwise only reached by the full-size tests)
 
     def build(seed):
         g = torch.Generator().manual_seed(seed)
@@ -313,7 +318,7 @@ def test_proj_var_vs_oracle(T, H, W, monkeypatch, kernel_variant):
 
 
 @pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows"])
-def test_conv_f22_error_against_float64(profile, monkeypatch):
+def test_conv_f22_error_against_float64(profile, set_opt):
     """IDEE_CONV_MATH=f22 (3^3 replicate convs: forward, data gradient and weight gradient on two f16 pieces per operand; weights
     prescaled per set, dy scaled by a power of two per work unit / per row) against a FLOAT64 evaluation of the oracle's
     proj_var, beside the exact-f32 kernels and the bf16-piece backward (IDEE_CONV_MATH=split) on the same inputs.
@@ -353,7 +358,7 @@ def test_conv_f22_error_against_float64(profile, monkeypatch):
     ref.update({n: l.grad for n, l in zip(names, leaves)})
 
     def run(mode):
-        monkeypatch.setenv("IDEE_CONV_MATH", mode)
+        set_opt("IDEE_CONV_MATH", mode)
         dl = [t.to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
         y = ops.ProjVar.apply(*dl)
         (y * r.to(DEV)).sum().backward()
@@ -371,7 +376,7 @@ def test_conv_f22_error_against_float64(profile, monkeypatch):
 
 
 @pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows"])
-def test_classifier_f22_error_against_float64(profile, monkeypatch):
+def test_classifier_f22_error_against_float64(profile, set_opt):
     """The classifier on z_q (plain path) at V = 6: the 96 -> 96 joint head — conv_wide_split_kernel forward / data gradient and
     wgrad_wide_split_kernel (two 6 x 3 block halves, workgroup-wide row scale) — and the heads' 16 -> 16 (2,3,3) convs under
     IDEE_CONV_MATH=f22, against the oracle's classifier evaluated in FLOAT64, beside the exact-f32 kernels on the same inputs.
@@ -405,7 +410,7 @@ def test_classifier_f22_error_against_float64(profile, monkeypatch):
     c = c.to(DEV)
 
     def run(mode):
-        monkeypatch.setenv("IDEE_CONV_MATH", mode)
+        set_opt("IDEE_CONV_MATH", mode)
         for p_ in c.parameters():
             p_.grad = None
         xd = x.to(DEV).requires_grad_()
@@ -532,7 +537,7 @@ def test_classifier_golden(tag, kernel_variant):
 @pytest.mark.parametrize("V,H,W,E", [(3, 7, 72, 16), (6, 5, 40, 16), (1, 3, 3, 16), (5, 4, 20, 16), (6, 6, 200, 16), (2, 3, 200, 16),
                                      (6, 4, 24, 32), (3, 3, 20, 32), (2, 19, 40, 16), (3, 5, 24, 16)])
 @variants('default', 'conv_split', 'conv_f22')
-def test_classifier_vs_oracle(V, H, W, E, monkeypatch, kernel_variant):
+def test_classifier_vs_oracle(V, H, W, E, set_opt, kernel_variant):
     """Plain path (convolutions on z_q).  W = 200: the frame-wide row-wrapping column-block numbering of conv_wide,
     its zero borders, the wide weight-gradient kernel and the heads' strip kernels at both frame edges.  E = 32 (config #4's
     width): the 192 -> 192 joint head (weight gradient as a grid of 6 x 6-block sub-problems) and the 32 -> 32 heads (strip
@@ -541,7 +546,7 @@ def test_classifier_vs_oracle(V, H, W, E, monkeypatch, kernel_variant):
     from idee_amd.models.classifier.CNN_3D import CNN_3D
     N, T = (1 if W == 200 else 2), (16 if (H, W, E) == (5, 24, 16) else 8)     # T = 16 (config #4): two output frames, the
     if H == 19:      # the heads' strip kernels in runs of 8, 8, 3 rows (run starts away from row 0)      # Cout = 1 convs read 4
-        monkeypatch.setenv("IDEE_CONV_HRUN", "8")
+        set_opt("IDEE_CONV_HRUN", "8")
 
     torch.manual_seed(V * 100 + W)
     c = CNN_3D(in_var=V, embed_dim=E, dim=E, drop_rate=0.0)
@@ -579,25 +584,25 @@ def test_classifier_vs_oracle(V, H, W, E, monkeypatch, kernel_variant):
 @pytest.mark.parametrize("V,D,H,W", [(3, 1, 7, 72), (6, 1, 5, 40), (1, 1, 3, 3), (5, 2, 4, 20), (8, 2, 3, 19), (6, 1, 6, 200),
                                      (2, 2, 3, 200), (6, 1, 19, 40)])
 @variants('default', 'conv_split', 'conv_f22', 'dgrad_to16_wide')
-def test_classifier_sign_field_vs_oracle(V, D, H, W, monkeypatch, kernel_variant):
+def test_classifier_sign_field_vs_oracle(V, D, H, W, set_opt, kernel_variant):
     """The rank-d input path (ops.ClassifierHeadsSigns: convs on the sign field with folded weights) against
     the oracle's classifier applied to z_q = project_out(signs): outputs and every gradient (strict, tie-free case)."""
-    _sign_field_case(V, D, H, W, monkeypatch, 1)
+    _sign_field_case(V, D, H, W, set_opt, 1)
 
 
 @pytest.mark.parametrize("V,D,H,W,ncls", [(2, 1, 5, 24, 3), (3, 2, 4, 20, 16)])
-def test_classifier_sign_field_n_classes(V, D, H, W, ncls, monkeypatch):
+def test_classifier_sign_field_n_classes(V, D, H, W, ncls, set_opt):
     """n_classes > 1 (the joint head's conv3 has n_classes outputs, classifier/CNN_3D.py:85; the per-variable heads keep one):
     the sign-field path against the oracle, as above."""
-    _sign_field_case(V, D, H, W, monkeypatch, ncls)
+    _sign_field_case(V, D, H, W, set_opt, ncls)
 
 
-def _sign_field_case(V, D, H, W, monkeypatch, ncls):
+def _sign_field_case(V, D, H, W, set_opt, ncls):
     from oracle import idee_oracle as O
     from idee_amd.models.classifier.CNN_3D import CNN_3D
     N, T, E = (1 if W == 200 else 2), 8, 16
     if H == 19:      # row ranges of at most 8 rows: the K-split data gradient of the sign-field convs starts away from row 0
-        monkeypatch.setenv("IDEE_CONV_HRUN", "8")
+        set_opt("IDEE_CONV_HRUN", "8")
 
     torch.manual_seed(V * 100 + W)
     c = CNN_3D(in_var=V, embed_dim=E, dim=16, n_classes=ncls, drop_rate=0.0)
@@ -877,7 +882,7 @@ def test_e2e_train_steps_golden(tag, kernel_variant):
     after = ts.model.state_dict()
     for k, v in after.items():
         if v.is_floating_point():
-            if os.environ.get("IDEE_CONV_MATH") == "split":
+            if _L().get_option("IDEE_CONV_MATH") == "split":
                 # opt-in split-precision convolutions: a parameter whose gradient is at the f32 noise level can take an Adam
                 # step of either sign (|step| <= lr per step): a handful of elements within 3 lr, everything else strict
                 d = (v.detach().float().cpu() - a["sd_after3/" + k].float()).abs()
@@ -1259,7 +1264,7 @@ def test_swin_block_elementwise_dropout_vs_oracle(C, window, shift, D, H, W):
     assert float((y0 - y.detach()).abs().max()) > 1e-3
 
 
-def test_swin_encoder_dropout_module_flags_and_split_refusal(monkeypatch):
+def test_swin_encoder_dropout_module_flags_and_split_refusal(set_opt):
     """Swin_3D(drop_rate, attn_drop_rate): training forward / backward run with fresh masks per step (two steps differ), eval is
     deterministic and equals the rate-0 encoder; the split-precision kernels refuse dropout with a clear error."""
     from idee_amd.models.encoder.Swin_3D import Swin_3D
@@ -1278,7 +1283,7 @@ def test_swin_encoder_dropout_module_flags_and_split_refusal(monkeypatch):
     with torch.no_grad():
         torch.testing.assert_close(enc(x), ref(x), atol=0, rtol=0)
     enc.train()
-    monkeypatch.setenv("IDEE_SWIN_MATH", "split")
+    set_opt("IDEE_SWIN_MATH", "split")
     with pytest.raises(L.IdeeHipError, match="dropout"):
         enc(x)
 

@@ -25,6 +25,21 @@ def test_library_exports_every_declared_symbol():
     assert _lib.last_error() == ""
 
 
+def test_option_table_set_get_restore():
+    """idee_set_option / idee_get_option (no launch involved): values stick, "" / None reset, unknown names are refused."""
+    from idee_amd import _lib
+    before = _lib.get_option("IDEE_SWIN_MATH")
+    with _lib.options(IDEE_SWIN_MATH="f22", IDEE_CONV_HRUN=8):
+        assert _lib.get_option("IDEE_SWIN_MATH") == "f22" and _lib.get_option("IDEE_CONV_HRUN") == "8"
+        _lib.set_option("IDEE_SWIN_MATH", None)
+        assert _lib.get_option("IDEE_SWIN_MATH") == ""
+    assert _lib.get_option("IDEE_SWIN_MATH") == before and _lib.get_option("IDEE_CONV_HRUN") == ""
+    with pytest.raises(_lib.IdeeHipError, match="unknown option"):
+        _lib.set_option("IDEE_NO_SUCH_SWITCH", "1")
+    with pytest.raises(_lib.IdeeHipError, match="too long"):
+        _lib.set_option("IDEE_SWIN_MATH", "x" * 40)
+
+
 def test_config_surface_equals_reference():
     import argparse
     from idee_amd import config
