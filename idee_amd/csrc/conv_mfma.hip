@@ -613,7 +613,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
           if constexpr (GSC) {
             float am = 0.f;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) am = fmaxf(am, fmaxf(amax4(xa[m]), amax4(xb[m])));
+            for (int m = 0; m < MT; ++m) am = amax_acc(amax_acc(am, xa[m]), xb[m]);
             if (gs.set ? __any(am * gs.s() >= 256.f) : __any(am > 0.f)) {
               const int k0 = gs.k;
               const bool was = gs.set;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
           if constexpr (ASC) {
             float am = 0.f;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) am = fmaxf(am, fmaxf(amax4(xa[m]), amax4(xb[m])));
+            for (int m = 0; m < MT; ++m) am = amax_acc(amax_acc(am, xa[m]), xb[m]);
             if (ag.exceeds(am)) {         // (rare: |x| >= 2^15 at the chunk's scale)
               const int dk = ag.lower(wave_umax(__float_as_uint(ActGuard::finite(am))));
               const float f = pow2i(dk < -126 ? -126 : dk);
@@ -1357,28 +1357,37 @@ constexpr int kSplitRowW = 2 * kC16Row * 4;     // 32-bit words of one staged ro
 // SC = SC_ACT (f16 pieces, forward modes): the staged ACTIVATION rows are range-guarded instead (common.h ActGuard): split as they
 // are (k = 0) until a staged row's largest |x| reaches 2^15, then the unit's rows carry 2^k, k < 0, through the same restaging
 // path — an input of any finite magnitude keeps two normal f16 pieces.
-template <int MODE, bool F16, int SC = SC_NONE>
+// NB output blocks per wave (one input block; blockIdx.z picks the group of NB blocks: 16 -> 16 NB gridDim.z channels, the
+// weights of all NB blocks in registers) and KTS temporal taps of the zero-padded forward mode: NB = 3, KTS = 1 is the (1,3,3)
+// sign-field forward 16 -> 96 (K = 9 taps x 16 channels in 5 tap pairs, 3 piece products each; its f32 kernel ran at 80 TFLOP/s
+// for a launch whose memory time is a quarter of that).
+template <int MODE, bool F16, int SC = SC_NONE, int NB = 1, int KTS = 2>
 __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
   constexpr bool GSC = SC == SC_GRAD, ASC = SC == SC_ACT;
   static_assert(!GSC || (F16 && (MODE == DGRAD_REP || MODE == DGRAD_S2)), "gradient scale: f16 pieces, data-gradient modes");
   static_assert(!ASC || (F16 && (MODE == FWD_REP || MODE == FWD_S2)), "activation guard: f16 pieces, forward modes");
+  static_assert(NB == 1 || MODE == FWD_S2, "several output blocks per wave: zero-padded forward mode");
   constexpr int MT = 2;
   constexpr bool REP = MODE == FWD_REP || MODE == DGRAD_REP;
-  constexpr int TSN = REP ? 3 : (MODE == FWD_S2 ? 2 : 1);
+  constexpr int TSN = REP ? 3 : (MODE == FWD_S2 ? KTS : 1);
   constexpr int NTAP = TSN * 9, NPAIR = (NTAP + 1) / 2;
-  __shared__ __attribute__((aligned(16))) unsigned s_xw[4][2 * 9 * kSplitRowW];   // [piece][T-slot * 3 + ring slot][row]
+  constexpr int PIECE = 3 * TSN * kSplitRowW;     // words between the hi and the lo piece image of a wave's ring
+  __shared__ __attribute__((aligned(16))) unsigned s_xw[4][2 * PIECE];   // [piece][T-slot * 3 + ring slot][row]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
+  const int gb0 = blockIdx.z * NB;     // first output block of this workgroup
   unsigned* s_x = s_xw[wave];
-  u32x4 wh[NPAIR], wl[NPAIR];       // A fragments of a tap pair: [piece of tap a | piece of tap b]
+  u32x4 wh[NPAIR][NB], wl[NPAIR][NB];       // A fragments of a tap pair: [piece of tap a | piece of tap b]
   int wkey = -1;
-  const float* wp = a.wp + (long)wset * a.ntaps * 256;
+  // packed layout [tap][input block][output block][lane][4]: one input block here, so a tap is GnTot fragments
+  const int wtap = NB == 1 ? 256 : a.GnTot * 256;     // (NB = 1: the 16 -> 16 convolutions, one output block in all)
+  const float* wp = a.wp + (long)wset * a.ntaps * wtap;
   // power-of-two weight scale (f16 pieces only): max |w| of this weight set lands in [2^13, 2^14)
   float wscale = 1.f, winv = 1.f;
   if (F16) {
     float mx = 0.f;
-    for (int tp = 0; tp < a.ntaps; ++tp) {
+    for (int tp = 0; tp < (NB == 1 ? a.ntaps : a.ntaps * a.GnTot); ++tp) {
       const f32x4 f = ld4(wp + tp * 256 + lane * 4);
       mx = fmaxf(fmaxf(mx, fmaxf(fabsf(f[0]), fabsf(f[1]))), fmaxf(fabsf(f[2]), fabsf(f[3])));
     }
@@ -1444,7 +1453,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
 #pragma unroll
       for (int ot = 0; ot < TSN; ++ot)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) am = fmaxf(am, amax4(stg[ot][k]));
+        for (int k = 0; k < 3; ++k) am = amax_acc(am, stg[ot][k]);
       return am;
     };
 
@@ -1508,7 +1517,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
               const int o = ((u & 3) >> 1) * (kC16Row * 4) + (u >> 2) * 4 + (u & 1) * 2;
               typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
               *reinterpret_cast<u32x2v*>(dst + o) = u32x2v{p.h01, p.h23};
-              *reinterpret_cast<u32x2v*>(dst + 9 * kSplitRowW + o) = u32x2v{p.l01, p.l23};
+              *reinterpret_cast<u32x2v*>(dst + PIECE + o) = u32x2v{p.l01, p.l23};
             }
           }
         }
@@ -1520,24 +1529,28 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
         if (key != wkey) {
           wkey = key;
 #pragma unroll
-          for (int pr = 0; pr < NPAIR; ++pr) {
-            Split sa, sb = {0u, 0u, 0u, 0u};
-            {
-              const int tp = 2 * pr, ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
-              sa = split2<F16>(ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * 256 + lane * 4) * wscale);
+          for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+              Split sa, sb = {0u, 0u, 0u, 0u};
+              {
+                const int tp = 2 * pr, ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
+                sa = split2<F16>(ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * wtap + (gb0 + n) * 256 + lane * 4) * wscale);
+              }
+              if (2 * pr + 1 < NTAP) {
+                const int tp = 2 * pr + 1, ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
+                sb = split2<F16>(ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * wtap + (gb0 + n) * 256 + lane * 4) * wscale);
+              }
+              wh[pr][n] = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
+              wl[pr][n] = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
             }
-            if (2 * pr + 1 < NTAP) {
-              const int tp = 2 * pr + 1, ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
-              sb = split2<F16>(ld4(wp + ((st[ot].tap * 3 + sh[oh].tap) * 3 + ow) * 256 + lane * 4) * wscale);
-            }
-            wh[pr] = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
-            wl[pr] = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
-          }
         }
       }
-      f32x4 acc[MT];
+      f32x4 acc[MT][NB];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       // word address of (T-slot ot, tap row oh, pixel shift ow) for this lane, piece 0, tile 0
       auto addr = [&](int tp) __attribute__((always_inline)) {
         const int ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
@@ -1551,8 +1564,8 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
         for (int m = 0; m < MT; ++m) {
           const int mo = m ? blk1 * 4 : 0;
           const u32x2v ha = *reinterpret_cast<const u32x2v*>(s_x + aa + mo), hb = *reinterpret_cast<const u32x2v*>(s_x + ab + mo);
-          const u32x2v la = *reinterpret_cast<const u32x2v*>(s_x + 9 * kSplitRowW + aa + mo),
-                       lb = *reinterpret_cast<const u32x2v*>(s_x + 9 * kSplitRowW + ab + mo);
+          const u32x2v la = *reinterpret_cast<const u32x2v*>(s_x + PIECE + aa + mo),
+                       lb = *reinterpret_cast<const u32x2v*>(s_x + PIECE + ab + mo);
           bh[m] = u32x4{ha[0], ha[1], hb[0], hb[1]};
           bl[m] = u32x4{la[0], la[1], lb[0], lb[1]};
         }
@@ -1563,11 +1576,14 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
       for (int pr = 0; pr < NPAIR; ++pr) {
         if (pr + 1 < NPAIR) rd(pr + 1, bh[(pr + 1) & 1], bl[(pr + 1) & 1]);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma_s<F16>(wh[pr], bh[pr & 1][m], acc[m]);
+        for (int n = 0; n < NB; ++n) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma_s<F16>(wh[pr], bl[pr & 1][m], acc[m]);
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wh[pr][n], bh[pr & 1][m], acc[m][n]);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma_s<F16>(wl[pr], bh[pr & 1][m], acc[m]);
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wh[pr][n], bl[pr & 1][m], acc[m][n]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wl[pr][n], bh[pr & 1][m], acc[m][n]);
+        }
       }
       // epilogue (as conv16_lds_kernel; the f16 weight scale is taken out first)
       float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
@@ -1580,10 +1596,12 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
         int wdst = p;
         bool atomic = false;
         if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
-        f32x4 v = F16 ? acc[m] * (GSC ? winv * gs.inv() : ASC ? winv * ag.inv() : winv) : acc[m];
-        if (a.bias) v += ld4(a.bias + (long)wset * 16 + 4 * kq);
+#pragma unroll
+       for (int n = 0; n < NB; ++n) {
+        f32x4 v = F16 ? acc[m][n] * (GSC ? winv * gs.inv() : ASC ? winv * ag.inv() : winv) : acc[m][n];
+        if (a.bias) v += ld4(a.bias + (NB == 1 ? (long)wset * 16 : (long)wset * a.GnTot * 16 + (gb0 + n) * 16) + 4 * kq);
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const long o = (long)wdst * a.o_sW + 4 * kq;
+        const long o = (long)wdst * a.o_sW + 4 * kq + (NB == 1 ? 0 : goff(gb0 + n, a.o_gpu, a.o_sU, a.o_sG));
         if (ref_r) {
           const f32x4 rr = ld4(ref_r + o);
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
@@ -1596,6 +1614,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
           if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
           st4(out_r + o, v);
         }
+       }
       }
       ++h;
     }
@@ -1995,6 +2014,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
         }
       int slot_of[3];
       bool redo = false;
+      int redo_dk = 0;
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) {
         const int hs = MODE == FWD_REP ? min(max(h + oh - 1, 0), a.H - 1) : h + oh - 1;
@@ -2025,21 +2045,18 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
 #pragma unroll
           for (int ot = 0; ot < TSL; ++ot)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) am = fmaxf(am, amax4(stg[ot][k]));
+            for (int k = 0; k < 3; ++k) am = amax_acc(am, stg[ot][k]);
           if (ag.exceeds(am)) {             // (rare: |x| >= 2^15 at the unit's scale) lower the scale, stage the ring again
-            const int dk = ag.lower(wave_umax(__float_as_uint(ActGuard::finite(am))));
-            scale_acc(pow2i(dk < -126 ? -126 : dk));
+            redo_dk = ag.lower(wave_umax(__float_as_uint(ActGuard::finite(am))));
             res0 = res1 = res2 = -1;
             redo = true;
             break;
           }
-          if (ag.k != 0) {                  // wave-uniform
-            const float xsc = ag.s();
+          const float xsc = ag.s();         // (1 unless the guard has fired in this unit)
 #pragma unroll
-            for (int ot = 0; ot < TSL; ++ot)
+          for (int ot = 0; ot < TSL; ++ot)
 #pragma unroll
-              for (int k = 0; k < 3; ++k) stg[ot][k] *= xsc;
-          }
+            for (int k = 0; k < 3; ++k) stg[ot][k] *= xsc;
         }
 #pragma unroll
         for (int ot = 0; ot < TSL; ++ot) {
@@ -2056,13 +2073,16 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
           }
         }
       }
-      if (F16 && redo) continue;          // (h not advanced: the row's ring is staged again at the new scale)
+      if (F16 && redo) {                  // (h not advanced: the row's ring is staged again at the new scale, which the
+        scale_acc(pow2i(redo_dk < -126 ? -126 : redo_dk));   //  accumulators follow)
+        continue;
+      }
 #pragma unroll
       for (int n = 0; n < NB; ++n) bsum[n] += hsum4(d0[n]) + hsum4(d1[n]);
       if constexpr (F16) {
         float am = 0.f;
 #pragma unroll
-        for (int n = 0; n < NB; ++n) am = fmaxf(am, fmaxf(amax4(d0[n]), amax4(d1[n])));
+        for (int n = 0; n < NB; ++n) am = amax_acc(amax_acc(am, d0[n]), d1[n]);
         const float f = gs.update(wave_umax(__float_as_uint(am)));
         if (f != 1.f) scale_acc(f);
         const float gsc = gs.s();
@@ -2376,7 +2396,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
 #pragma unroll
       for (int i = 0; i < XU; ++i) {
         if (xd[i] < 0) continue;
-        const Split p = split2<PM_F16X2>(ag.k != 0 ? xr[i] * xsc : xr[i]);
+        const Split p = split2<PM_F16X2>(xr[i] * xsc);
         unsigned* d = dst + xd[i];
         *reinterpret_cast<u32x2v*>(d) = u32x2v{p.h01, p.h23};
         *reinterpret_cast<u32x2v*>(d + 8) = u32x2v{p.l01, p.l23};
@@ -2394,7 +2414,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
     auto x_amax = [&](const f32x4 (&xv)[XU]) __attribute__((always_inline)) {
       float am = 0.f;
 #pragma unroll
-      for (int i = 0; i < XU; ++i) am = fmaxf(am, amax4(xv[i]));
+      for (int i = 0; i < XU; ++i) am = amax_acc(am, xv[i]);
       return ActGuard::finite(am);
     };
     auto wg_max = [&](const unsigned (&red)[WAVES]) __attribute__((always_inline)) {
@@ -2403,21 +2423,27 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
       for (int w = 0; w < WAVES; ++w) m = m > red[w] ? m : red[w];
       return m;
     };
-    {   // unit start: rows h0 - 1 and h0 into the ring, at the unit's own guard scale (k = 0 unless they hold |x| >= 2^15)
-      if (ag.k != 0) {                               // (workgroup-uniform) a new unit starts unguarded again
-        scale_acc(pow2i(-ag.k < 126 ? -ag.k : 126));
-        ag = ActGuard();
-      }
-      load_x(h0 - 1, xr); load_x(h0, xr2);
+    if (ag.k != 0) {                                 // (workgroup-uniform) a new unit starts unguarded again
+      scale_acc(pow2i(-ag.k < 126 ? -ag.k : 126));
+      ag = ActGuard();
+    }
+    // A unit is walked in one segment — or, when the guard fires for a row (workgroup-uniform, rare), begun again from that row
+    // at the lower scale through the same segment-start code.
+    int pend_dk = 0;
+    for (int hb = h0;;) {
+    bool again = false;
+    {   // segment start: rows hb - 1 and hb into the ring, at the unit's guard scale (k = 0 unless they hold |x| >= 2^15)
+      if (pend_dk != 0) { scale_acc(pow2i(imax_dev(pend_dk, -126))); pend_dk = 0; }
+      load_x(hb - 1, xr); load_x(hb, xr2);
       const unsigned wm0 = wave_umax(__float_as_uint(fmaxf(x_amax(xr), x_amax(xr2))));
       if (lane == 0) s_redx0[wave] = wm0;
-      __syncthreads();                               // the previous unit's readers are done; s_redx0 holds the two rows' maxima
+      __syncthreads();                               // the previous readers are done; s_redx0 holds the two rows' maxima
       const unsigned m0 = wg_max(s_redx0);
       if (__uint_as_float(m0) >= ag.thr) scale_acc(pow2i(imax_dev(ag.lower(m0), -126)));
-      store_x(h0 - 1, xr);
-      store_x(h0, xr2);
-      load_x(h0 + 1, xr);  load_dy(h0, dv);
-      load_x(h0 + 2, xr2); load_dy(h0 + 1, dv2);
+      store_x(hb - 1, xr);
+      store_x(hb, xr2);
+      load_x(hb + 1, xr);  load_dy(hb, dv);
+      load_x(hb + 2, xr2); load_dy(hb + 1, dv2);
     }
     // the row's largest |dy| (and the largest |x| of the x row staged with it) goes to s_red / s_redx right after the MFMAs of
     // the row before (its loads have landed by then), so ONE barrier both retires the previous row's readers and publishes
@@ -2425,13 +2451,13 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
     auto post_amax = [&]() __attribute__((always_inline)) {
       float am = 0.f;
 #pragma unroll
-      for (int i = 0; i < DYU; ++i) am = fmaxf(am, amax4(dv[i]));
+      for (int i = 0; i < DYU; ++i) am = amax_acc(am, dv[i]);
       const unsigned wm = wave_umax(__float_as_uint(am));
       const unsigned wx = wave_umax(__float_as_uint(x_amax(xr)));
       if (lane == 0) { s_red[wave] = wm; s_redx[wave] = wx; }
     };
     post_amax();
-    for (int h = h0; h < h1; ++h) {
+    for (int h = hb; h < h1; ++h) {
       __syncthreads();                               // the previous row's readers are done; s_red / s_redx hold this row's maxima
       int slot_of[3];
       bool ok_h[3];
@@ -2444,10 +2470,10 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
       {
         const unsigned mx = wg_max(s_redx);
         if (__uint_as_float(mx) >= ag.thr) {         // (workgroup-uniform, rare) row h + 1 holds |x| >= 2^15 at the unit's scale:
-          scale_acc(pow2i(imax_dev(ag.lower(mx), -126)));   // lower it, stage rows h - 1 and h again (xr2 lends its registers)
-          load_x(h - 1, xr2); store_x(h - 1, xr2);
-          load_x(h, xr2);     store_x(h, xr2);
-          load_x(h + 2, xr2);
+          pend_dk = ag.lower(mx);                    // lower it and begin the segment again at row h (the accumulators
+          hb = h;                                    // follow at the segment start)
+          again = true;
+          break;
         }
       }
       store_x(h + 1, xr);                            // (row h + 1 replaces row h - 2 in the ring)
@@ -2520,6 +2546,8 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
         }
       }
       if (h + 1 < h1) post_amax();
+    }
+    if (!again) break;
     }
   }
   float* dw = a.dwp + (long)(blockIdx.x % kWgradCopies) * a.copy_stride + (long)wset * a.ntaps * a.Cin * a.CoutPad;
@@ -3050,6 +3078,23 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       auto kern = conv16_lds_kernel<MODE>;
       const dim3 grid(one_round(cdiv(nunits, 4), a.wsets, wg_per_cu(kern, 256)), a.wsets);
       hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
+      return IDEE_OK;
+    }
+  }
+  if constexpr (MODE == FWD_S2) {
+    // (1,3,3) forward from ONE input block into 3 n output blocks (the sign-field convs 16 -> 96 / 192) on f16 pieces: the strip
+    // kernel with the weights of 3 output blocks per wave in registers, grid.z = n
+    if (!cin1 && conv_split_math(true) && a.Gk == 1 && a.kt == 1 && a.GnTot % 3 == 0 && a.cout_real == 16 * a.GnTot && !a.w_tap_stride &&
+        !a.addend_first) {
+      const int nstrip = cdiv(cdiv(a.Wo, 16), 2);
+      const long bt = (long)(a.B / a.wsets) * a.To;
+      const int gzs = a.GnTot / 3;
+      const int hrun = pick_hrun(a.Ho, bt * nstrip, (long)a.wsets * gzs, 2);
+      const int nhrun = cdiv(a.Ho, hrun);
+      const long nunits = bt * nhrun * nstrip;
+      auto kern = conv16_split_kernel<FWD_S2, true, SC_ACT, 3, 1>;
+      const dim3 grid(one_round(cdiv(nunits, 4), (long)a.wsets * gzs, wg_per_cu(kern, 256)), a.wsets, gzs);
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, a, nstrip, hrun, nhrun);
       return IDEE_OK;
     }
   }

@@ -44,6 +44,8 @@ class ClipWindowDataset(torch.utils.data.Dataset):
         mask_extreme_loss (H, W)   uint8: any extreme inside the window
         mask_anomaly (V, delta_t, H, W), tstep (1,)"""
 
+    item_layout = "synthetic"      # what PrefetchLoader batches (it does not load an item to find out)
+
     def __init__(self, dynamic, static, time, timestep, extreme, anomaly, delta_t=8, is_aug=False, rng=None):
         self.dynamic, self.static, self.time, self.timestep = dynamic, static, time, timestep
         self.extreme, self.anomaly = extreme, anomaly
@@ -91,6 +93,8 @@ class ERA5ClipDataset(torch.utils.data.Dataset):
     __generate_mask does, :417-484: VHI = nanmean_files(alpha VCI + (1 - alpha) TCI)); mean_var / std_var (V,) (:579-581)
     or, with `clima=(mean, std)` arrays (V, 2, T_total, H, W) in the cube's week order, the per-pixel climatology scaling
     (:573-577)."""
+
+    item_layout = "era5"
 
     def __init__(self, dynamic, vci, tci, cold, mask_water, mask_no_vegetation, mean_var=None, std_var=None, clima=None,
                  delta_t=8, threshold=26.0, alpha=0.5, nan_fill=0.0, is_norm=True, is_aug=False, names=None, rng=None):
@@ -160,7 +164,8 @@ class ERA5ClipDataset(torch.utils.data.Dataset):
 class PrefetchLoader:
     """Device batches produced `depth` batches ahead by a worker thread through pinned buffers and a side stream.
     rank / world shard the (shuffled) index list like a DistributedSampler with drop_last over ranks.  Two item layouts
-    (detected from the dataset's first item):
+    (`layout=` argument, else the dataset's `item_layout` attribute, else told from the first item the worker loads — the
+    constructor never loads an item: no IO and no draw from an augmenting dataset's RNG before the first batch):
       synthetic  (SyntheticClipDataset items) -> (x_d (B,V,1,T,H,W) f32, mask_extreme (B,H,W), mask_extreme_loss (B,H,W),
                  timestep (B,) int64)                      — what train_synthetic.py:171-177 moves to the device;
       era5       (ERA5ClipDataset 8-tuples)   -> (x_d (B,V,2,T,H,W) f32, mask_drought (B,H,W), mask_drought_loss (B,H,W),
@@ -168,15 +173,21 @@ class PrefetchLoader:
     each a tuple harness.train_epoch hands to SyntheticTrainStep / ERA5TrainStep (the last element is the time step index
     for the anomaly collector, None for ERA5 whose items carry a file name instead)."""
 
-    def __init__(self, dataset, batch_size, device, shuffle=True, drop_last=True, seed=0, rank=0, world=1, depth=2):
+    def __init__(self, dataset, batch_size, device, shuffle=True, drop_last=True, seed=0, rank=0, world=1, depth=2, layout=None):
         self.ds, self.bs, self.device = dataset, int(batch_size), torch.device(device)
         self.shuffle, self.drop_last, self.seed, self.rank, self.world, self.depth = shuffle, drop_last, seed, rank, world, depth
         self.epoch = 0
         self.cuda = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(self.device) if self.cuda else None
-        first = dataset[0]
-        self.layout = "era5" if (len(first) == 8 and isinstance(first[-1], str)) else "synthetic"
-        # (index in the item, leading-dims-free shape, dtype) of every tensor of a batch
+        self.layout = layout or getattr(dataset, "item_layout", None)
+        if self.layout not in (None, "synthetic", "era5"):
+            raise ValueError(f"PrefetchLoader: layout must be 'synthetic' or 'era5', got {self.layout!r}")
+        self.fields = None          # set from the first item of the first batch (_describe)
+
+    def _describe(self, first):
+        """(index in the item, leading-dims-free shape, dtype) of every tensor of a batch, from an item already loaded."""
+        if self.layout is None:
+            self.layout = "era5" if (len(first) == 8 and isinstance(first[-1], str)) else "synthetic"
         if self.layout == "era5":
             self.fields = [(0, first[0].shape, torch.float32)] + [(i, first[i].shape, torch.float32) for i in (1, 2, 3, 4)]
         else:
@@ -197,8 +208,7 @@ class PrefetchLoader:
         n = len(self._indices())
         return n // self.bs if self.drop_last else -(-n // self.bs)
 
-    def _collate(self, ids, bufs):
-        items = [self.ds[int(i)] for i in ids]
+    def _collate(self, items, bufs):
         for k, it in enumerate(items):
             for buf, (src, shape, dtype) in zip(bufs, self.fields):
                 if shape == ():
@@ -210,10 +220,9 @@ class PrefetchLoader:
     def __iter__(self):
         idx = self._indices()
         nb = len(self)
-        ring = [tuple(torch.empty((self.bs,) + tuple(shape), dtype=dtype, pin_memory=self.cuda) for _, shape, dtype in self.fields)
-                for _ in range(self.depth + 1)]
+        ring = []                   # pinned staging buffers, allocated by the worker once the first items are loaded
         free, ready = queue.Queue(), queue.Queue(maxsize=self.depth)
-        for r in range(len(ring)):
+        for r in range(self.depth + 1):
             free.put(r)
         stop = threading.Event()
 
@@ -223,7 +232,13 @@ class PrefetchLoader:
                     r = free.get()
                     if stop.is_set():
                         return
-                    n = self._collate(idx[b * self.bs:(b + 1) * self.bs], ring[r])
+                    items = [self.ds[int(i)] for i in idx[b * self.bs:(b + 1) * self.bs]]
+                    if not ring:
+                        if self.fields is None:
+                            self._describe(items[0])
+                        ring.extend(tuple(torch.empty((self.bs,) + tuple(shape), dtype=dtype, pin_memory=self.cuda)
+                                          for _, shape, dtype in self.fields) for _ in range(self.depth + 1))
+                    n = self._collate(items, ring[r])
                     if self.cuda:
                         with torch.cuda.stream(self.stream):
                             dev = tuple(t[:n].to(self.device, non_blocking=True) for t in ring[r])

@@ -70,6 +70,9 @@ class VQ_model(nn.Module):
         self.act_dtype = torch.bfloat16 if ad == "bf16" else torch.float32
         if self.act_dtype == torch.bfloat16 and config.encoder != "Swin_3D":
             raise NotImplementedError("bf16 activation storage is built for the Swin_3D encoder (BASELINE config #4)")
+        if self.act_dtype == torch.bfloat16 and (config.en_drop_rate > 0 or config.en_attn_drop_rate > 0):
+            raise NotImplementedError("element-wise dropout inside the Swin block (en_drop_rate / en_attn_drop_rate > 0) is built for f32 "
+                                      "activation storage only; with config.act_dtype = 'bf16' set both rates to 0")
         self.encoder.act_dtype = self.act_dtype
         # IDEE_SIGN_FIELD=0 runs the classifier on z_q itself, convolution for convolution as build.py:157
         self.sign_field_classifier = os.environ.get("IDEE_SIGN_FIELD", "1") != "0" and self.codebook_impl == "LFQ"

@@ -87,6 +87,33 @@ def test_prefetch_loader_cpu_batches_and_sharding():
     assert [b[0].shape[0] for b in l4] == [5, 5, 2]
 
 
+def test_prefetch_loader_constructor_loads_no_item():
+    """Building the loader reads nothing from the dataset (no IO, no draw from an augmenting dataset's RNG): the batches of a
+    seeded augmenting dataset equal the items drawn in loader order from a twin dataset with the same seed."""
+    class Counting(ClipWindowDataset):
+        loads = 0
+
+        def __getitem__(self, i):
+            Counting.loads += 1
+            return super().__getitem__(i)
+    c = synthetic_cube(V=2, T_total=14, H=6, W=6, seed=4)
+    ds = Counting(**c, delta_t=8, is_aug=True, rng=np.random.RandomState(7))
+    ld = PrefetchLoader(ds, batch_size=2, device="cpu", shuffle=False)
+    assert Counting.loads == 0 and ld.layout == "synthetic"
+    twin = ClipWindowDataset(**c, delta_t=8, is_aug=True, rng=np.random.RandomState(7))
+    k = 0
+    for x, me, ml, ts in ld:
+        for j in range(x.shape[0]):
+            item = twin[k]
+            assert torch.equal(x[j], torch.from_numpy(item[0])) and int(ts[j]) == int(item[6][0])
+            k += 1
+    assert k == Counting.loads == 6
+    # an explicit layout overrides; an unknown one is refused
+    assert PrefetchLoader(ds, batch_size=2, device="cpu", layout="era5").layout == "era5"
+    with pytest.raises(ValueError):
+        PrefetchLoader(ds, batch_size=2, device="cpu", layout="netcdf")
+
+
 def test_prefetch_loader_worker_error_surfaces():
     class Bad(ClipWindowDataset):
         def __getitem__(self, i):

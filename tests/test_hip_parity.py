@@ -117,7 +117,7 @@ def test_swin_block_golden(tag, kernel_variant):
         gclose("d" + n, p.grad[0], grads[n])
 
 
-@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows", "ragged_windows"])
+@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows", "ragged_windows", "huge_x"])
 def test_swin_f22_error_against_float64(profile, set_opt):
     """IDEE_SWIN_MATH=f22 (every GEMM of the block on two f16 pieces per operand, weights prescaled by powers of two, the
     incoming gradient scaled per 32-token work item) measured against a FLOAT64 evaluation of the oracle, beside the exact-f32
@@ -127,18 +127,22 @@ def test_swin_f22_error_against_float64(profile, set_opt):
     all-zero frames in between (scale changes in both directions inside a wave, zero tiles, the +40 clamp); `ragged_windows`:
     one magnitude per (batch item, pair of frames of a shifted window) over 12 decades, one pair all zero — every work item
     of both backward kernels is then homogeneous, so each frame's gradient must come out at f32 level RELATIVE TO ITS OWN
-    MAGNITUDE (what a per-launch scale could not give).
+    MAGNITUDE (what a per-launch scale could not give).  `huge_x`: block inputs of magnitude 1e5 with rows of 1e-3 between them
+    (every GEMM operand of the block is an image of a LayerNorm output under the block's own weights, so no activation operand
+    can leave f16's range whatever the input's magnitude: the f16 pieces need no activation guard here, unlike the convolutions).
     Asserted: relative L2 error of y, dx and every parameter gradient within 4x the exact-f32 kernels' own error (+ 2e-7);
     for `loss_scale` / `ragged_windows` also the branch gradient dx - dy of every frame (n, d) against that frame's largest
     |dy|: within 4x the exact kernels' worst frame (+ 1e-7)."""
     from oracle import idee_oracle as O
     ops = _ops()
-    g = torch.Generator().manual_seed({"loss_scale": 5, "ragged_rows": 11, "ragged_windows": 13}[profile])
+    g = torch.Generator().manual_seed({"loss_scale": 5, "ragged_rows": 11, "ragged_windows": 13, "huge_x": 17}[profile])
     N, D, H, W, C, NH = 2, 8, 24, 40, 16, 2
     window, shift = (2, 4, 4), (1, 2, 2)
     x = torch.randn((N, 1, D, H, W, C), generator=g) * 1.5
     r = torch.randn((N, 1, D, H, W, C), generator=g)
-    if profile == "loss_scale":
+    if profile == "huge_x":
+        x = x * torch.where(torch.rand((N, 1, D, H, 1, 1), generator=g) < 0.7, 1e5, 1e-3)
+    if profile in ("loss_scale", "huge_x"):
         r = r * 1e-7
     elif profile == "ragged_rows":
         mag = 10.0 ** (torch.rand((N, 1, D, H, 1, 1), generator=g) * 15.0 - 14.0)
@@ -191,7 +195,7 @@ def test_swin_f22_error_against_float64(profile, set_opt):
         e = {m: rel(res[m][k], ref[k]) for m in res}
         print(f"  {k:38s} {e['f32']:.2e}  {e['f22']:.2e}  {e['split']:.2e}")
         assert e["f22"] <= 4.0 * e["f32"] + 2e-7, (k, e)
-    if profile == "ragged_rows":
+    if profile in ("ragged_rows", "huge_x"):
         return
     e32, scale = frame_err(res["f32"])
     e22, _ = frame_err(res["f22"])
@@ -317,14 +321,27 @@ def test_proj_var_vs_oracle(T, H, W, set_opt, kernel_variant):
         gclose(n, a_.grad, b_.grad)
 
 
-@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows"])
+def _row_ties(rec, dims):
+    """relu_record.ties() with the tie threshold relative to the mean |a| of each ROW (reduced over `dims`) instead of the whole
+    tensor: for inputs whose rows differ by many decades a quiet row is not a tie just because another row is large."""
+    from conftest import TIE_REL
+    rec.ties = lambda: sum(int((t.abs() < TIE_REL * t.abs().mean(dim=dims, keepdim=True)).sum()) for t in rec.inputs)
+    return rec
+
+
+@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows", "huge_x", "ragged_x"])
 def test_conv_f22_error_against_float64(profile, set_opt):
     """IDEE_CONV_MATH=f22 (3^3 replicate convs: forward, data gradient and weight gradient on two f16 pieces per operand; weights
     prescaled per set, dy scaled by a power of two per work unit / per row) against a FLOAT64 evaluation of the oracle's
     proj_var, beside the exact-f32 kernels and the bf16-piece backward (IDEE_CONV_MATH=split) on the same inputs.
     `loss_scale`: upstream gradient 1e-7; `ragged_rows`: one magnitude per (n, v, t, h) row over 12 decades, two all-zero
     frames (the data gradient's scale moves down inside a unit and rows are begun again; the weight gradient's accumulators
-    are rescaled in both directions).  Asserted: relative L2 error of y, dx and the four parameter gradients within 4x the
+    are rescaled in both directions).  `huge_x`: activations of magnitude 3e5 (an unguarded f16 hi piece is inf from 65520 on:
+    the forward and weight-gradient kernels' activation range guard, common.h ActGuard, must fire in every work unit);
+    `ragged_x`: one activation magnitude per (n, v, t, h) row over 9 decades, 1e-2 .. 1e7, and one batch item at magnitude 1
+    (the guard fires in the middle of units, moves down more than once, rows are staged again; units of the quiet item stay
+    unguarded) — there the quiet item's outputs must also come out at f32 level relative to THEIR OWN magnitude.
+    Asserted: relative L2 error of y, dx and the four parameter gradients within 4x the
     exact kernels' own error (+ 2e-7).  The case is ReLU-tie-free (float64 and f32 masks agree)."""
     from oracle import idee_oracle as O
     ops = _ops()
@@ -336,10 +353,16 @@ def test_conv_f22_error_against_float64(profile, set_opt):
         r = torch.randn((N, V, T, H, W, C), generator=g)
         if profile == "loss_scale":
             r = r * 1e-7
-        else:
+        elif profile == "ragged_rows":
             r = r * 10.0 ** (torch.rand((N, V, T, H, 1, 1), generator=g) * 12.0 - 11.0)
             r[0, 0, 1] = 0.0
             r[1, 1, 2] = 0.0
+        elif profile == "huge_x":
+            x = x * 3e5
+        else:
+            mag = 10.0 ** (torch.rand((N, V, T, H, 1, 1), generator=g) * 9.0 - 2.0)
+            mag[1] = 1.0                          # item 1: every frame quiet (its units never see a large row)
+            x = x * mag
         w1, w2 = (torch.randn((V, C, C, 3, 3, 3), generator=g) * 0.05 for _ in range(2))
         b1, b2 = (torch.randn((V, C), generator=g) * 0.1 for _ in range(2))
         leaves = [t.double().requires_grad_() for t in (x, w1, b1, w2, b2)]
@@ -348,9 +371,11 @@ def test_conv_f22_error_against_float64(profile, set_opt):
             for v in range(V):
                 sd = {"0.weight": leaves[1][v], "0.bias": leaves[2][v], "2.weight": leaves[3][v], "2.bias": leaves[4][v]}
                 outs.append(O.proj_var(leaves[0][:, v].permute(0, 4, 1, 2, 3), sd, "").permute(0, 2, 3, 4, 1))
+        if profile == "ragged_x":
+            _row_ties(rec, (1, 4))            # (N, C, T, H, W) pre-activations: one scale per (n, t, h) row
         return ((x, w1, b1, w2, b2), r, leaves, torch.stack(outs, 1)), rec
 
-    (x, w1, b1, w2, b2), r, leaves, y64 = tie_free_case(build, range(500, 508), f"proj_var f64 {profile}")
+    (x, w1, b1, w2, b2), r, leaves, y64 = tie_free_case(build, range(500, 516), f"proj_var f64 {profile}")
     assert y64.dtype == torch.float64
     (y64 * r.double()).sum().backward()
     names = ("dx", "dw1", "db1", "dw2", "db2")
@@ -373,13 +398,20 @@ def test_conv_f22_error_against_float64(profile, set_opt):
         e = {m: float((res[m][k] - ref[k]).norm() / ref[k].norm()) for m in res}
         print(f"  {k:6s} {e['f32']:.2e}  {e['f22']:.2e}  {e['split']:.2e}")
         assert e["f22"] <= 4.0 * e["f32"] + 2e-7, (k, e)
+    if profile == "ragged_x":       # the quiet item: its own relative error, not the batch's
+        q = {m: float((res[m]["y"][1] - ref["y"][1]).norm() / ref["y"][1].norm()) for m in res}
+        qd = {m: float((res[m]["dx"][1] - ref["dx"][1]).norm() / ref["dx"][1].norm()) for m in res}
+        print(f"  quiet item alone: y {q['f32']:.2e} / {q['f22']:.2e}, dx {qd['f32']:.2e} / {qd['f22']:.2e} (exact / f22)")
+        assert q["f22"] <= 4.0 * q["f32"] + 2e-7 and qd["f22"] <= 4.0 * qd["f32"] + 2e-7, (q, qd)
 
 
-@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows"])
+@pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows", "huge_x", "ragged_x"])
 def test_classifier_f22_error_against_float64(profile, set_opt):
     """The classifier on z_q (plain path) at V = 6: the 96 -> 96 joint head — conv_wide_split_kernel forward / data gradient and
     wgrad_wide_split_kernel (two 6 x 3 block halves, workgroup-wide row scale) — and the heads' 16 -> 16 (2,3,3) convs under
     IDEE_CONV_MATH=f22, against the oracle's classifier evaluated in FLOAT64, beside the exact-f32 kernels on the same inputs.
+    `huge_x` / `ragged_x`: classifier inputs of magnitude 3e5, resp. one magnitude per (n, h) row over 1e-2 .. 1e7 — the activation
+    range guard of the wide forward, of both weight-gradient kernels and of the heads' 16 -> 16 forward fires (common.h ActGuard).
     Asserted: relative L2 error of the logits, dx and every parameter gradient within 4x the exact kernels' (+ 2e-7).  Tie-free case."""
     from oracle import idee_oracle as O
     from idee_amd.models.classifier.CNN_3D import CNN_3D
@@ -393,16 +425,22 @@ def test_classifier_f22_error_against_float64(profile, set_opt):
         rz, ry = torch.randn(N, 1, H, W), torch.randn(V, N, 1, H, W)
         if profile == "loss_scale":
             rz, ry = rz * 1e-7, ry * 1e-7
-        else:
+        elif profile == "ragged_rows":
             mag = 10.0 ** (torch.rand(N, 1, H, 1) * 12.0 - 11.0)
             rz, ry = rz * mag, ry * mag
+        elif profile == "huge_x":
+            x = x * 3e5
+        else:
+            x = x * 10.0 ** (torch.rand(N, 1, 1, 1, H, 1) * 9.0 - 2.0)
         sdl = {k: v.double().requires_grad_() for k, v in sd.items()}
         xo = x.double().requires_grad_()
         with relu_record() as rec:
             zo, yo = O.classifier(xo, sdl, pre="")
+        if profile == "ragged_x":
+            _row_ties(rec, (1, 2, 4))         # (N, C, T, H, W) pre-activations: one scale per (n, h) row
         return (c, sd, x, rz, ry, sdl, xo, zo, yo), rec
 
-    c, sd, x, rz, ry, sdl, xo, zo, yo = tie_free_case(build, range(900, 912), f"classifier f64 {profile}")
+    c, sd, x, rz, ry, sdl, xo, zo, yo = tie_free_case(build, range(900, 924), f"classifier f64 {profile}")
     assert zo.dtype == torch.float64
     ((zo * rz.double()).sum() + sum((yo[v] * ry[v].double()).sum() for v in range(V))).backward()
     ref = {"z": zo.detach(), "y": torch.stack(yo).detach(), "dx": xo.grad}
@@ -1215,8 +1253,10 @@ def test_swin_block_drop_path_vs_oracle(C, kernel_variant):
 @pytest.mark.parametrize("C,window,shift,D,H,W", [(16, (2, 4, 4), (1, 2, 2), 4, 6, 10), (16, (2, 4, 4), (0, 0, 0), 4, 8, 8),
                                                    (16, (8, 1, 1), (0, 0, 0), 8, 3, 5), (32, (2, 4, 4), (1, 2, 2), 2, 8, 12),
                                                    (32, (8, 1, 1), (4, 0, 0), 16, 2, 3)])
-def test_swin_block_elementwise_dropout_vs_oracle(C, window, shift, D, H, W):
-    """Element-wise dropout INSIDE the fused block (en_drop_rate: Mlp.drop after GELU and after fc2 + proj_drop; en_attn_drop_rate
+@variants('default', 'swin_f22', 'swin_split')
+def test_swin_block_elementwise_dropout_vs_oracle(C, window, shift, D, H, W, kernel_variant):
+    """(Under IDEE_SWIN_MATH = f22 / split a block with a non-zero rate is routed to the exact-f32 kernels, forward and backward.)
+    Element-wise dropout INSIDE the fused block (en_drop_rate: Mlp.drop after GELU and after fc2 + proj_drop; en_attn_drop_rate
     on the attention probabilities; Swin_3D.py:34-41, :138-140, :172, :176): output and every gradient against the oracle run
     with the SAME keep masks (oracle.swin_dropout_masks restates the kernels' counter-based generator; the reference's own
     masks come from torch's Philox stream, so parity is defined given the masks).  Shifted / padded / temporal windows, C = 16
@@ -1264,9 +1304,10 @@ def test_swin_block_elementwise_dropout_vs_oracle(C, window, shift, D, H, W):
     assert float((y0 - y.detach()).abs().max()) > 1e-3
 
 
-def test_swin_encoder_dropout_module_flags_and_split_refusal(set_opt):
+def test_swin_encoder_dropout_module_flags_and_bf16_refusal(set_opt):
     """Swin_3D(drop_rate, attn_drop_rate): training forward / backward run with fresh masks per step (two steps differ), eval is
-    deterministic and equals the rate-0 encoder; the split-precision kernels refuse dropout with a clear error."""
+    deterministic and equals the rate-0 encoder; under IDEE_SWIN_MATH=f22 the dropout blocks run (on the exact kernels); bf16
+    activation storage with a non-zero rate is refused when the MODEL is built."""
     from idee_amd.models.encoder.Swin_3D import Swin_3D
     from idee_amd import _lib as L
     torch.manual_seed(5)
@@ -1283,9 +1324,14 @@ def test_swin_encoder_dropout_module_flags_and_split_refusal(set_opt):
     with torch.no_grad():
         torch.testing.assert_close(enc(x), ref(x), atol=0, rtol=0)
     enc.train()
-    set_opt("IDEE_SWIN_MATH", "split")
-    with pytest.raises(L.IdeeHipError, match="dropout"):
-        enc(x)
+    set_opt("IDEE_SWIN_MATH", "f22")
+    yf = enc(x)
+    yf.sum().backward()
+    assert torch.isfinite(yf).all() and float((yf - y1).abs().max()) > 1e-4
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    with pytest.raises(NotImplementedError, match="dropout"):
+        VQ_model(default_config(encoder="Swin_3D", in_channels=1, act_dtype="bf16", en_drop_rate=0.1))
 
 
 @variants('default', 'swin_split', 'swin_f22')

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Time the bf16 convolution passes of config #4 in isolation (GPU box):  python3 tools/conv_bench.py [k333|k233|k133] [Cin] [Cout] [reps]
+"""Time the bf16 convolution passes of config #4 in isolation (GPU box):
+    python3 tools/conv_bench.py [k333|k233|k133] [Cin] [Cout] [--reps R]
 Shapes: B = 6 weight sets x 1 item, T = 16, 412 x 424 (k133: the heads' 16 -> 192 / 192 -> 16 convs run on T = 8)."""
-import sys, torch
+import argparse, sys, torch
 sys.path.insert(0, ".")
 from idee_amd import ops, _lib as L
 
-name = sys.argv[1] if len(sys.argv) > 1 else "k333"
-Cin = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-Cout = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+ap = argparse.ArgumentParser()
+ap.add_argument("name", nargs="?", default="k333", choices=["k333", "k233", "k133"])
+ap.add_argument("Cin", nargs="?", type=int, default=32)
+ap.add_argument("Cout", nargs="?", type=int, default=32)
+ap.add_argument("--reps", type=int, default=10)      # (an option, so that a wrapper can append it after any number of positionals)
+_a = ap.parse_args()
+name, Cin, Cout, reps = _a.name, _a.Cin, _a.Cout, _a.reps
 dev, BF = "cuda", torch.bfloat16
 mode = dict(k333=L.CONV_K333_REPLICATE, k233=L.CONV_K233_S2_ZERO, k133=L.CONV_K133_ZERO)[name]
 kt = dict(k333=3, k233=2, k133=1)[name]
