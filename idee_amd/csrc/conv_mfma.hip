@@ -433,24 +433,37 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
     }
 
     if (!row_ok) continue;
+    // the NT bias vectors in one batch ahead of the stores (a load between stores waits, through vmcnt(0), for every store
+    // before it: 24 serialized memory round trips per chunk)
+    f32x4 biasv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = a.bias ? ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (!vm[m]) continue;
       const long ro = (long)b * a.o_sB + (long)t * a.o_sT + (long)hm[m] * a.o_sH + (long)wm[m] * a.o_sW + 4 * kq;
       float* out_r = a.out + ro;
       const float* ref_r = a.relu_ref ? a.relu_ref + ro : nullptr;
+      // (all loads of this pixel column ahead of its stores: see biasv)
+      f32x4 rrv[NT], adv[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const long o = goff(n, a.o_gpu, a.o_sU, a.o_sG);
+        rrv[n] = ref_r ? ld4(ref_r + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+        adv[n] = a.addend ? ld4(a.addend + (out_r - a.out) + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         f32x4 v = acc[m][n];
-        if (a.bias) v += ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq);
+        v += biasv[n];
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const long o = goff(n, a.o_gpu, a.o_sU, a.o_sG);
         if (ref_r) {
-          const f32x4 rr = ld4(ref_r + o);
+          const f32x4 rr = rrv[n];
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
           v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
         }
-        if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
+        v += adv[n];
         st4(out_r + o, v);
       }
     }
@@ -494,7 +507,16 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
   if constexpr (F16) {
     __shared__ unsigned s_wmax[WAVES];
     float mx = 0.f;
-    for (long i = 4L * tid; i < (long)a.ntaps * slab; i += 4 * 512) mx = fmaxf(mx, amax4(ld4(wp + i)));
+    {   // eight loads in flight per trip (one load and its wait per trip: ~80 serialized memory round trips per workgroup)
+      const long nw = (long)a.ntaps * slab;
+      for (long i = 4L * tid; i < nw; i += 8 * 4 * 512) {
+        f32x4 f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const long iu = i + (long)u * 4 * 512; f[u] = ld4(wp + (iu < nw ? iu : i)); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mx = amax_acc(mx, f[u]);
+      }
+    }
     const unsigned wm_ = wave_umax(__float_as_uint(mx));
     if (lane == 0) s_wmax[wave] = wm_;
     __syncthreads();
@@ -676,24 +698,37 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       __syncthreads();
     }
     if (!row_ok) continue;
+    // the NT bias vectors in one batch ahead of the stores (a load between stores waits, through vmcnt(0), for every store
+    // before it: 24 serialized memory round trips per chunk)
+    f32x4 biasv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = a.bias ? ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (!vm[m]) continue;
       const long ro = (long)b * a.o_sB + (long)t * a.o_sT + (long)hm[m] * a.o_sH + (long)wm[m] * a.o_sW + 4 * kq;
       float* out_r = a.out + ro;
       const float* ref_r = a.relu_ref ? a.relu_ref + ro : nullptr;
+      // (all loads of this pixel column ahead of its stores: see biasv)
+      f32x4 rrv[NT], adv[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const long o = goff(n, a.o_gpu, a.o_sU, a.o_sG);
+        rrv[n] = ref_r ? ld4(ref_r + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+        adv[n] = a.addend ? ld4(a.addend + (out_r - a.out) + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         f32x4 v = F16 ? acc[m][n] * (GSC ? winv * gs.inv() : ASC ? winv * ag.inv() : winv) : acc[m][n];
-        if (a.bias) v += ld4(a.bias + (long)wset * NT * 16 + n * 16 + 4 * kq);
+        v += biasv[n];
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const long o = goff(n, a.o_gpu, a.o_sU, a.o_sG);
         if (ref_r) {
-          const f32x4 rr = ld4(ref_r + o);
+          const f32x4 rr = rrv[n];
           v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
           v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
         }
-        if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
+        v += adv[n];
         st4(out_r + o, v);
       }
     }
@@ -728,6 +763,8 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
+  // (the bias once per wave: loaded in the epilogue it is a memory round trip per row, behind the row's stores)
+  const f32x4 biasv = a.bias ? ld4(a.bias + (long)wset * 16 + 4 * ((threadIdx.x & 63) >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
   float* s_x = s_xw[wave];
   // wr[(ot*3+oh)*3+ow] = fragment of the weight tap that (ot, oh, ow) uses under the CURRENT edge pattern: the forward
   // conv always uses tap (ot, oh, ow); the data gradient flips a T / H tap where the replicate padding folds a source
@@ -864,8 +901,7 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
         int wdst = p;
         bool atomic = false;
         if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
-        f32x4 v = acc[m];
-        if (a.bias) v += ld4(a.bias + (long)wset * 16 + 4 * kq);
+        f32x4 v = acc[m] + biasv;
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const long o = (long)wdst * a.o_sW + 4 * kq;
         if (ref_r) {
@@ -1345,6 +1381,12 @@ __global__ __launch_bounds__(768) void dgrad_k133_to16_kernel(ConvArgs a, int ns
 // staged rows are kept as two piece images [quad pair][pixel][quad & 1][4 channels x 16 bit] so that a lane's 4 channels
 // of one piece are one 8-byte, conflict-free ds_read_b64 (32 lanes x 8 B = one 256-byte LDS row).
 // ---------------------------------------------------------------------------------------------
+#ifndef IDEE_DBG_SKIP
+#define IDEE_DBG_SKIP 0      // timing variants of conv16_split_kernel (never set in a shipped build): 1 no row loads, 2 no MFMA loop, 4 no stores, 8 no staging
+#endif
+#ifndef IDEE_RD_DEPTH
+#define IDEE_RD_DEPTH 1
+#endif
 constexpr int kSplitRowW = 2 * kC16Row * 4;     // 32-bit words of one staged row of ONE piece: [2 quad pairs][34 px][4 words]
 
 // GSC (IDEE_CONV_MATH=f22, data-gradient modes with f16 pieces): the staged dy rows carry a power-of-two factor 2^k kept per
@@ -1358,7 +1400,7 @@ constexpr int kSplitRowW = 2 * kC16Row * 4;     // 32-bit words of one staged ro
 // are (k = 0) until a staged row's largest |x| reaches 2^15, then the unit's rows carry 2^k, k < 0, through the same restaging
 // path — an input of any finite magnitude keeps two normal f16 pieces.
 // NB output blocks per wave (one input block; blockIdx.z picks the group of NB blocks: 16 -> 16 NB gridDim.z channels, the
-// weights of all NB blocks in registers) and KTS temporal taps of the zero-padded forward mode: NB = 3, KTS = 1 is the (1,3,3)
+// weights of all NB blocks in registers) and KTS temporal taps of the zero-padded forward mode: NB = 2, KTS = 1 is the (1,3,3)
 // sign-field forward 16 -> 96 (K = 9 taps x 16 channels in 5 tap pairs, 3 piece products each; its f32 kernel ran at 80 TFLOP/s
 // for a launch whose memory time is a quarter of that).
 template <int MODE, bool F16, int SC = SC_NONE, int NB = 1, int KTS = 2>
@@ -1387,9 +1429,15 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
   float wscale = 1.f, winv = 1.f;
   if (F16) {
     float mx = 0.f;
-    for (int tp = 0; tp < (NB == 1 ? a.ntaps : a.ntaps * a.GnTot); ++tp) {
-      const f32x4 f = ld4(wp + tp * 256 + lane * 4);
-      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(f[0]), fabsf(f[1]))), fmaxf(fabsf(f[2]), fabsf(f[3])));
+    // (nine loads in flight per trip — tap counts are multiples of 9: one load and its wait per trip made this scan a chain of
+    //  27 .. 54 memory round trips at the start of every wave, a quarter of the (1,3,3) forward's time)
+    const int nfr = NB == 1 ? a.ntaps : a.ntaps * a.GnTot;
+    for (int tp = 0; tp < nfr; tp += 9) {
+      f32x4 f[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) f[u] = ld4(wp + (tp + u < nfr ? tp + u : tp) * 256 + lane * 4);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) mx = amax_acc(mx, f[u]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -1398,6 +1446,12 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
     wscale = ldexpf(1.f, 14 - e);
     winv = ldexpf(1.f, e - 14);
   }
+  // the bias of this lane's output channels, once (a load in the epilogue is a memory round trip per row: its s_waitcnt vmcnt(0)
+  // also waits for the stores issued just before it)
+  f32x4 biasv[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+    biasv[n] = a.bias ? ld4(a.bias + (NB == 1 ? (long)wset * 16 : (long)wset * a.GnTot * 16 + (gb0 + n) * 16) + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
   const int Wframe = (MODE == DGRAD_REP) ? a.Wo + 2 : a.Wo;
   const int nsub = (Wframe + 15) / 16;
   const int nb = a.B / a.wsets;
@@ -1431,7 +1485,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
       const int u = lane + 64 * k;
       const int px = u >> 2, q4 = u & 3;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (u < rowlen * 4 && live) {
+      if (u < rowlen * 4 && live && !(IDEE_DBG_SKIP & 1)) {
         if (MODE == FWD_REP) {
           const int w = min(max(p0 + px - 1, 0), a.Wi - 1);
           v = ld4(src + (long)w * a.i_sW + 4 * q4);
@@ -1512,7 +1566,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int u = lane + 64 * k;
-            if (u < rowlen * 4) {
+            if (u < rowlen * 4 && (!(IDEE_DBG_SKIP & 8) || stg[ot][k][0] == 1.2345e-30f)) {
               const Split p = split2<F16>(stg[ot][k]);
               const int o = ((u & 3) >> 1) * (kC16Row * 4) + (u >> 2) * 4 + (u & 1) * 2;
               typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
@@ -1570,51 +1624,77 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
           bl[m] = u32x4{la[0], la[1], lb[0], lb[1]};
         }
       };
-      u32x4 bh[2][MT], bl[2][MT];
-      rd(0, bh[0], bl[0]);
+      // epilogue operands (ReLU reference, addend) requested AHEAD of the taps: loaded between the row's stores they cost a
+      // memory round trip each (s_waitcnt vmcnt(0) also waits for the stores before them)
+      float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
+      const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
+      // (data-gradient modes; the forward modes take neither in practice and read them, if given, in the epilogue)
+      constexpr bool EARLY = MODE == DGRAD_REP || MODE == DGRAD_S2;
+      long eo[MT];
+      bool eon[MT], eat[MT];
+      f32x4 rrv[EARLY ? MT : 1][NB], adv[EARLY ? MT : 1][NB];
 #pragma unroll
-      for (int pr = 0; pr < NPAIR; ++pr) {
-        if (pr + 1 < NPAIR) rd(pr + 1, bh[(pr + 1) & 1], bl[(pr + 1) & 1]);
+      for (int m = 0; m < MT; ++m) {
+        const int p = p0 + m * 16 + j;
+        eon[m] = m < my_sub && p < Wframe;
+        int wdst = p;
+        eat[m] = false;
+        if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); eat[m] = (p <= 1) || (p >= a.Wo); }
+        eo[m] = (long)wdst * a.o_sW + 4 * kq;
+        if constexpr (EARLY) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            const long o = eo[m] + (NB == 1 ? 0 : goff(gb0 + n, a.o_gpu, a.o_sU, a.o_sG));
+            rrv[m][n] = (ref_r && eon[m]) ? ld4(ref_r + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+            adv[m][n] = (a.addend && eon[m] && !eat[m]) ? ld4(a.addend + (out_r - a.out) + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+      constexpr int RD = IDEE_RD_DEPTH;      // tap pairs read ahead of their MFMAs
+      u32x4 bh[RD + 1][MT], bl[RD + 1][MT];
+#pragma unroll
+      for (int pr = 0; pr < RD && pr < NPAIR && !(IDEE_DBG_SKIP & 2); ++pr) rd(pr, bh[pr], bl[pr]);
+      // (scheduling fences: left alone the compiler sinks every fragment read to just before its MFMA — ds_read, s_waitcnt
+      //  lgkmcnt(0..2), v_mfma — and the LDS round trip is exposed at each of the 14 tap pairs of a row: most of these kernels' time)
+#pragma unroll
+      for (int pr = 0; pr < ((IDEE_DBG_SKIP & 2) ? 0 : NPAIR); ++pr) {
+        if (pr + RD < NPAIR) rd(pr + RD, bh[(pr + RD) % (RD + 1)], bl[(pr + RD) % (RD + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wh[pr][n], bh[pr & 1][m], acc[m][n]);
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wh[pr][n], bh[pr % (RD + 1)][m], acc[m][n]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wh[pr][n], bl[pr & 1][m], acc[m][n]);
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wh[pr][n], bl[pr % (RD + 1)][m], acc[m][n]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wl[pr][n], bh[pr & 1][m], acc[m][n]);
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(wl[pr][n], bh[pr % (RD + 1)][m], acc[m][n]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // epilogue (as conv16_lds_kernel; the f16 weight scale is taken out first)
-      float* out_r = a.out + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH;
-      const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        if (m >= my_sub) continue;
-        const int p = p0 + m * 16 + j;
-        if (p >= Wframe) continue;
-        int wdst = p;
-        bool atomic = false;
-        if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
+        if (!eon[m]) continue;
 #pragma unroll
-       for (int n = 0; n < NB; ++n) {
-        f32x4 v = F16 ? acc[m][n] * (GSC ? winv * gs.inv() : ASC ? winv * ag.inv() : winv) : acc[m][n];
-        if (a.bias) v += ld4(a.bias + (NB == 1 ? (long)wset * 16 : (long)wset * a.GnTot * 16 + (gb0 + n) * 16) + 4 * kq);
-        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const long o = (long)wdst * a.o_sW + 4 * kq + (NB == 1 ? 0 : goff(gb0 + n, a.o_gpu, a.o_sU, a.o_sG));
-        if (ref_r) {
-          const f32x4 rr = ld4(ref_r + o);
-          v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
-          v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+        for (int n = 0; n < NB; ++n) {
+          f32x4 v = F16 ? acc[m][n] * (GSC ? winv * gs.inv() : ASC ? winv * ag.inv() : winv) : acc[m][n];
+          v += biasv[n];
+          if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          const long o = eo[m] + (NB == 1 ? 0 : goff(gb0 + n, a.o_gpu, a.o_sU, a.o_sG));
+          if (ref_r) {
+            const f32x4 rr = EARLY ? rrv[EARLY ? m : 0][n] : ld4(ref_r + o);
+            v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
+            v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+          }
+          if (eat[m]) {
+            atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
+            atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
+          } else {
+            if (EARLY) v += adv[EARLY ? m : 0][n];
+            else if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
+            if (!(IDEE_DBG_SKIP & 4) || v[0] == 1.2345e-30f) st4(out_r + o, v);
+          }
         }
-        if (atomic) {
-          atomicAdd(out_r + o, v[0]); atomicAdd(out_r + o + 1, v[1]);
-          atomicAdd(out_r + o + 2, v[2]); atomicAdd(out_r + o + 3, v[3]);
-        } else {
-          if (a.addend) v += ld4(a.addend + (out_r - a.out) + o);
-          st4(out_r + o, v);
-        }
-       }
       }
       ++h;
     }
@@ -3082,17 +3162,17 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
     }
   }
   if constexpr (MODE == FWD_S2) {
-    // (1,3,3) forward from ONE input block into 3 n output blocks (the sign-field convs 16 -> 96 / 192) on f16 pieces: the strip
-    // kernel with the weights of 3 output blocks per wave in registers, grid.z = n
-    if (!cin1 && conv_split_math(true) && a.Gk == 1 && a.kt == 1 && a.GnTot % 3 == 0 && a.cout_real == 16 * a.GnTot && !a.w_tap_stride &&
+    // (1,3,3) forward from ONE input block into 2 n output blocks (the sign-field convs 16 -> 96 / 192) on f16 pieces: the strip
+    // kernel with the weights of 2 output blocks per wave in registers, grid.z = n
+    if (!cin1 && conv_split_math(true) && a.Gk == 1 && a.kt == 1 && a.GnTot % 2 == 0 && a.cout_real == 16 * a.GnTot && !a.w_tap_stride &&
         !a.addend_first) {
       const int nstrip = cdiv(cdiv(a.Wo, 16), 2);
       const long bt = (long)(a.B / a.wsets) * a.To;
-      const int gzs = a.GnTot / 3;
+      const int gzs = a.GnTot / 2;       // (two blocks = one 128-byte line of a 96-channel pixel; three blocks per wave spilled)
       const int hrun = pick_hrun(a.Ho, bt * nstrip, (long)a.wsets * gzs, 2);
       const int nhrun = cdiv(a.Ho, hrun);
       const long nunits = bt * nhrun * nstrip;
-      auto kern = conv16_split_kernel<FWD_S2, true, SC_ACT, 3, 1>;
+      auto kern = conv16_split_kernel<FWD_S2, true, SC_ACT, 2, 1>;
       const dim3 grid(one_round(cdiv(nunits, 4), (long)a.wsets * gzs, wg_per_cu(kern, 256)), a.wsets, gzs);
       hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, a, nstrip, hrun, nhrun);
       return IDEE_OK;
