@@ -2776,12 +2776,14 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
 #pragma unroll
     for (int o = 0; o < PXT; ++o) accv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
     int b = 0, h = 0, w0 = 0;
+    float biasv = 0.f;                            // (read with the source pixels: between the stores it is a round trip per pixel)
     if (g < ngrp && q < QC) {
       const unsigned gr = g / (unsigned)WG;
       w0 = (int)(g - gr * WG) * PXT;
       b = (int)(gr / (unsigned)a.H);             // (item, frame) pair index; item = b / To
       h = (int)(gr - (unsigned)b * a.H);
       const int wset = (b / a.To) % a.wsets;
+      if (a.bias) biasv = a.bias[wset];
       if (wset != wcur) {
         wcur = wset;
         const float* wp = a.w + (long)wset * 18 * Gi * 256;
@@ -2789,19 +2791,29 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
         for (int tap = 0; tap < 18; ++tap) wr[tap] = c1_w4_fwd(wp, Gi, tap, q);
       }
       const XT* xb = reinterpret_cast<const XT*>(a.x) + (long)(b / a.To) * a.x_sB + (long)(b % a.To) * 2 * a.x_sT + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
+      // per frame: the 18 source vectors (3 rows x 6 pixels, clamped addresses) are ALL requested before the first is used —
+      // with the out-of-frame select written right behind each load the compiler waited (vmcnt(0)) after every single one:
+      // 36 serialized memory round trips per 4 output pixels
+      typedef typename Raw4<XT>::type raw_t;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt) {
+        raw_t xr[3][PXT + 2];
+#pragma unroll
+        for (int oh = 0; oh < 3; ++oh) {
+          const XT* row = xb + (long)kt * a.x_sT + (long)min(max(h + oh - 1, 0), a.H - 1) * a.x_sH;
+#pragma unroll
+          for (int i = 0; i < PXT + 2; ++i) xr[oh][i] = ldraw4<XT>(row + (long)min(max(w0 - 1 + i, 0), a.W - 1) * a.x_sW);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int oh = 0; oh < 3; ++oh) {
           const int hs = h + oh - 1;
           const bool rok = hs >= 0 && hs < a.H;
-          const XT* row = xb + (long)kt * a.x_sT + (long)min(max(hs, 0), a.H - 1) * a.x_sH;
           f32x4 xv[PXT + 2];
 #pragma unroll
-          for (int i = 0; i < PXT + 2; ++i) {            // source pixels w0-1 .. w0+PXT: clamped address, zeroed outside the frame
+          for (int i = 0; i < PXT + 2; ++i) {            // source pixels w0-1 .. w0+PXT, zeroed outside the frame
             const int ws = w0 - 1 + i;
-            xv[i] = ldx4<XT>(row + (long)min(max(ws, 0), a.W - 1) * a.x_sW);
-            if (!(rok && ws >= 0 && ws < a.W)) xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xv[i] = (rok && ws >= 0 && ws < a.W) ? cvtraw4(xr[oh][i]) : f32x4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
           for (int ow = 0; ow < 3; ++ow) {
@@ -2810,14 +2822,14 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
             for (int o = 0; o < PXT; ++o) accv[o] = __builtin_elementwise_fma(xv[o + ow], wv, accv[o]);
           }
         }
+      }
     }
 #pragma unroll
     for (int o = 0; o < PXT; ++o) {
       float acc = (accv[o][0] + accv[o][1]) + (accv[o][2] + accv[o][3]);
 #pragma unroll
       for (int sft = 1; sft < LPP; sft <<= 1) acc += __shfl_xor(acc, sft, 64);
-      if (g < ngrp && q == 0 && w0 + o < a.W)
-        a.y[((long)b * a.H + h) * a.W + w0 + o] = acc + (a.bias ? a.bias[(b / a.To) % a.wsets] : 0.f);
+      if (g < ngrp && q == 0 && w0 + o < a.W) a.y[((long)b * a.H + h) * a.W + w0 + o] = acc + biasv;
     }
   }
 }
@@ -2838,45 +2850,82 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(C1Args a) {
       for (int u = 0; u < 4; ++u) wr[tap][u] = c1_w_dgrad(wp, Gi, tap, 4 * q + u);
   }
   const int nb = a.B / a.wsets;
-  const unsigned npw = (unsigned)nb * a.To * 2 * a.H * a.W;       // (32-bit index arithmetic: see c1_fwd_kernel)
-  (void)npix;
-  for (unsigned p0 = blockIdx.x * PPB; p0 < npw; p0 += gridDim.x * PPB) {
-    const unsigned p = p0 + pl;
-    if (p >= npw || q >= QC) continue;
-    const unsigned pr = p / (unsigned)a.W, ph = pr / (unsigned)a.H;
-    const int w = (int)(p - pr * a.W), h = (int)(pr - ph * a.H), kt = (int)(ph & 1u);
-    const unsigned bt = ph >> 1;                                         // (item of this weight set, output frame)
-    const unsigned bi = bt / (unsigned)a.To;
-    const int to = (int)(bt - bi * a.To);
-    const int b = (int)bi * a.wsets + wset;
-    const float* dyb = a.dy + ((long)b * a.To + to) * a.H * a.W;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const unsigned npw = (unsigned)nb * a.To * a.H * a.W;           // output pixels (b, to, h, w) of this weight set (32-bit index
+  (void)npix;                                                     // arithmetic: see c1_fwd_kernel)
+  // A lane group owns BOTH input frames (kt = 0, 1) of UN pixels per trip: the 9 dy values of a pixel serve both frames, and
+  // every load of the trip — dy (clamped addresses, masked afterwards), the ReLU references, the addends — is requested before
+  // the first use (one pixel and frame per trip, loaded at the points of use: three dependent memory round trips per 16-byte
+  // store, 1.1 - 1.7 TB/s).
+  constexpr int UN = 2;
+  typedef typename Raw4<XT>::type raw_t;
+  const unsigned pstride = gridDim.x * PPB;
+  for (unsigned p0 = blockIdx.x * PPB; p0 < npw; p0 += UN * pstride) {
+    float gv[UN][9];
+    raw_t rr_raw[UN][2], ad_raw[UN][2];
+    long off[UN];
+    int hh[UN], ww[UN];
+    bool on[UN];
 #pragma unroll
-    for (int oh = 0; oh < 3; ++oh) {
-      const int hq = h - (oh - 1);
+    for (int r = 0; r < UN; ++r) {
+      const unsigned p = p0 + r * pstride + pl;
+      on[r] = p < npw && q < QC;
+      const unsigned pc = on[r] ? p : 0u;
+      const unsigned pr = pc / (unsigned)a.W, bt = pr / (unsigned)a.H;
+      const int w = (int)(pc - pr * a.W), h = (int)(pr - bt * a.H);
+      const unsigned bi = bt / (unsigned)a.To;
+      const int to = (int)(bt - bi * a.To);
+      const int b = (int)bi * a.wsets + wset;
+      hh[r] = h; ww[r] = w;
+      const float* dyb = a.dy + ((long)b * a.To + to) * a.H * a.W;
+      const int qe = on[r] ? q : 0;
+      off[r] = (long)b * a.x_sB + (long)(2 * to) * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + goff(qe / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (qe % 4);
 #pragma unroll
-      for (int ow = 0; ow < 3; ++ow) {
-        const int wq = w - (ow - 1);
-        const bool ok = hq >= 0 && hq < a.H && wq >= 0 && wq < a.W;
-        const float g = ok ? dyb[(long)hq * a.W + wq] : 0.f;
-        acc += (kt == 0 ? wr[oh * 3 + ow] : wr[9 + oh * 3 + ow]) * g;
+      for (int oh = 0; oh < 3; ++oh)
+#pragma unroll
+        for (int ow = 0; ow < 3; ++ow)
+          gv[r][oh * 3 + ow] = dyb[(long)min(max(h - (oh - 1), 0), a.H - 1) * a.W + min(max(w - (ow - 1), 0), a.W - 1)];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        rr_raw[r][kt] = raw_t(); ad_raw[r][kt] = raw_t();
+        if (a.relu_ref) rr_raw[r][kt] = ldraw4<XT>(reinterpret_cast<const XT*>(a.relu_ref) + off[r] + (long)kt * a.x_sT);
+        if (a.accumulate) ad_raw[r][kt] = ldraw4<XT>(reinterpret_cast<const XT*>(a.dx) + off[r] + (long)kt * a.x_sT);
       }
     }
-    const long off = (long)b * a.x_sB + (long)(2 * to + kt) * a.x_sT + (long)h * a.x_sH + (long)w * a.x_sW + goff(q / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * (q % 4);
-    if (a.relu_ref) {
-      const f32x4 rr = ldx4<XT>(reinterpret_cast<const XT*>(a.relu_ref) + off);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = rr[u] > 0.f ? acc[u] : 0.f;
+    for (int r = 0; r < UN; ++r) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const int hq = hh[r] - (oh - 1);
+#pragma unroll
+        for (int ow = 0; ow < 3; ++ow) {
+          const int wq = ww[r] - (ow - 1);
+          const bool ok = hq >= 0 && hq < a.H && wq >= 0 && wq < a.W;
+          const float g = ok ? gv[r][oh * 3 + ow] : 0.f;
+          acc[0] += wr[oh * 3 + ow] * g;
+          acc[1] += wr[9 + oh * 3 + ow] * g;
+        }
+      }
+      if (!on[r]) continue;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        if (a.relu_ref) {
+          const f32x4 rr = cvtraw4(rr_raw[r][kt]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[kt][u] = rr[u] > 0.f ? acc[kt][u] : 0.f;
+        }
+        if (a.accumulate) acc[kt] += cvtraw4(ad_raw[r][kt]);
+        stx4<XT>(reinterpret_cast<XT*>(a.dx) + off[r] + (long)kt * a.x_sT, acc[kt]);
+      }
     }
-    if (a.accumulate) acc += ldx4<XT>(reinterpret_cast<const XT*>(a.dx) + off);
-    stx4<XT>(reinterpret_cast<XT*>(a.dx) + off, acc);
   }
 }
 
 // dW[tap][c] = sum_{b,h,w} x[b][kt][h+oh-1][w+ow-1][c] dy[b][h][w]: every x value is read once and spread over its 9 taps
 template <int LPP, typename XT>
 __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
-  __shared__ float s_red[256 / LPP][LPP][4];
+  __shared__ __attribute__((aligned(16))) float s_red18[18][4][LPP][4];
   const int QC = a.C / 4;
   const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP, PPB = 256 / LPP;
   const int wset = blockIdx.y;
@@ -2911,25 +2960,39 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
 #pragma unroll
         for (int ow = 0; ow < 3; ++ow) {
           const int h = hs - (oh - 1), w = ws - (ow - 1);      // output pixel this source feeds through tap (oh, ow)
-          gq[r][oh * 3 + ow] = (on[r] && h >= 0 && h < a.H && w >= 0 && w < a.W) ? dyb[(long)h * a.W + w] : 0.f;
+          gq[r][oh * 3 + ow] = dyb[(long)min(max(h, 0), a.H - 1) * a.W + min(max(w, 0), a.W - 1)];   // (masked after the loads)
         }
       const XT* xb = reinterpret_cast<const XT*>(a.x) + (long)b * a.x_sB + (long)(2 * to) * a.x_sT + (long)hs * a.x_sH + (long)ws * a.x_sW + goff((on[r] ? q : 0) / 4, a.x_gpu, a.x_sU, a.x_sG) + 4 * ((on[r] ? q : 0) % 4);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) xq[r][kt] = ldx4<XT>(xb + (long)kt * a.x_sT);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < UN; ++r) {
+      const unsigned p = p0 + r * pstride + pl;
+      const unsigned pc = on[r] ? p : 0u;
+      const unsigned pr = pc / (unsigned)a.W;
+      const int ws = (int)(pc - pr * a.W), hs = (int)(pr % (unsigned)a.H);
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh)
+#pragma unroll
+        for (int ow = 0; ow < 3; ++ow) {
+          const int h = hs - (oh - 1), w = ws - (ow - 1);
+          if (!(on[r] && h >= 0 && h < a.H && w >= 0 && w < a.W)) gq[r][oh * 3 + ow] = 0.f;    // pixels that do not exist
+        }
       if (q == 0) bsum += gq[r][4];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] += xq[r][kt] * gq[r][t9];      // dy is zero for pixels that do not exist
+        for (int t9 = 0; t9 < 9; ++t9) acc[kt][t9] += xq[r][kt] * gq[r][t9];
     }
   }
   // reduce over the lanes of a wave that own the same channels, then over the 4 waves, then one atomic per value
   float* dw = a.dwp + (long)wset * 18 * a.C * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* red = &s_red[0][0][0];            // reused as [4 waves][LPP][4]
+  float* red = &s_red18[0][0][0][0];       // [18 taps][4 waves][LPP][4]
+  // all 18 tap sums of a wave go to LDS in one pass (two workgroup barriers in all: a barrier pair per tap was most of this
+  // kernel's time — a workgroup streams only ~2,000 pixels)
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -2940,19 +3003,15 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
         v[0] += __shfl_xor(v[0], o, 64); v[1] += __shfl_xor(v[1], o, 64);
         v[2] += __shfl_xor(v[2], o, 64); v[3] += __shfl_xor(v[3], o, 64);
       }
-      __syncthreads();
-      if (lane < LPP)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) red[(wave * LPP + lane) * 4 + u] = v[u];
-      __syncthreads();
-      if (threadIdx.x < LPP && q < QC) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float sum = red[(0 * LPP + q) * 4 + u] + red[(1 * LPP + q) * 4 + u] + red[(2 * LPP + q) * 4 + u] + red[(3 * LPP + q) * 4 + u];
-          atomicAdd(dw + ((long)(kt * 9 + t9) * a.C + 4 * q + u) * 16, sum);
-        }
-      }
+      if (lane < LPP) st4(red + (((kt * 9 + t9) * 4 + wave) * LPP + lane) * 4, v);
     }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 18 * LPP * 4; e += 256) {
+    const int tap = e / (LPP * 4), qq = (e / 4) % LPP, u = e & 3;
+    if (qq >= QC) continue;
+    const float* rp = red + (tap * 4 * LPP + qq) * 4 + u;
+    atomicAdd(dw + ((long)tap * a.C + 4 * qq + u) * 16, (rp[0] + rp[LPP * 4]) + (rp[2 * LPP * 4] + rp[3 * LPP * 4]));
+  }
   if (a.dbias) {      // (uniform) one atomic per WORKGROUP: per-wave atomics onto this single address form a chain of ~17 ns each
     bsum = wave_sum(bsum);
     __syncthreads();
@@ -2969,11 +3028,11 @@ int launch_c1_t(int which, C1Args& a, hipStream_t st) {
   if (QC > 64) return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): Cin %d > 256 is not built", a.C);
   const int PPB = 256 / LPP;
   const long nbw = a.B / a.wsets;
-  const long npix = (which == 1 ? nbw * 2 * a.H * a.W : (which == 0 ? (long)a.B * a.H * ((a.W + 3) / 4) : nbw * a.H * a.W)) * a.To;
+  const long npix = (which == 0 ? (long)a.B * a.H * ((a.W + 3) / 4) : nbw * a.H * a.W) * a.To;
   if ((long)a.B * a.To * 2 * a.H * a.W + 4L * 256 * kCUs * 8 >= (1L << 31))      // the kernels index pixels (and their grid strides) in 32 bits
     return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): more than 2^31 pixels per launch");
   const int per = which == 0 ? 1 : a.wsets;                       // dgrad / wgrad: one weight set per grid column
-  const int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : 8), per));
+  const int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : which == 1 ? 4 : 8), per));
   const dim3 grid(gx < 1 ? 1 : gx, per);
 #define C1(K) do { if (LPP == 4) hipLaunchKernelGGL((K<4, XT>), grid, dim3(256), 0, st, a); else if (LPP == 8) hipLaunchKernelGGL((K<8, XT>), grid, dim3(256), 0, st, a); \
   else if (LPP == 16) hipLaunchKernelGGL((K<16, XT>), grid, dim3(256), 0, st, a); else if (LPP == 32) hipLaunchKernelGGL((K<32, XT>), grid, dim3(256), 0, st, a); \
