@@ -410,11 +410,9 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
             for (int n = 0; n < NT; ++n) {
               const f32x4 wf = ld4(wcur + (g * NT + n) * 256 + lane * 4);
   #pragma unroll
-              for (int m = 0; m < MT; ++m)
-                if (m < nm) {
+              for (int m = 0; m < MT; ++m)      // (no guard m < nm: see conv_wide_split_kernel)
   #pragma unroll
-                  for (int s = 0; s < 4; ++s) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
             }
           }
   #pragma unroll
@@ -674,17 +672,19 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
             bh[m] = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
             bl[m] = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
           }
+          // (no per-column guard `m < nm`: it compiled to a scalar branch around every group of three MFMAs; only the one wave
+          //  that holds the ragged end of a workgroup's range has 0 < nm < MT, and its absent columns multiply zeros that are
+          //  never stored)
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             const u32x4 ah = *reinterpret_cast<const u32x4*>(wcur + (((gp * NT + n) * 2 + 0) * 64 + lane) * 4);
             const u32x4 al = *reinterpret_cast<const u32x4*>(wcur + (((gp * NT + n) * 2 + 1) * 64 + lane) * 4);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              if (m < nm) {
-                acc[m][n] = mfma_s<F16>(ah, bh[m], acc[m][n]);
-                acc[m][n] = mfma_s<F16>(ah, bl[m], acc[m][n]);
-                acc[m][n] = mfma_s<F16>(al, bh[m], acc[m][n]);
-              }
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(ah, bh[m], acc[m][n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(ah, bl[m], acc[m][n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(al, bh[m], acc[m][n]);
           }
         }
 #pragma unroll
