@@ -2178,24 +2178,29 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
       }
       wave_fence();
       // acc[tap][cin][cout] += sum over the strip's 32 pixels of x[pixel + tap offset][cin] dy[pixel][cout]
+      // (the x fragments of tap tp + 1 are read while tap tp is multiplied, with scheduling fences: the compiler's own order is
+      //  ds_read_tr x 4, s_waitcnt lgkmcnt(0), 3 MFMAs per tap — an exposed LDS round trip at each of the 27 taps)
+      auto rdA = [&](int tp, u32x4& Ah, u32x4& Al) __attribute__((always_inline)) {
+        const int ot = tp / 9, oh = (tp / 3) % 3, ow = tp % 3;
+        const unsigned* ap = s_x + (ot * 3 + slot_of[oh]) * ROWW + ow * 16 + tr_off;
+        const unsigned long long h0_ = tr(ap), h1_ = tr(ap + 4 * 16), l0_ = tr(ap + 8), l1_ = tr(ap + 4 * 16 + 8);
+        Ah = u32x4{(unsigned)h0_, (unsigned)(h0_ >> 32), (unsigned)h1_, (unsigned)(h1_ >> 32)};
+        Al = u32x4{(unsigned)l0_, (unsigned)(l0_ >> 32), (unsigned)l1_, (unsigned)(l1_ >> 32)};
+      };
+      u32x4 Ahb[2], Alb[2];
+      rdA(0, Ahb[0], Alb[0]);
 #pragma unroll
-      for (int ot = 0; ot < TSL; ++ot)
+      for (int tp = 0; tp < NTAPS; ++tp) {
+        if (tp + 1 < NTAPS) rdA(tp + 1, Ahb[(tp + 1) & 1], Alb[(tp + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int oh = 0; oh < 3; ++oh)
-#pragma unroll
-          for (int ow = 0; ow < 3; ++ow) {
-            const unsigned* ap = s_x + (ot * 3 + slot_of[oh]) * ROWW + ow * 16 + tr_off;
-            const unsigned long long h0_ = tr(ap), h1_ = tr(ap + 4 * 16), l0_ = tr(ap + 8), l1_ = tr(ap + 4 * 16 + 8);
-            const u32x4 Ah = {(unsigned)h0_, (unsigned)(h0_ >> 32), (unsigned)h1_, (unsigned)(h1_ >> 32)};
-            const u32x4 Al = {(unsigned)l0_, (unsigned)(l0_ >> 32), (unsigned)l1_, (unsigned)(l1_ >> 32)};
-            const int tp = (ot * 3 + oh) * 3 + ow;
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-              acc[tp][n] = mfma_s<F16>(Ah, Bh[n], acc[tp][n]);
-              acc[tp][n] = mfma_s<F16>(Ah, Bl[n], acc[tp][n]);
-              acc[tp][n] = mfma_s<F16>(Al, Bh[n], acc[tp][n]);
-            }
-          }
+        for (int n = 0; n < NB; ++n) {
+          acc[tp][n] = mfma_s<F16>(Ahb[tp & 1], Bh[n], acc[tp][n]);
+          acc[tp][n] = mfma_s<F16>(Ahb[tp & 1], Bl[n], acc[tp][n]);
+          acc[tp][n] = mfma_s<F16>(Alb[tp & 1], Bh[n], acc[tp][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       ++h;
     }
   }
