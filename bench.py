@@ -33,8 +33,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")             # --math f32
-PMC_SUMMARY_F22 = os.path.join(ROOT, "profiles", "r03_pmc_traffic_f22.json")     # --math f22 (the default line)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")             # --math f32
+PMC_SUMMARY_F22 = os.path.join(ROOT, "profiles", "r04_pmc_traffic_f22.json")     # --math f22 (the default line)
 PMC_SUMMARY_BF16 = os.path.join(ROOT, "profiles", "r03_pmc_traffic_config4_bf16.json")
 
 CONFIGS = {
@@ -251,10 +251,12 @@ def math_label(math, cfg, dtype="f32"):
             d["swin_gemm"] = ("forward: two f16 pieces per operand, all 4 piece products, f32 accumulate (operand rounding 2^-22), attention "
                               "scores on the f32 MFMA; backward: exact f32 MFMA")
             if math == "f22":
-                d["conv"] = ("16->16 and 96-wide convs, forward, data gradient and weight gradient, and the (1,3,3) weight gradient: two f16 "
-                             "pieces per operand, 3 piece products; weights prescaled by a power of two per set, dy scaled by a power of two "
-                             "per work unit / chunk (data gradients, the scale only moving down) or per row (weight gradients, accumulators "
-                             "rescaled along); forward and data gradient of the (1,3,3) sign-field convs and the Cout = 1 convs exact f32")
+                d["conv"] = ("16->16 and 96-wide convs, forward, data gradient and weight gradient, and the (1,3,3) forward and weight "
+                             "gradient: two f16 pieces per operand, 3 piece products; weights prescaled by a power of two per set, dy scaled "
+                             "by a power of two per work unit / chunk (data gradients, the scale only moving down) or per row (weight "
+                             "gradients, accumulators rescaled along), activations under a range guard (split as they are until a staged "
+                             "tile's largest |x| reaches 2^15, then scaled by an exact 2^k: any finite input keeps two normal pieces); data "
+                             "gradient of the (1,3,3) sign-field convs and the Cout = 1 convs exact f32")
                 d["swin_gemm"] = ("forward and backward: two f16 pieces per operand, all 4 piece products, f32 accumulate; weight tensors "
                                   "prescaled by a power of two per tensor (largest |w| in [2^6, 2^7)), the incoming gradient scaled by a "
                                   "power of two per 32-token work item (largest |dy| in [2^1, 2^8)): operand rounding max(2^-22 |x|, "
@@ -462,7 +464,7 @@ def main():
     elif mfma_fams:
         k, (ms, n, fl, by) = mfma_fams[0]      # the entry point (all its shapes) with the largest total time in the timed region
         traffic, src = pmc_traffic(k, n // a.steps, headline and a.math in ("f32", "f22"), PMC_SUMMARY_F22 if a.math == "f22" else PMC_SUMMARY)
-        # what actually limits the family (profiles/r03_sq_counters.txt): the convolution kernels are paced by the f32 MFMA pipe
+        # what actually limits the family (profiles/r04_sq_counters*.txt): the convolution kernels are paced by the f32 MFMA pipe
         # (MFMA-busy ~80 %); the fused Swin kernels by VALU issue (LayerNorm / softmax / GELU share the issue slots with the f32
         # MFMA, which does not co-execute with VALU work on gfx950) — their peak is the same 157.3 TFLOP/s f32 vector rate
         # (f22: the f16 MFMA overlaps the VALU stream, the Swin kernels stay VALU-issue bound; FLOPs are the reference
@@ -517,8 +519,9 @@ def main():
                       "f32 storage/accumulate; forward convolutions and Swin linear layers on two-piece f16 split MFMAs (operand rounding "
                       "2^-22), every backward pass exact f32" if a.math == "fwd22" else
                       "f32 storage and accumulation; GEMM operands as two f16 pieces at f32 level (operand rounding 2^-22: weights prescaled by "
-                      "exact powers of two per tensor, gradients per tile) in the Swin block and the 16->16 / 96-wide convolutions, all passes; "
-                      "attention scores, the (1,3,3) forward / data gradient and the Cout = 1 convolutions exact f32 (see `math`, `exact_f32`)"
+                      "exact powers of two per tensor, gradients per tile, convolution inputs under a range guard) in the Swin block and the "
+                      "16->16 / 96-wide / (1,3,3)-forward convolutions; attention scores, the (1,3,3) data gradient and the Cout = 1 "
+                      "convolutions exact f32 (see `math`, `exact_f32`)"
                       if a.math == "f22" else
                       "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs"),
                math=math_label(a.math, cfg, a.dtype),

@@ -3037,7 +3037,10 @@ int launch_c1_t(int which, C1Args& a, hipStream_t st) {
   if ((long)a.B * a.To * 2 * a.H * a.W + 4L * 256 * kCUs * 8 >= (1L << 31))      // the kernels index pixels (and their grid strides) in 32 bits
     return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (Cout=1): more than 2^31 pixels per launch");
   const int per = which == 0 ? 1 : a.wsets;                       // dgrad / wgrad: one weight set per grid column
-  const int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : which == 1 ? 4 : 8), per));
+  int gx = imin(cdiv(npix, PPB), cdiv((long)kCUs * (which == 2 ? 2 : which == 1 ? 4 : 8), per));
+  // weight gradient: a workgroup ends with an 18-tap reduction and 72 C atomics — at least 8 trips of 4 PPB pixels each, or a
+  // small input (config #1: 8,192 pixels) is all epilogue
+  if (which == 2) gx = imin(gx, imax(npix / (PPB * 4 * 8), 1));
   const dim3 grid(gx < 1 ? 1 : gx, per);
 #define C1(K) do { if (LPP == 4) hipLaunchKernelGGL((K<4, XT>), grid, dim3(256), 0, st, a); else if (LPP == 8) hipLaunchKernelGGL((K<8, XT>), grid, dim3(256), 0, st, a); \
   else if (LPP == 16) hipLaunchKernelGGL((K<16, XT>), grid, dim3(256), 0, st, a); else if (LPP == 32) hipLaunchKernelGGL((K<32, XT>), grid, dim3(256), 0, st, a); \
