@@ -35,6 +35,10 @@ struct ConvArgs {
   long w_set_stride;                     // floats between weight sets (default ntaps * 256)
   int bias_set_stride;                   // floats between the bias vectors of weight sets (default 16)
   int addend_first;                      // 1: out = relu(acc + addend + bias) (a partial sum), 0: relu(acc + bias) + addend
+  // replicate-mode data gradient: the two virtual frame columns (-1, W) are folded onto columns 0 / W - 1 INSIDE the wave (a DPP
+  // row shift between the two lanes that hold them — they share a 16-column tile unless W % 16 == 15) instead of with atomics on
+  // top of a pre-initialised edge: set by idee_conv_dgrad_add for the kernels that implement it (conv16_split_kernel)
+  int no_edge_atomics;
 };
 
 struct Slot { int src, tap; bool ok; };

@@ -1639,7 +1639,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
         eon[m] = m < my_sub && p < Wframe;
         int wdst = p;
         eat[m] = false;
-        if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); eat[m] = (p <= 1) || (p >= a.Wo); }
+        if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); eat[m] = ((p <= 1) || (p >= a.Wo)) && !a.no_edge_atomics; }
         eo[m] = (long)wdst * a.o_sW + 4 * kq;
         if constexpr (EARLY) {
 #pragma unroll
@@ -1674,6 +1674,25 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
       // epilogue (as conv16_lds_kernel; the f16 weight scale is taken out first)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
+        if constexpr (MODE == DGRAD_REP) {
+          // The virtual frame columns -1 and W (replicate padding) belong to the real columns 0 and W - 1: frame column p = 0 is
+          // added to p = 1 and p = W + 1 to p = W by a DPP row shift (both lanes of a pair sit in one 16-column tile: the host
+          // sets no_edge_atomics only when W % 16 != 15) — no atomics and no pre-initialised edge columns (the edge lanes'
+          // atomics, 12 per row in a divergent branch, were 0.08 of the 3^3 data gradient's 0.71 ms)
+          if (a.no_edge_atomics) {
+            const int p = p0 + m * 16 + j;
+            f32x4 fl, fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float ar = acc[m][0][r];     // (a scalar copy: bit-casting the vector element in place compiled to component 0 four times)
+              fl[r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
+              fr[r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x101 /*row_shl:1*/, 0xf, 0xf, true));
+            }
+            if (p == 1) acc[m][0] += fl;
+            if (p == a.Wo) acc[m][0] += fr;
+            if (p == 0 || p == a.Wo + 1) eon[m] = false;      // (folded into their neighbours)
+          }
+        }
         if (!eon[m]) continue;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
@@ -3205,6 +3224,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
         return IDEE_OK;
       }
+      if (a.no_edge_atomics) return idee::fail(IDEE_ERR_INVALID_ARG, "conv_dgrad: edge folding was requested for a kernel that does not implement it");
       if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
         const bool reg_staged = env_is("IDEE_CONV16", "regs");
         if (!reg_staged) {
@@ -3440,13 +3460,17 @@ extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const void* dy_, con
   if (d->mode == IDEE_CONV_K333_REPLICATE) {
     IDEE_CHECK_ARG(!cin1, "conv_dgrad: Cout == 1 is only built for the (2,3,3) mode");
     split_tiles(a, a.Wo + 2);
-    if (addend != dx) {   // interior columns are plain stores; the two edge columns are atomics on top of 0 / the addend
+    // the split-precision 16 -> 16 kernel folds the two virtual frame columns inside the wave (ConvArgs::no_edge_atomics);
+    // this mirrors launch_conv<DGRAD_REP>'s choice of that kernel, which refuses the flag for any other
+    a.no_edge_atomics = a.GnTot == 1 && a.Gk == 1 && a.cout_real == 16 && (conv_f22_math() || conv_split_math(false)) &&
+                        a.Wo % 16 != 15 && a.Wo >= 2;
+    if (addend != dx && !a.no_edge_atomics) {   // interior columns are plain stores; the two edge columns are atomics on top of 0 / the addend
       IDEE_CHECK_ARG(d->x_sG == 16 && d->x_gpu <= 0, "conv_dgrad (replicate): grouped dx layouts are not built");
       const long total = (long)d->B * d->T * d->H * 2 * (d->Cin / 4);
       hipLaunchKernelGGL(init_w_edges_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, dx, addend,
                          d->B, d->T, d->H, d->W, d->Cin, d->x_sB, d->x_sT, d->x_sH, d->x_sW);
     }
-    launch_conv<DGRAD_REP>(a, false, (hipStream_t)stream);
+    if (int rc = launch_conv<DGRAD_REP>(a, false, (hipStream_t)stream)) return rc;
   } else {
     split_tiles(a, a.Wo);
     launch_conv<DGRAD_S2>(a, cin1, (hipStream_t)stream);
