@@ -754,6 +754,22 @@ __device__ __forceinline__ void wave_fence() {   // LDS hand-off inside one wave
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Replicate-mode data gradient, ConvArgs::no_edge_atomics: frame column p = 0 (virtual column -1) is added to p = 1 and p = W + 1
+// (virtual column W) to p = W by a DPP row shift — the two lanes of a pair sit in one 16-column tile — and the donor lanes drop out.
+// Returns false for a donor lane.  (Called by all lanes of the wave.)
+__device__ __forceinline__ bool fold_w_edges(f32x4& acc, int p, int Wo) {
+  f32x4 fl, fr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float ar = acc[r];     // (a scalar copy: bit-casting the vector element in place compiled to component 0 four times)
+    fl[r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
+    fr[r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x101 /*row_shl:1*/, 0xf, 0xf, true));
+  }
+  if (p == 1) acc += fl;
+  if (p == Wo) acc += fr;
+  return !(p == 0 || p == Wo + 1);
+}
+
 template <int MODE /*FWD_REP, DGRAD_REP: 3x3x3 replicate ; FWD_S2, DGRAD_S2: (kt,3,3) zero padding, 16 -> 16*/>
 __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstrip, int hrun, int nhrun) {
   constexpr int MT = 2;
@@ -895,12 +911,14 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(ConvArgs a, int nstr
       const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        if (m >= my_sub) continue;
         const int p = p0 + m * 16 + j;
+        bool live = true;
+        if (MODE == DGRAD_REP && a.no_edge_atomics) live = fold_w_edges(acc[m], p, a.Wo);
+        if (m >= my_sub || !live) continue;
         if (p >= Wframe) continue;
         int wdst = p;
         bool atomic = false;
-        if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
+        if (MODE == DGRAD_REP) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = ((p <= 1) || (p >= a.Wo)) && !a.no_edge_atomics; }
         f32x4 v = acc[m] + biasv;
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const long o = (long)wdst * a.o_sW + 4 * kq;
@@ -1151,12 +1169,14 @@ __global__ __launch_bounds__(256, 2) void conv16_glds_kernel(ConvArgs a, int nst
       const float* ref_r = a.relu_ref ? a.relu_ref + (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH : nullptr;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        if (m >= my_sub) continue;
         const int p = p0 + m * 16 + j;
+        bool live = true;
+        if (!FWD && a.no_edge_atomics) live = fold_w_edges(acc[m], p, a.Wo);
+        if (m >= my_sub || !live) continue;
         if (p >= Wframe) continue;
         int wdst = p;
         bool atomic = false;
-        if (!FWD) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = (p <= 1) || (p >= a.Wo); }
+        if (!FWD) { wdst = min(max(p - 1, 0), a.Wo - 1); atomic = ((p <= 1) || (p >= a.Wo)) && !a.no_edge_atomics; }
         f32x4 v = acc[m];
         const long o = (long)wdst * a.o_sW + 4 * kq;
         const bool add_first = FWD && a.addend_first && a.addend;       // forward partial sums: the ReLU acts on the total
@@ -1679,19 +1699,7 @@ __global__ __launch_bounds__(256, 2) void conv16_split_kernel(ConvArgs a, int ns
           // added to p = 1 and p = W + 1 to p = W by a DPP row shift (both lanes of a pair sit in one 16-column tile: the host
           // sets no_edge_atomics only when W % 16 != 15) — no atomics and no pre-initialised edge columns (the edge lanes'
           // atomics, 12 per row in a divergent branch, were 0.08 of the 3^3 data gradient's 0.71 ms)
-          if (a.no_edge_atomics) {
-            const int p = p0 + m * 16 + j;
-            f32x4 fl, fr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float ar = acc[m][0][r];     // (a scalar copy: bit-casting the vector element in place compiled to component 0 four times)
-              fl[r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
-              fr[r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x101 /*row_shl:1*/, 0xf, 0xf, true));
-            }
-            if (p == 1) acc[m][0] += fl;
-            if (p == a.Wo) acc[m][0] += fr;
-            if (p == 0 || p == a.Wo + 1) eon[m] = false;      // (folded into their neighbours)
-          }
+          if (a.no_edge_atomics && !fold_w_edges(acc[m][0], p0 + m * 16 + j, a.Wo)) eon[m] = false;      // (donors: folded into their neighbours)
         }
         if (!eon[m]) continue;
 #pragma unroll
@@ -3224,7 +3232,6 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         hipLaunchKernelGGL(kern, grid, block, 0, stream, a, nstrip, hrun, nhrun);
         return IDEE_OK;
       }
-      if (a.no_edge_atomics) return idee::fail(IDEE_ERR_INVALID_ARG, "conv_dgrad: edge folding was requested for a kernel that does not implement it");
       if constexpr (MODE == FWD_REP || MODE == DGRAD_REP) {
         const bool reg_staged = env_is("IDEE_CONV16", "regs");
         if (!reg_staged) {
@@ -3328,6 +3335,7 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       return IDEE_OK;
     }
   }
+  if (a.no_edge_atomics) return idee::fail(IDEE_ERR_INVALID_ARG, "conv_dgrad: edge folding was requested for a kernel that does not implement it");
 #define LC(NT_, WL_, C1_)                                                                                     \
   do {                                                                                                        \
     auto kern = conv_kernel<MODE, NT_, WL_, C1_>;                                                             \
@@ -3460,10 +3468,9 @@ extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const void* dy_, con
   if (d->mode == IDEE_CONV_K333_REPLICATE) {
     IDEE_CHECK_ARG(!cin1, "conv_dgrad: Cout == 1 is only built for the (2,3,3) mode");
     split_tiles(a, a.Wo + 2);
-    // the split-precision 16 -> 16 kernel folds the two virtual frame columns inside the wave (ConvArgs::no_edge_atomics);
-    // this mirrors launch_conv<DGRAD_REP>'s choice of that kernel, which refuses the flag for any other
-    a.no_edge_atomics = a.GnTot == 1 && a.Gk == 1 && a.cout_real == 16 && (conv_f22_math() || conv_split_math(false)) &&
-                        a.Wo % 16 != 15 && a.Wo >= 2;
+    // the 16 -> 16 strip kernels (exact and split) fold the two virtual frame columns inside the wave (ConvArgs::no_edge_atomics);
+    // this mirrors launch_conv<DGRAD_REP>'s choice of those kernels, which refuses the flag for any other
+    a.no_edge_atomics = a.GnTot == 1 && a.Gk == 1 && a.cout_real == 16 && a.Wo % 16 != 15 && a.Wo >= 2;
     if (addend != dx && !a.no_edge_atomics) {   // interior columns are plain stores; the two edge columns are atomics on top of 0 / the addend
       IDEE_CHECK_ARG(d->x_sG == 16 && d->x_gpu <= 0, "conv_dgrad (replicate): grouped dx layouts are not built");
       const long total = (long)d->B * d->T * d->H * 2 * (d->Cin / 4);
