@@ -507,7 +507,8 @@ __global__ void lfq_finalize_kernel(const float* __restrict__ partials, int nblo
   const int t = threadIdx.x;   // 64 threads
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
-    for (int b = t; b < nblocks; b += 64) s += (double)partials[(long)b * R + r];
+    #pragma unroll 8      // (independent loads in flight)
+  for (int b = t; b < nblocks; b += 64) s += (double)partials[(long)b * R + r];
     sm[r][t] = s;
   }
   __syncthreads();
@@ -762,6 +763,7 @@ __global__ void ratio_finalize_kernel(const float* __restrict__ partials, int nb
   const int t = threadIdx.x;
   for (int p = P; p >= 0; --p) {
     double s = 0.0;
+    #pragma unroll 8      // (independent loads in flight)
     for (int b = t; b < nblocks; b += 64) s += (double)partials[(long)b * (P + 1) + p];
     sm[t] = s;
     __syncthreads();
@@ -962,6 +964,7 @@ __global__ void column_sum_kernel(const float* __restrict__ partials, int nblock
   __shared__ double sm[64];
   const int r = blockIdx.x, t = threadIdx.x;
   double s = 0.0;
+  #pragma unroll 8      // (independent loads in flight)
   for (int b = t; b < nblocks; b += 64) s += (double)partials[(long)b * R + r];
   sm[t] = s;
   __syncthreads();
@@ -1419,6 +1422,7 @@ __global__ void fold_fwd_kernel(const float* __restrict__ w, const float* __rest
         if (ch < V * D && v != ch / D) continue;
         if (per_var && v != vr) continue;
         const float* wrow = per_var ? w + ((long)row * C) * 18 : w + ((long)row * V * C + (long)v * C) * 18;
+#pragma unroll 8                  // (independent loads in flight: one load and its wait per trip made this a chain of C round trips)
         for (int c = 0; c < C; ++c)
           acc = fmaf(wrow[(long)c * 18 + tap], ch < V * D ? w_out[c * D + ch % D] : b_out[c], acc);
       }
@@ -1454,6 +1458,7 @@ __global__ void fold_bwd_p_kernel(const float* __restrict__ dweff, const float* 
   const int G = per_var ? 1 : V;
   float acc = 0.f;
   const long total = (long)rows * G * 18;
+#pragma unroll 8                      // (as in fold_fwd_kernel: 40 serialized round trips per thread at the joint head's size)
   for (long e = threadIdx.x; e < total; e += blockDim.x) {
     const int tap = (int)(e % 18); long r = e / 18;
     const int g = (int)(r % G); const int row = (int)(r / G);
