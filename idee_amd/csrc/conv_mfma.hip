@@ -1326,6 +1326,14 @@ __global__ __launch_bounds__(768) void dgrad_k133_to16_kernel(ConvArgs a, int ns
       const char* rowq[3];
 #pragma unroll
       for (int oh = 0; oh < 3; ++oh) rowq[oh] = reinterpret_cast<const char*>(s_x) + (((h - (oh - 1)) % 3 + 3) % 3) * kRowB;
+      // the summing waves request their epilogue operands ahead of the taps (read after the workgroup barrier they were a
+      // memory round trip on the critical path of every row: the other waves wait at the next barrier for waves 0 / 1)
+      const int pe = p0 + wave * 16 + j;
+      const bool sum_on = wave < my_sub && pe < a.Wo;
+      const long oe = (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH + (long)pe * a.o_sW + 4 * kq;
+      f32x4 rrv = {1.f, 1.f, 1.f, 1.f}, adv = {0.f, 0.f, 0.f, 0.f};
+      if (sum_on && a.relu_ref) rrv = ld4(a.relu_ref + oe);
+      if (sum_on && a.addend) adv = ld4(a.addend + oe);
       f32x4 xb[2][2];
       auto rd = [&](int nb_, int tp, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
         const int oh = 2 - tp / 3, ow = tp % 3;
@@ -1369,16 +1377,12 @@ __global__ __launch_bounds__(768) void dgrad_k133_to16_kernel(ConvArgs a, int ns
         const int m = wave;
         f32x4 v = ld4(red + (long)m * 256 + lane * 4);
         for (int g = 1; g < G; ++g) v += ld4(red + ((long)g * MT + m) * 256 + lane * 4);
-        const int p = p0 + m * 16 + j;
-        if (p < a.Wo) {
-          const long o = (long)b * a.o_sB + (long)t * a.o_sT + (long)h * a.o_sH + (long)p * a.o_sW + 4 * kq;
+        if (sum_on) {
           if (a.relu_ref) {
-            const f32x4 rr = ld4(a.relu_ref + o);
-            v[0] = rr[0] > 0.f ? v[0] : 0.f; v[1] = rr[1] > 0.f ? v[1] : 0.f;
-            v[2] = rr[2] > 0.f ? v[2] : 0.f; v[3] = rr[3] > 0.f ? v[3] : 0.f;
+            v[0] = rrv[0] > 0.f ? v[0] : 0.f; v[1] = rrv[1] > 0.f ? v[1] : 0.f;
+            v[2] = rrv[2] > 0.f ? v[2] : 0.f; v[3] = rrv[3] > 0.f ? v[3] : 0.f;
           }
-          if (a.addend) v += ld4(a.addend + o);
-          st4(a.out + o, v);
+          st4(a.out + oe, v + adv);
         }
       }
       par ^= 1;

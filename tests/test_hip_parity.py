@@ -286,11 +286,13 @@ def test_conv_block_golden(tag, cin, kernel_variant):
         gclose("d" + k, p.grad[0], gref)
 
 
-@pytest.mark.parametrize("T,H,W", [(8, 9, 72), (3, 5, 200), (8, 6, 200), (1, 1, 1), (2, 2, 17), (3, 21, 40)])
+@pytest.mark.parametrize("T,H,W", [(8, 9, 72), (3, 5, 200), (8, 6, 200), (1, 1, 1), (2, 2, 17), (3, 21, 40), (2, 3, 31), (2, 2, 2)])
 @variants('default', 'conv_split', 'conv_f22', 'conv16_regs', 'wgrad16_regs')
 def test_proj_var_vs_oracle(T, H, W, set_opt, kernel_variant):
     """Multi-tile widths (72 = 3+2 column blocks, 200 = 4+3+3+3 incl. both frame edges), thin extents
-    (clamp-everything cases).  Strict gradient tolerance on a tie-free case."""
+    (clamp-everything cases).  W = 31 (W % 16 == 15): the data gradient's right-hand virtual column falls into the NEXT
+    16-column tile, so the edge columns take the atomic path instead of the in-wave fold; W = 2: the narrowest folded frame;
+    W = 1: both virtual columns fold onto the one real column (atomics).  Strict gradient tolerance on a tie-free case."""
     from oracle import idee_oracle as O
     ops = _ops()
     N, V, C = 2, 2, 16
