@@ -1458,14 +1458,27 @@ __global__ void fold_bwd_p_kernel(const float* __restrict__ dweff, const float* 
   const int G = per_var ? 1 : V;
   float acc = 0.f;
   const long total = (long)rows * G * 18;
-#pragma unroll 8                      // (as in fold_fwd_kernel: 40 serialized round trips per thread at the joint head's size)
-  for (long e = threadIdx.x; e < total; e += blockDim.x) {
-    const int tap = (int)(e % 18); long r = e / 18;
-    const int g = (int)(r % G); const int row = (int)(r / G);
-    const int v = per_var ? row / Co : g;
-    const float wv = w[(((long)row * G + g) * C + c) * 18 + tap];
-    const int ch = i < D ? v * D + i : V * D;
-    acc = fmaf(wv, dweff[((long)row * CP + (tap / 9) * R + ch) * 9 + tap % 9], acc);
+  // eight (w, dweff) pairs requested per trip before the first is used (one pair and its wait per trip: 40 serialized memory
+  // round trips per thread at the joint head's size — `#pragma unroll` alone left the loads in program order behind their fmas)
+  constexpr int UN = 8;
+  for (long e0 = threadIdx.x; e0 < total; e0 += (long)UN * blockDim.x) {
+    float wv[UN], dv[UN];
+    bool on_[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = e0 + (long)u * blockDim.x;
+      const bool on = e < total;
+      on_[u] = on;
+      const long ec = on ? e : e0;
+      const int tap = (int)(ec % 18); long r = ec / 18;
+      const int g = (int)(r % G); const int row = (int)(r / G);
+      const int v = per_var ? row / Co : g;
+      const int ch = i < D ? v * D + i : V * D;
+      wv[u] = w[(((long)row * G + g) * C + c) * 18 + tap];
+      dv[u] = dweff[((long)row * CP + (tap / 9) * R + ch) * 9 + tap % 9];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc = fmaf(on_[u] ? wv[u] : 0.f, dv[u], acc);      // (masked AFTER all loads are out)
   }
   __shared__ float sm[4];
   acc = wave_sum(acc);
