@@ -2052,6 +2052,8 @@ __global__ __launch_bounds__(256, 2) void wgrad16_glds_kernel(WgradArgs a, int n
 // (common.h ActGuard: per work unit, k = 0 until a staged row's largest |x| reaches 2^15; then the unit's rows are staged again
 // with 2^k, k < 0, and the accumulators, which carry 2^(k_dy + k_x), are multiplied along).
 // NB output blocks per wave (blockIdx.z picks the group; 16 input channels): NB = 3 for the (1,3,3) sign-field convs 16 -> 48 k.
+// (NB = 1, the 16 -> 16 convolutions, now runs on wgrad16_shift_kernel below: a third of the LDS reads; this kernel keeps NB = 3,
+//  whose three shifted dy operands per output block would not fit the register file.)
 template <int MODE /*FWD_REP | FWD_S2*/, int TSL, bool F16 = false, int NB = 1>
 __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
   constexpr int NTAPS = TSL * 9;
@@ -2255,6 +2257,238 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
       v += __shfl_xor(v, 32, 64);
       if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + (gb0 + n) * 16 + lane, v);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad16_shift_kernel: the 16 -> 16 weight gradient of wgrad16_split_kernel with the W taps taken on the dy operand.
+//   acc[ot][oh][ow][cin][cout] += sum_q x_pad[row(oh), frame(ot)][q][cin] dy[q - ow][cout]     (q: padded W coordinate, x_pad[q] = x[q - 1])
+// A strip is 32 PADDED pixels q0 .. q0 + 31 (strips tile [0, W + 2): the same 7 strips at W = 200): the x fragments of a staged
+// row are the same for the three W taps, so a row is read from LDS ONCE per (ot, oh) — 36 transposing reads per output row where
+// wgrad16_split_kernel issues 108, each now feeding 9 MFMAs instead of 3 (profiles r04: that kernel's LDS pipe was busy half of
+// its time, a quarter of it on bank conflicts) — and the shift lives in the registers of the dy operand: a lane loads the 10
+// pixels q0 + 8 kq - 2 .. + 7 of its output channel and forms the three shifted 8-pixel operands by register naming.  No halo
+// pixels in the staged rows (32 x 64 B); the hi / lo halves of a pixel's 64 bytes swap places with (pixel bit 1) xor (pixel bit 3),
+// which makes the 8-byte writes (banks mod 32, 4 pixels per service group) and the transposing reads (banks mod 64, pixels
+// 8 kq .. 8 kq + 3 of two kq per group) both conflict-free; the reads' swizzle is static per lane because nothing shifts.
+// Scales (F16): as wgrad16_split_kernel — GradScale on the dy row (all 10 pixels of every lane), ActGuard on the x rows.
+// ---------------------------------------------------------------------------------------------
+template <int MODE /*FWD_REP | FWD_S2*/, int TSL, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void wgrad16_shift_kernel(WgradArgs a, int nstrip, int hrun, int nhrun) {
+  constexpr int NTAPS = TSL * 9, NR = TSL * 3;
+  constexpr int ROWW = 32 * 16;                    // 32-bit words per staged row: 32 pixels x (8 words hi + 8 words lo)
+  __shared__ __attribute__((aligned(16))) unsigned s_xw[4][NR * ROWW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y, gb0 = blockIdx.z;
+  unsigned* s_x = s_xw[wave];
+  f32x4 acc[NTAPS];
+  float bsum = 0.f;
+  GradScale gs;
+  ActGuard ag;
+  auto scale_acc = [&](float f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tp = 0; tp < NTAPS; ++tp) acc[tp] *= f;
+  };
+#pragma unroll
+  for (int tp = 0; tp < NTAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nb = a.B / a.wsets;
+  const long nunits = (long)nb * a.To * nhrun * nstrip;
+  // transposed read of this lane: pixel 8 kq + (r16 >> 2) [+ 4 for the second read], channels 4 (r16 & 3) ..; lo piece: ^ 8 words
+  const int px0 = 8 * kq + (r16 >> 2);
+  const int tr_hi = px0 * 16 + (((px0 >> 1) ^ (px0 >> 3)) & 1) * 8 + 2 * (r16 & 3);
+  typedef short s16x4t __attribute__((ext_vector_type(4)));
+  auto tr = [&](const unsigned* p) __attribute__((always_inline)) {
+    const s16x4t t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4t __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(unsigned long long, t);
+  };
+
+  for (long un = (long)blockIdx.x * 4 + wave; un < nunits; un += (long)gridDim.x * 4) {
+    long r = un;      // t fastest: see conv16_lds_kernel
+    const int t = (int)(r % a.To); r /= a.To;
+    const int sp = (int)(r % nstrip); r /= nstrip;
+    const int hr = (int)(r % nhrun);
+    const int b = (int)(r / nhrun) * a.wsets + wset;
+    const int q0 = sp * 32;
+    const int qn = min(32, a.W + 2 - q0);           // padded pixels of this strip
+    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
+    int res0 = -1, res1 = -1, res2 = -1;
+    const float* x_b = a.x + (long)b * a.x_sB;
+    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT + goff(gb0, a.y_gpu, a.y_sU, a.y_sG) + r16;
+    int tsrc[TSL];
+#pragma unroll
+    for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : a.kt * t + ot;
+    if (F16 && ag.k != 0) {          // a new unit starts unguarded again (wave-uniform; rare)
+      scale_acc(pow2i(-ag.k < 126 ? -ag.k : 126));
+      ag = ActGuard();
+    }
+
+    // dy of a row: e[i] = dy[q0 + 8 kq - 2 + i] of output channel r16; ten loads from clamped addresses, masked at their use
+    auto load_dy = [&](int hh, float (&ee)[10]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int p = q0 + 8 * kq - 2 + i;
+        ee[i] = dy_b[(long)hh * a.y_sH + (long)min(max(p, 0), a.W - 1) * a.y_sW];
+      }
+    };
+    // one source row of all T slots, raw (two 16-byte units per lane and slot; zero outside the frame / the strip)
+    auto load_row = [&](int hs, bool inside, f32x4 (&st)[TSL][2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ot = 0; ot < TSL; ++ot) {
+        const float* src = x_b + (long)tsrc[ot] * a.x_sT + (long)hs * a.x_sH;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int u = lane + 64 * k;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (u < qn * 4 && inside) {
+            const int w = q0 + (u >> 2) - 1;
+            if (MODE == FWD_REP) v = ld4(src + (long)min(max(w, 0), a.W - 1) * a.x_sW + 4 * (u & 3));
+            else if (w >= 0 && w < a.W) v = ld4(src + (long)w * a.x_sW + 4 * (u & 3));
+          }
+          st[ot][k] = v;
+        }
+      }
+    };
+    // The NEXT output row's operands are requested before this row's MFMA loop and used after it: its dy row and the one source
+    // row it adds to the ring (tag pf_row = that row + 1; a row the ring already holds is never taken from here).  Their
+    // registers are live over the MFMA loop only, where the staging registers are dead; without this every output row exposed
+    // one memory round trip per wave (loads issued and waited for at the top of the row).
+    float e[10];
+    f32x4 pf[TSL][2];
+    int pf_row = -1;
+    load_dy(h0, e);
+
+    for (int h = h0; h < h1;) {
+      wave_fence();
+      int slot_of[3];
+      bool redo = false;
+      int redo_dk = 0;
+#pragma unroll
+      for (int oh = 0; oh < 3; ++oh) {
+        const int hs = MODE == FWD_REP ? min(max(h + oh - 1, 0), a.H - 1) : h + oh - 1;
+        const bool inside = hs >= 0 && hs < a.H;
+        const int slot = (hs + 3) % 3;
+        slot_of[oh] = slot;
+        const int cur = slot == 0 ? res0 : slot == 1 ? res1 : res2;
+        if (cur == hs + 1) continue;
+        if (slot == 0) res0 = hs + 1; else if (slot == 1) res1 = hs + 1; else res2 = hs + 1;
+        f32x4 stg[TSL][2];
+        if (pf_row == hs + 1) {           // (wave-uniform) requested a row ago
+#pragma unroll
+          for (int ot = 0; ot < TSL; ++ot)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) stg[ot][k] = pf[ot][k];
+        } else {
+          load_row(hs, inside, stg);
+        }
+        if constexpr (F16) {
+          float am = 0.f;
+#pragma unroll
+          for (int ot = 0; ot < TSL; ++ot)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) am = amax_acc(am, stg[ot][k]);
+          if (ag.exceeds(am)) {             // (rare: |x| >= 2^15 at the unit's scale) lower the scale, stage the ring again
+            redo_dk = ag.lower(wave_umax(__float_as_uint(ActGuard::finite(am))));
+            res0 = res1 = res2 = -1;
+            redo = true;
+            break;
+          }
+          const float xsc = ag.s();         // (1 unless the guard has fired in this unit)
+#pragma unroll
+          for (int ot = 0; ot < TSL; ++ot)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) stg[ot][k] *= xsc;
+        }
+#pragma unroll
+        for (int ot = 0; ot < TSL; ++ot) {
+          unsigned* dst = s_x + (ot * 3 + slot) * ROWW;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int u = lane + 64 * k, px = u >> 2;
+            const int o = px * 16 + (((px >> 1) ^ (px >> 3)) & 1) * 8 + (u & 3) * 2;
+            const Split p = split2<F16>(stg[ot][k]);
+            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2v*>(dst + o) = u32x2v{p.h01, p.h23};
+            *reinterpret_cast<u32x2v*>(dst + (o ^ 8)) = u32x2v{p.l01, p.l23};
+          }
+        }
+      }
+      if (F16 && redo) {                  // (h not advanced: the row's ring is staged again at the new scale, which the
+        scale_acc(pow2i(redo_dk < -126 ? -126 : redo_dk));   //  accumulators follow)
+        continue;
+      }
+      float ev[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int p = q0 + 8 * kq - 2 + i;
+        ev[i] = (p >= 0 && p < a.W) ? e[i] : 0.f;
+      }
+      bsum += ((ev[1] + ev[2]) + (ev[3] + ev[4])) + ((ev[5] + ev[6]) + (ev[7] + ev[8]));      // the ow = 1 operand: every dy pixel once
+      if constexpr (F16) {
+        float am = 0.f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) am = fmaxf(am, __builtin_fabsf(ev[i]));
+        const float f = gs.update(wave_umax(__float_as_uint(am)));
+        if (f != 1.f) scale_acc(f);
+        const float gsc = gs.s();
+#pragma unroll
+        for (int i = 0; i < 10; ++i) ev[i] *= gsc;
+      }
+      u32x4 Bh[3], Bl[3];                 // dy shifted by ow pixels: K index jj <-> dy pixel q0 + 8 kq + jj - ow = ev[jj + 2 - ow]
+#pragma unroll
+      for (int ow = 0; ow < 3; ++ow) {
+        const Split s0 = split2<F16>(f32x4{ev[2 - ow], ev[3 - ow], ev[4 - ow], ev[5 - ow]});
+        const Split s1 = split2<F16>(f32x4{ev[6 - ow], ev[7 - ow], ev[8 - ow], ev[9 - ow]});
+        Bh[ow] = u32x4{s0.h01, s0.h23, s1.h01, s1.h23};
+        Bl[ow] = u32x4{s0.l01, s0.l23, s1.l01, s1.l23};
+      }
+      const bool more = h + 1 < h1;       // (wave-uniform)
+      if (more) {
+        load_dy(h + 1, e);
+        const int hs = MODE == FWD_REP ? min(h + 2, a.H - 1) : h + 2;
+        pf_row = hs + 1;
+        load_row(hs, hs < a.H, pf);
+      }
+      wave_fence();
+      // the x fragments of staged row r + 1 are read while row r is multiplied (9 MFMAs per read; scheduling fences as in
+      // wgrad16_split_kernel); the three W taps' accumulators alternate so that no MFMA waits for its predecessor
+      auto rdA = [&](int rr, u32x4& Ah, u32x4& Al) __attribute__((always_inline)) {
+        const int o = (rr / 3 * 3 + slot_of[rr % 3]) * ROWW + tr_hi;
+        const unsigned long long h0_ = tr(s_x + o), h1_ = tr(s_x + o + 64), l0_ = tr(s_x + (o ^ 8)), l1_ = tr(s_x + (o ^ 8) + 64);
+        Ah = u32x4{(unsigned)h0_, (unsigned)(h0_ >> 32), (unsigned)h1_, (unsigned)(h1_ >> 32)};
+        Al = u32x4{(unsigned)l0_, (unsigned)(l0_ >> 32), (unsigned)l1_, (unsigned)(l1_ >> 32)};
+      };
+      u32x4 Ahb[2], Alb[2];
+      rdA(0, Ahb[0], Alb[0]);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) {
+        if (rr + 1 < NR) rdA(rr + 1, Ahb[(rr + 1) & 1], Alb[(rr + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int tp0 = (rr / 3) * 9 + (rr % 3) * 3;
+#pragma unroll
+        for (int ow = 0; ow < 3; ++ow) acc[tp0 + ow] = mfma_s<F16>(Ahb[rr & 1], Bh[ow], acc[tp0 + ow]);
+#pragma unroll
+        for (int ow = 0; ow < 3; ++ow) acc[tp0 + ow] = mfma_s<F16>(Ahb[rr & 1], Bl[ow], acc[tp0 + ow]);
+#pragma unroll
+        for (int ow = 0; ow < 3; ++ow) acc[tp0 + ow] = mfma_s<F16>(Alb[rr & 1], Bh[ow], acc[tp0 + ow]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ++h;
+    }
+  }
+  float* dw = a.dwp + (long)(blockIdx.x % kWgradCopies) * a.copy_stride + (long)wset * NTAPS * 16 * a.CoutPad;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+  const float un = F16 ? gs.inv() : 1.f, unx = F16 ? ag.inv() : 1.f;   // (two factors: their product may leave f32's range)
+#pragma unroll
+  for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      atomicAdd(dw + ((long)tp * 16 + r0 + r) * a.CoutPad + gb0 * 16 + col, F16 ? acc[tp][r] * un * unx : acc[tp][r]);
+  if (a.dbias) {
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + gb0 * 16 + lane, v);
   }
 }
 
@@ -3552,11 +3786,22 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
     const bool split = conv_split_math(false) && Gb == 1 && Ga == 1;
     const bool f22 = conv_f22_math() && Gb == 1 && Ga == 1;
     const bool f22_k133 = conv_f22_math() && Ga == 1 && d->mode == IDEE_CONV_K133_ZERO && Gb > 1 && Gb % 3 == 0 && !bf;
+    // the 16 -> 16 split kernels take the W taps on the dy operand: strips of 32 PADDED pixels (wgrad16_shift_kernel)
+    const int nstrip_s = cdiv(d->W + 2, 32);
+    const int hr2_s = pick_hrun(d->H, btr * nstrip_s, (long)d->wsets * gz, 2);
+    const int nhr2_s = cdiv(d->H, hr2_s);
+    const long nunits_s = btr * nhr2_s * nstrip_s;
+#define LSHIFT(KERN)                                                                                          \
+  do {                                                                                                        \
+    auto kern = KERN;                                                                                         \
+    hipLaunchKernelGGL(kern, dim3(one_round(cdiv(nunits_s, 4), (long)d->wsets * gz, wg_per_cu(kern, 256)), d->wsets, gz), \
+                       dim3(256), 0, st, a, nstrip_s, hr2_s, nhr2_s);                                         \
+  } while (0)
     if (f22_k133) LSTRIP((wgrad16_split_kernel<FWD_S2, 1, true, 3>));     // the sign-field convs 16 -> 48 k (gz = Gb / 3 groups)
-    else if (rep && f22) LSTRIP((wgrad16_split_kernel<FWD_REP, 3, true>));
-    else if (d->mode == IDEE_CONV_K233_S2_ZERO && f22) LSTRIP((wgrad16_split_kernel<FWD_S2, 2, true>));
-    else if (rep && split) LSTRIP((wgrad16_split_kernel<FWD_REP, 3>));
-    else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSTRIP((wgrad16_split_kernel<FWD_S2, 2>));
+    else if (rep && f22) LSHIFT((wgrad16_shift_kernel<FWD_REP, 3, true>));
+    else if (d->mode == IDEE_CONV_K233_S2_ZERO && f22) LSHIFT((wgrad16_shift_kernel<FWD_S2, 2, true>));
+    else if (rep && split) LSHIFT((wgrad16_shift_kernel<FWD_REP, 3>));
+    else if (d->mode == IDEE_CONV_K233_S2_ZERO && split) LSHIFT((wgrad16_shift_kernel<FWD_S2, 2>));
     else if (rep && !env_is("IDEE_WGRAD16_REGS", "1")) {
       // LDS-DMA staged kernel, cost-axis partition (see conv16_glds_kernel); a one-block last strip's rows weigh by their K-chunks
       auto kern = wgrad16_glds_kernel;
@@ -3575,6 +3820,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
     else if (Gb == 1) LSTRIP((wgrad16_strip_kernel<FWD_S2, 1, 1>));
     else LSTRIP((wgrad16_strip_kernel<FWD_S2, 1, 3>));
 #undef LSTRIP
+#undef LSHIFT
   }
   else if (!rep && (Ga == Gb || Ga == 1) && (Gb == 6 || Gb == 3 || Gb == 2 || (Gb % 6 == 0 && Ga % 6 == 0)) && d->Cout % 16 == 0) {
     // wide LDS-staged kernel: segment width from the LDS budget (ring of 3 x rows + dy row, padded pixel strides)
