@@ -156,6 +156,13 @@ __device__ __forceinline__ Split split2(f32x4 x) {
   return p;
 }
 
+// one PAIR of elements as f16 pieces (the values split2<PM_F16X2> gives; no inline asm): hi = packed halves, lo = packed residuals
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& hi, unsigned& lo) {
+  const h16x2 h = __builtin_convertvector(f32x2{a, b}, h16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = cvt_pk_f16(a - (float)h[0], b - (float)h[1]);      // (exact residuals; compiler-scheduled: v_cvt_f32_f16 x 2, v_pk_add_f32)
+}
+
 // ---- f16 pieces at f32 level: exact power-of-two scale factors (swin_mfma.hip "f16 pieces at f32 level", conv_mfma.hip) ----
 __device__ __forceinline__ float pow2i(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }   // |k| <= 126
 // max over the 64 lanes, every lane gets it: four DPP row rotations (16-lane rows) and gfx950's two permlane swaps — ten VALU
