@@ -248,8 +248,9 @@ def math_label(math, cfg, dtype="f32"):
                       "weights pre-scaled by a power of two); every data and weight gradient exact f32 MFMA",
                  everything_else="f32")
         if swin:
-            d["swin_gemm"] = ("forward: two f16 pieces per operand, all 4 piece products, f32 accumulate (operand rounding 2^-22), attention "
-                              "scores on the f32 MFMA; backward: exact f32 MFMA")
+            d["swin_gemm"] = ("forward: two f16 pieces per operand, f32 accumulate (operand rounding 2^-22), the attention scores (head_dim "
+                              "8: a lane's two dims x three piece products in the K = 32 slots of one MFMA) and P.V included; backward: "
+                              "exact f32 MFMA")
             if math == "f22":
                 d["conv"] = ("16->16 and 96-wide convs, forward, data gradient and weight gradient, and the (1,3,3) forward and weight "
                              "gradient: two f16 pieces per operand, 3 piece products; weights prescaled by a power of two per set, dy scaled "
@@ -260,14 +261,16 @@ def math_label(math, cfg, dtype="f32"):
                 d["swin_gemm"] = ("forward and backward: two f16 pieces per operand, all 4 piece products, f32 accumulate; weight tensors "
                                   "prescaled by a power of two per tensor (largest |w| in [2^6, 2^7)), the incoming gradient scaled by a "
                                   "power of two per 32-token work item (largest |dy| in [2^1, 2^8)): operand rounding max(2^-22 |x|, "
-                                  "2^-26 of the tile's / tensor's largest element); attention scores on the f32 MFMA")
+                                  "2^-26 of the tile's / tensor's largest element); forward attention scores (head_dim 8) and P.V on f16 "
+                                  "pieces too; the backward's S = K Q^T and dP = V dO^T (K = head_dim) on the exact f32 MFMA")
         return d
     d = dict(conv="16->16 convs (all three passes) and the forward / data gradient of the 96-wide convs: two 16-bit pieces per operand, "
                   "3 piece products (f16 fwd: 2^-22 operand rounding, bf16 bwd: 2^-18); every other conv kernel exact f32 MFMA",
              everything_else="f32")
     if swin:
         d["swin_gemm"] = ("C = 16 and C = 32: two 16-bit pieces per operand, all 4 piece products, f32 accumulate (f16 pieces fwd: 2^-22 "
-                          "operand rounding; bf16 pieces bwd: 2^-18); attention scores on the f32 MFMA")
+                          "operand rounding, attention scores at head_dim 8 and P.V included; bf16 pieces bwd: 2^-18, its attention "
+                          "scores on the f32 MFMA)")
     return d
 
 
@@ -520,7 +523,7 @@ def main():
                       "2^-22), every backward pass exact f32" if a.math == "fwd22" else
                       "f32 storage and accumulation; GEMM operands as two f16 pieces at f32 level (operand rounding 2^-22: weights prescaled by "
                       "exact powers of two per tensor, gradients per tile, convolution inputs under a range guard) in the Swin block and the "
-                      "16->16 / 96-wide / (1,3,3)-forward convolutions; attention scores, the (1,3,3) data gradient and the Cout = 1 "
+                      "16->16 / 96-wide / (1,3,3)-forward convolutions; the backward's attention scores, the (1,3,3) data gradient and the Cout = 1 "
                       "convolutions exact f32 (see `math`, `exact_f32`)"
                       if a.math == "f22" else
                       "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs"),
