@@ -768,6 +768,28 @@ def test_losses_golden():
     close("an_r/dz_q", zq.grad, a["an_r/dz_q"], atol=1e-9, rtol=1e-3)
 
 
+@pytest.mark.parametrize("M", [12, 4000, 32768, 160000, 160004, 1000003])
+@pytest.mark.parametrize("kind", ["binary", "all_equal", "real_valued"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_bce_class_counts_vs_histc(M, kind, masked):
+    """idee_bce_class_counts against torch.histc(target[valid], bins=2) (losses.py:80, :115) on the CPU: the one-workgroup kernel
+    (small or unaligned M) and the many-workgroup kernel (M >= 32768, 16-byte loadable) — labels in {0, 1}, a constant target
+    (histc widens its range to [min - 1, max + 1]), real-valued targets (data-derived range), with and without a validity mask.
+    Counts are integers: exact."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + len(kind))
+    if kind == "binary":
+        t = (torch.rand(M, generator=g) < 0.3).float()
+    elif kind == "all_equal":
+        t = torch.full((M,), 1.0)
+    else:
+        t = torch.randn(M, generator=g) * 3.0 + 0.5
+    v = (torch.rand(M, generator=g) < 0.8).float() if masked else None
+    ref = torch.histc(t[v.bool()] if masked else t, bins=2)
+    got = ops.bce_class_counts(dev(t), dev(v) if masked else None).cpu()
+    assert torch.equal(got, ref), (got, ref)
+
+
 @pytest.mark.parametrize("E,K,valid", [(16, 2, False), (16, 2, True), (16, 4, True), (32, 2, False), (32, 4, True)])
 def test_anomaly_loss_on_code_bits_vs_oracle(E, K, valid):
     """The rank-d form of the anomaly loss (ops.AnomalyL1Signs: reads LFQ's code bits, returns gradients for the bits and
