@@ -258,7 +258,9 @@ def math_label(math, cfg, dtype="f32"):
                              "gradients, accumulators rescaled along), activations under a range guard (split as they are until a staged "
                              "tile's largest |x| reaches 2^15, then scaled by an exact 2^k: any finite input keeps two normal pieces); data "
                              "gradient of the (1,3,3) sign-field convs and the Cout = 1 convs exact f32")
-                d["swin_gemm"] = ("forward and backward: two f16 pieces per operand, all 4 piece products, f32 accumulate; weight tensors "
+                d["swin_gemm"] = ("forward and backward: two f16 pieces per operand, f32 accumulate — all 4 piece products in the linear layers, "
+                                  "3 (lo x lo, 2^-22 of a product, dropped) where two 16-token / 16-key blocks share the K = 32 slots of an "
+                                  "MFMA: P.V, the attention backward's row pass, the token-reduction (weight-gradient) GEMMs; weight tensors "
                                   "prescaled by a power of two per tensor (largest |w| in [2^6, 2^7)), the incoming gradient scaled by a "
                                   "power of two per 32-token work item (largest |dy| in [2^1, 2^8)): operand rounding max(2^-22 |x|, "
                                   "2^-26 of the tile's / tensor's largest element); forward attention scores (head_dim 8) and P.V on f16 "
