@@ -485,6 +485,7 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 // lowers k, the chunk's accumulators are multiplied along (exact), and the epilogue multiplies by 2^-k.
 // SC_ACT (forward): the ACTIVATION operands of a wave's chunk are range-guarded the same way (common.h ActGuard): split as they are
 // until an operand's largest |x| reaches 2^15, then scaled by 2^k, k < 0, the chunk's accumulators multiplied along.
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst);     // (LDS-DMA of 64 x 16 bytes: defined with conv16_glds_kernel)
 enum { SC_NONE = 0, SC_GRAD = 1, SC_ACT = 2 };   // scale carried by the f16-piece operand that has no a-priori range
 template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT, int SC = SC_NONE>
 __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
   static_assert(!ASC || MODE == FWD_S2, "activation guard: forward mode");
   constexpr int MT = 4, WAVES = 8;
   constexpr bool F16 = MODE == FWD_S2 || GSC;
-  extern __shared__ __attribute__((aligned(16))) unsigned s_ws[];   // [2][Gk/2 * NT * 2 pieces * 256 words]
+  extern __shared__ __attribute__((aligned(1024))) unsigned s_ws[];   // [2][Gk/2 * NT * 2 pieces * 256 words] piece slabs, then one RAW f32 slab
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y;
@@ -611,11 +612,15 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       const unsigned* wcur = s_ws + (it & 1) * slab;
       unsigned* wnext = s_ws + ((it + 1) & 1) * slab;
       // prefetch the next tap's raw fragments into registers (up to 3 units = 6 x 16 bytes per thread at 6 x 6 blocks)
-      f32x4 pa[3], pb[3];
+      // the next tap's RAW weight slab goes to LDS by DMA (one 1 KB block of 64 x 16 bytes per instruction, the blocks dealt to
+      // the 8 waves) and is converted to piece fragments from there at the end of the tap: as 2 x 3 fragments per thread in
+      // registers through the whole tap it was 24 registers in a kernel that spills
       const bool more = it + 1 < ntap_it;
       if (more) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { const int u = tid + q * 512; if (u < npu) load_unit(tap_of(it + 1), u, pa[q], pb[q]); }
+        const float* rsrc = wp + (long)tap_of(it + 1) * slab + lane * 4;
+        const unsigned rdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(s_ws + 2 * slab));
+        for (int blk_ = __builtin_amdgcn_readfirstlane(wave); blk_ < a.Gk * NT; blk_ += WAVES)
+          glds16(rsrc + blk_ * 256, __builtin_amdgcn_readfirstlane(rdst + (unsigned)blk_ * 1024u));
       }
       TapSrc nxt = cur;
       if (more) nxt = tap_src(it + 1);
@@ -698,8 +703,18 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       }
       cur = nxt;
       if (more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA blocks have landed
+        __syncthreads();                                      // ... and every other wave's
+        const float* raw = reinterpret_cast<const float*>(s_ws + 2 * slab);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { const int u = tid + q * 512; if (u < npu) store_unit(wnext, u, pa[q], pb[q]); }
+        for (int q = 0; q < 3; ++q) {
+          const int u = tid + q * 512;
+          if (u < npu) {
+            const int l = u & 63, r = u >> 6, n = r % NT, gp = r / NT;
+            const f32x4 fa = ld4(raw + ((2 * gp) * NT + n) * 256 + l * 4), fb = ld4(raw + ((2 * gp + 1) * NT + n) * 256 + l * 4);
+            store_unit(wnext, u, fa, fb);
+          }
+        }
       }
       __syncthreads();
     }
@@ -3549,8 +3564,8 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         a.tiles = a.To * a.hgroups;
       }
       const bool wide_f22 = (MODE == DGRAD_S2) && conv_f22_math();    // f16 pieces with the per-chunk gradient scale
-      if ((wide_f22 || conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2)) {
-        const long lds2 = 2 * slab_bytes;
+      if ((wide_f22 || conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2) && 3 * slab_bytes <= 156 * 1024) {
+        const long lds2 = 3 * slab_bytes;      // two piece slabs + one raw slab
         // (the kernel keeps a tap's source offsets inside one batch item as 32-bit element counts)
         if ((long)(a.Ti - 1) * a.i_sT + (long)(a.Hi - 1) * a.i_sH + (long)(a.Wi - 1) * a.i_sW >= (1L << 31) - (1L << 24))
           return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (wide, split): a batch item of %d x %d x %d pixels exceeds the 32-bit source offsets", a.Ti, a.Hi, a.Wi);
