@@ -2137,15 +2137,15 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
 
     for (int h = h0; h < h1;) {
       wave_fence();
-      // dy of this row: lane (cout = r16, pixels p0 + 8 kq + {0..7}); pixels past the row end contribute zero
+      // dy of this row: lane (cout = r16, pixels p0 + 8 kq + {0..7}); pixels past the row end contribute zero.  All 8 NB loads are
+      // issued from clamped addresses and masked after the staging below (`on ? load : 0` was a branch around every load)
       f32x4 d0[NB], d1[NB];
 #pragma unroll
       for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-          const int p = p0 + 8 * kq + jj;
-          const bool on = 8 * kq + jj < 16 * my_sub && p < a.W;
-          const float v = on ? dy_b[(long)h * a.y_sH + (long)p * a.y_sW + goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16] : 0.f;
+          const int p = min(p0 + 8 * kq + jj, a.W - 1);
+          const float v = dy_b[(long)h * a.y_sH + (long)p * a.y_sW + goff(gb0 + n, a.y_gpu, a.y_sU, a.y_sG) + r16];
           if (jj < 4) d0[n][jj] = v; else d1[n][jj - 4] = v;
         }
       int slot_of[3];
@@ -2213,6 +2213,13 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
         scale_acc(pow2i(redo_dk < -126 ? -126 : redo_dk));   //  accumulators follow)
         continue;
       }
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const bool on = 8 * kq + jj < 16 * my_sub && p0 + 8 * kq + jj < a.W;
+          if (jj < 4) d0[n][jj] = on ? d0[n][jj] : 0.f; else d1[n][jj - 4] = on ? d1[n][jj - 4] : 0.f;
+        }
 #pragma unroll
       for (int n = 0; n < NB; ++n) bsum[n] += hsum4(d0[n]) + hsum4(d1[n]);
       if constexpr (F16) {
