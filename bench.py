@@ -16,9 +16,12 @@ With --gpus N > 1 and no torchrun environment, this script starts the N ranks it
 BEFORE this process touches the GPU; rendezvous on 127.0.0.1) and exits with their status; it never prints a line
 for fewer ranks than were asked for.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel FAMILY (all launches of the entry
-point with the largest share of the step; duration from HIP events recorded on the launch stream inside the timed
-region) and `cpu_baseline` (the CPU oracle, oracle/idee_oracle.py, timed on this box's host cores — rank 0, N=1 only).
+Prints ONE JSON line (rank 0).  `value` / `ms_per_step` / `roofline` are the EXACT-F32 arithmetic (--math f32, the default:
+the reference's fp32).  Extra objects: `roofline` for the dominant kernel FAMILY (all launches of the entry point with the
+largest share of the step; duration from HIP events recorded on the launch stream inside the timed region; priced against the
+ceiling of the pipe that ran, see roofline_of), `f22` (the f16-piece arithmetic of the same workload timed in the same run,
+with its own roofline — a side line, narrower than f32) and `cpu_baseline` (the CPU oracle, oracle/idee_oracle.py, timed on
+this box's host cores — rank 0, N=1 only).
 """
 import argparse
 import json
@@ -57,21 +60,20 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
     ap.add_argument("--hw", type=int, default=None, help="override grid height = width")
     ap.add_argument("--encoder", default=None, help="override the config's encoder")
-    ap.add_argument("--math", default="f22", choices=["f32", "split", "fwd22", "f22"],
-                    help="f22 (default; see below): f32 storage and accumulation, GEMM operands as two f16 pieces at f32 level.  With "
-                         "--dtype f32 the exact-f32 line is measured in the same run and printed beside it (`exact_f32`).  "
-                         "f32: every GEMM-shaped kernel on the exact-f32 MFMA (the reference's arithmetic, the library's own default).  split: the "
-                         "opt-in two-piece split-precision kernels, convolutions (IDEE_CONV_MATH=split) AND Swin linear layers "
-                         "(IDEE_SWIN_MATH=split) — a separately labelled line, never the headline.  fwd22: only the FORWARD passes on the "
-                         "split kernels (f16 pieces: operand rounding 2^-22), every backward pass exact f32 — also a separate line.  f22: the Swin block's "
-                         "forward AND backward on f16 pieces with power-of-two prescaled weights and a per-work-item gradient scale "
-                         "(IDEE_SWIN_MATH=f22; operand rounding 2^-22 in every GEMM), convolutions: forward as in fwd22, 16->16 gradients on f16 "
-                         "pieces with per-tile gradient scales (IDEE_CONV_MATH=f22) — a separate line")
+    ap.add_argument("--math", default="f32", choices=["f32", "split", "fwd22", "f22"],
+                    help="f32 (default = the headline): every GEMM-shaped kernel on the exact-f32 MFMA — the reference's arithmetic and the "
+                         "library's own default; with one GPU the f16-piece line (`f22`) is measured in the same run and printed beside it as a "
+                         "labelled side object with its own roofline.  f22: f32 storage and accumulation, GEMM operands as two f16 pieces "
+                         "(operand rounding 2^-22: narrower than f32) with power-of-two prescaled weights, per-tile gradient scales and an "
+                         "activation range guard, Swin block forward + backward and the 16->16 / 96-wide / (1,3,3)-forward convolutions "
+                         "(IDEE_SWIN_MATH = IDEE_CONV_MATH = f22); `exact_f32` is then printed beside it.  fwd22: only the FORWARD passes on f16 "
+                         "pieces.  split: f16 pieces forward, bf16 pieces (2^-18) backward.  Neither is ever the default line")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="activation storage between the fused units.  f32 (default): the reference's arithmetic.  bf16: BASELINE "
                          "config #4's precision — bf16 tokens, bf16 MFMA GEMMs / convolutions with f32 accumulate, f32 LFQ, losses, "
                          "master weights and optimizer (Swin_3D encoder)")
-    ap.add_argument("--no-exact-line", action="store_true", help="--math f22: skip the exact-f32 measurement printed beside the line")
+    ap.add_argument("--no-side-line", "--no-exact-line", dest="no_side_line", action="store_true",
+                    help="skip the other arithmetic's line (--math f32: `f22`; --math f22: `exact_f32`) measured beside the headline")
     ap.add_argument("--codebook", default="LFQ", choices=["LFQ", "VQ"],
                     help="LFQ: what the reference's build.py wires.  VQ: the nearest-neighbour codebook of models/codebook/VQ.py in its "
                          "place (BASELINE config #4's '+ VQ codebook' variant line)")
@@ -355,6 +357,139 @@ def cpu_baseline(cfg, kind, model, T, H, W):
                        f"median; eval forward median of 3")
 
 
+DTYPE_TEXT = {
+    "f32": "f32",
+    "fwd22": "f32 storage/accumulate; forward convolutions and Swin linear layers on two-piece f16 split MFMAs (operand rounding "
+             "2^-22), every backward pass exact f32",
+    "f22": "f32 storage and accumulation; GEMM operands as two f16 pieces (operand rounding 2^-22: weights prescaled by exact powers of "
+           "two per tensor, gradients per tile, convolution inputs under a range guard) in the Swin block and the 16->16 / 96-wide / "
+           "(1,3,3)-forward convolutions; the backward's attention scores, the (1,3,3) data gradient and the Cout = 1 convolutions "
+           "exact f32 (see `math`)",
+    "split": "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs",
+}
+
+TIMED = ["idee_conv_fwd", "idee_conv_dgrad", "idee_conv_dgrad_add", "idee_conv_wgrad", "idee_swin_block_fwd", "idee_swin_block_bwd",
+         "idee_lfq_fwd", "idee_lfq_bwd", "idee_patch_embed_ln_fwd", "idee_patch_embed_ln_bwd", "idee_anomaly_l1_fwd", "idee_anomaly_l1_signs_fwd",
+         "idee_anomaly_l1_signs_bwd", "idee_anomaly_l1_bwd", "idee_adam_step", "idee_ln_relu_res_fwd", "idee_ln_relu_res_bwd"]
+
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (v_mfma_f32_16x16x32_{f16,bf16})
+
+
+def piece_products(name, shape, math):
+    """How many 16-bit piece products per multiply-add the kernels of this launch execute on the f16 / bf16 MFMA under `math`
+    (DESIGN.md §3d), or 0 when the launch runs on the exact-f32 MFMA / is a streaming kernel.  `shape`: ConvDesc or SwinGeom."""
+    if math == "f32":
+        return 0.0
+    if name.startswith("idee_swin_block_"):
+        if getattr(shape, "drop", 0.0) > 0 or getattr(shape, "attn_drop", 0.0) > 0:
+            return 0.0                                   # element-wise dropout: the exact kernels under any option
+        bwd = name.endswith("bwd")
+        if math == "fwd22" and bwd:
+            return 0.0
+        nw, C = shape.wd * shape.wh * shape.ww, shape.C
+        lin, att = 24.0 * C * C, 4.0 * nw * C
+        # linear layers: all 4 piece products; attention scores / P.V and (backward) the token-reduction GEMMs: 3
+        return (4 * lin + 3 * att) / (lin + att) if not bwd else 3.5
+    if name.startswith("idee_conv_"):
+        if shape.Cout == 1 or shape.Cin == 1:
+            return 0.0                                   # streaming dot products / generic kernel
+        if shape.mode == 2 and name.startswith("idee_conv_dgrad"):
+            return 0.0                                   # (1,3,3) data gradient: the exact K-split kernel
+        if math == "fwd22" and not name.endswith("fwd"):
+            return 0.0
+        return 3.0
+    return 0.0
+
+
+def family_table(log):
+    """event log -> (per (entry point, shape): [ms, launches, flops/launch, bytes/launch, piece-product flops/launch],
+    per entry point: [ms, launches, flops, bytes, piece-product flops] summed over the timed region)."""
+    import ctypes
+    from idee_amd import _lib
+    per, fam = {}, {}
+    math = _lib.get_option("IDEE_SWIN_MATH") or "f32"
+    cmath = _lib.get_option("IDEE_CONV_MATH") or "f32"
+    for name, evs in log.items():
+        name = "idee_conv_dgrad" if name == "idee_conv_dgrad_add" else name      # the same kernels, out = dgrad + addend
+        for e0, e1, args in evs:
+            ms = e0.elapsed_time(e1)
+            key, flops, nbytes, pflops = name, 0.0, 0.0, 0.0
+            if name.startswith("idee_conv_"):
+                d = ctypes.cast(args[0], ctypes.POINTER(_lib.ConvDesc)).contents
+                key = f"{name}[{('k333', 'k233', 'k133')[d.mode]} {d.Cin}->{d.Cout} B{d.B} T{d.T}]"
+                flops, nbytes = conv_flops(d), conv_bytes(d)
+                pflops = flops * (piece_products(name, d, cmath) if d.act_dtype == 0 else 1.0)
+            elif name.startswith("idee_swin_block_"):
+                g = ctypes.cast(args[-2], ctypes.POINTER(_lib.SwinGeom)).contents
+                key = f"{name}[w{g.wd}{g.wh}{g.ww} s{g.sd}{g.sh}{g.sw} C{g.C}]"
+                bwd = name.endswith("bwd")
+                flops, nbytes = swin_flops(g, bwd), swin_bytes(g, bwd)
+                # executed GEMM work of the backward = forward recompute + data gradients + weight gradients = 3 x forward (credited: 2 x)
+                pflops = (1.5 if bwd else 1.0) * flops * (piece_products(name, g, math) if g.act_dtype == 0 else 1.0)
+            r = per.setdefault(key, [0.0, 0, 0.0, 0.0, 0.0])
+            r[0] += ms; r[1] += 1; r[2] = flops; r[3] = nbytes; r[4] = pflops
+            f = fam.setdefault(name, [0.0, 0, 0.0, 0.0, 0.0])
+            f[0] += ms; f[1] += 1; f[2] += flops; f[3] += nbytes; f[4] += pflops
+    return per, fam
+
+
+def print_breakdown(per, fam, steps, dt):
+    rows = sorted(per.items(), key=lambda kv: -kv[1][0])
+    tot = sum(v[0] for v in per.values())
+    sys.stderr.write(f"{'entry point':66s} {'ms/step':>9s} {'calls':>6s} {'avg ms':>8s} {'TFLOP/s':>8s} {'alg GB/s':>9s}\n")
+    for k, (ms, n, fl, by, _pf) in rows:
+        sys.stderr.write(f"{k:66s} {ms / steps:9.3f} {n // steps:6d} {ms / n:8.3f} {fl / (ms / n) / 1e9 if fl else 0:8.2f} "
+                         f"{by / (ms / n) / 1e6 if by else 0:9.1f}\n")
+    sys.stderr.write("-- families --\n")
+    for k, (ms, n, fl, by, _pf) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+        sys.stderr.write(f"{k:66s} {ms / steps:9.3f} {n // steps:6d} {ms / n:8.3f} {fl / ms / 1e9 if fl else 0:8.2f} "
+                         f"{by / ms / 1e6 if by else 0:9.1f}\n")
+    sys.stderr.write(f"sum of bracketed entry points {tot / steps:.3f} ms/step; wall {dt / steps * 1e3:.3f} ms/step\n")
+
+
+def roofline_of(fam, math, dtype, steps, dt, headline, a):
+    """`roofline` of the dominant kernel FAMILY (all launches of the entry point with the largest total time in the timed
+    region; duration from the HIP events recorded on the launch stream), priced against the ceiling of the pipe that ran:
+
+      exact f32 (--math f32):  reference-formulation FLOPs against the f32 MFMA peak, 157.3 TFLOP/s
+                               (v_mfma_f32_16x16x4_f32 runs at the f32 vector rate) — bound "mfma";
+      f16 pieces (--math f22 / fwd22 / split) and bf16 activations:  BOTH ceilings of those kernels — algorithmic HBM bytes
+                               (unit inputs + outputs) per second against 8 TB/s, and the EXECUTED piece-product
+                               FLOPs (reference FLOPs x piece products per multiply-add x 1.5 for the Swin backward's recompute)
+                               against the dense f16 / bf16 MFMA peak, 2.5 PFLOP/s — `bound` / `frac` are those of the ceiling the
+                               family sits closer to, the other one is printed beside it.  No line can print a fraction >= 1.
+
+    A launch of the dominant family that stays on the exact-f32 MFMA under an f16-piece option (dropout blocks, the (1,3,3) data
+    gradient) counts with its f32 FLOPs against the f32 peak only in an f32 run; under f22 its time is in the family's time and
+    it adds no piece-product FLOPs."""
+    cand = sorted(((k, v) for k, v in fam.items() if v[2] > 0), key=lambda kv: -kv[1][0])
+    if not cand:
+        return None
+    k, (ms, n, fl, by, pf) = cand[0]
+    lps = n // steps
+    common = dict(kernel=k + " (all launches of this entry point in the step)", avg_launch_ms=round(ms / n, 4), launches_per_step=lps,
+                  flops_per_launch=fl / n, bytes_per_launch=by / n, share_of_step=round(ms / steps / (dt / steps * 1e3), 4))
+    if dtype == "bf16":
+        traffic, src = pmc_traffic(k, lps, a.config == "4" and a.hw is None and a.batch is None, PMC_SUMMARY_BF16)
+    else:
+        traffic, src = pmc_traffic(k, lps, headline and math in ("f32", "f22"), PMC_SUMMARY_F22 if math == "f22" else PMC_SUMMARY)
+    gbs, tf_eq = by / ms / 1e6, fl / ms / 1e9
+    if dtype == "f32" and math == "f32":
+        return dict(common, bound="mfma", achieved=round(tf_eq, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(tf_eq / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=src,
+                    pipe="v_mfma_f32_16x16x4_f32 (f32 MFMA = f32 vector rate; it does not co-execute with the VALU stream, so "
+                         "LayerNorm / softmax / GELU time adds to the MFMA time in the fused Swin kernels)",
+                    algorithmic_gbs=round(gbs, 1))
+    ptf = pf / ms / 1e9
+    hbm = dict(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
+    mf = dict(achieved=round(ptf, 1), peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ptf / PEAK_F16_MFMA_TFLOPS, 4),
+              note="executed 16-bit piece-product FLOPs on v_mfma_f32_16x16x32_{f16,bf16}")
+    lead, other = (("hbm", hbm), ("mfma", mf)) if hbm["frac"] >= mf["frac"] else (("mfma", mf), ("hbm", hbm))
+    return dict(common, bound=lead[0], achieved=lead[1]["achieved"], peak=lead[1]["peak"], unit=lead[1]["unit"], frac=lead[1]["frac"],
+                traffic=traffic, traffic_source=src, other_ceiling=dict(bound=other[0], **other[1]),
+                f32_equivalent_tflops=round(tf_eq, 2))
+
+
 def main():
     a = parse()
     if a.dtype == "bf16":
@@ -401,84 +536,35 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        ts.step(x, *masks)
-    timed = ["idee_conv_fwd", "idee_conv_dgrad", "idee_conv_dgrad_add", "idee_conv_wgrad", "idee_swin_block_fwd", "idee_swin_block_bwd",
-             "idee_lfq_fwd", "idee_lfq_bwd", "idee_patch_embed_ln_fwd", "idee_patch_embed_ln_bwd", "idee_anomaly_l1_fwd", "idee_anomaly_l1_signs_fwd", "idee_anomaly_l1_signs_bwd",
-             "idee_anomaly_l1_bwd", "idee_adam_step", "idee_ln_relu_res_fwd", "idee_ln_relu_res_bwd"]
-    log = _lib.set_event_log(timed)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        marks[i].record()
-        ts.step(x, *masks)
-    marks[a.steps].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    _lib.set_event_log(None)
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt)
+    def timed_region(steps, warmup):
+        """W untimed warm-up steps, then EXACTLY `steps` steps between two barriers (+ device synchronisation on both sides); every
+        launch of the entry points in TIMED is bracketed with HIP events on the launch stream.  -> (seconds [max over ranks],
+        per-step event intervals in ms, the event log)."""
+        for _ in range(warmup):
+            ts.step(x, *masks)
+        log = _lib.set_event_log(TIMED)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            marks[i].record()
+            ts.step(x, *masks)
+        marks[steps].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        _lib.set_event_log(None)
+        step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt)
+        return dt, step_ms, log
 
-    # ---- per-entry-point durations (HIP events on the launch stream), dominant family, roofline ----
-    import ctypes
-    per, fam = {}, {}
-    for name, evs in log.items():
-        name = "idee_conv_dgrad" if name == "idee_conv_dgrad_add" else name      # the same kernels, out = dgrad + addend
-        for e0, e1, args in evs:
-            ms = e0.elapsed_time(e1)
-            key, flops, nbytes = name, 0.0, 0.0
-            if name.startswith("idee_conv_"):
-                d = ctypes.cast(args[0], ctypes.POINTER(_lib.ConvDesc)).contents
-                key = f"{name}[{('k333', 'k233', 'k133')[d.mode]} {d.Cin}->{d.Cout} B{d.B} T{d.T}]"
-                flops, nbytes = conv_flops(d), conv_bytes(d)
-            elif name.startswith("idee_swin_block_"):
-                g = ctypes.cast(args[-2], ctypes.POINTER(_lib.SwinGeom)).contents
-                key = f"{name}[w{g.wd}{g.wh}{g.ww} s{g.sd}{g.sh}{g.sw} C{g.C}]"
-                flops, nbytes = swin_flops(g, name.endswith("bwd")), swin_bytes(g, name.endswith("bwd"))
-            r = per.setdefault(key, [0.0, 0, 0.0, 0.0])
-            r[0] += ms; r[1] += 1; r[2] = flops; r[3] = nbytes
-            f = fam.setdefault(name, [0.0, 0, 0.0, 0.0])
-            f[0] += ms; f[1] += 1; f[2] += flops; f[3] += nbytes
-    rows = sorted(per.items(), key=lambda kv: -kv[1][0])
+    dt, step_ms, log = timed_region(a.steps, a.warmup)
+    per, fam = family_table(log)
     if a.breakdown and rank == 0:
-        tot = sum(v[0] for v in per.values())
-        sys.stderr.write(f"{'entry point':66s} {'ms/step':>9s} {'calls':>6s} {'avg ms':>8s} {'TFLOP/s':>8s} {'alg GB/s':>9s}\n")
-        for k, (ms, n, fl, by) in rows:
-            sys.stderr.write(f"{k:66s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / (ms / n) / 1e9 if fl else 0:8.2f} "
-                             f"{by / (ms / n) / 1e6 if by else 0:9.1f}\n")
-        sys.stderr.write("-- families --\n")
-        for k, (ms, n, fl, by) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
-            sys.stderr.write(f"{k:66s} {ms / a.steps:9.3f} {n // a.steps:6d} {ms / n:8.3f} {fl / ms / 1e9 if fl else 0:8.2f} "
-                             f"{by / ms / 1e6 if by else 0:9.1f}\n")
-        sys.stderr.write(f"sum of bracketed entry points {tot / a.steps:.3f} ms/step; wall {dt / a.steps * 1e3:.3f} ms/step\n")
-    roof = None
-    mfma_fams = sorted(((k, v) for k, v in fam.items() if v[2] > 0), key=lambda kv: -kv[1][0])
-    if mfma_fams and a.dtype == "bf16":
-        # bf16 activations: 16 x the MFMA rate of the f32 path at half the bytes — the path is HBM-bound; the
-        # dominant family is priced in algorithmic bytes (conv_bytes / swin_bytes) per second against the HBM peak
-        k, (ms, n, fl, by) = mfma_fams[0]
-        traffic, src = pmc_traffic(k, n // a.steps, a.config == "4" and a.hw is None and a.batch is None, PMC_SUMMARY_BF16)
-        roof = dict(kernel=k + " (all launches of this entry point in the step)", bound="hbm", achieved=round(by / ms / 1e6, 1),
-                    peak=PEAK_HBM_GBS, unit="GB/s", frac=round(by / ms / 1e6 / PEAK_HBM_GBS, 4), traffic=traffic, traffic_source=src,
-                    avg_launch_ms=round(ms / n, 4), bytes_per_launch=by / n, flops_per_launch=fl / n, tflops=round(fl / ms / 1e9, 2),
-                    launches_per_step=n // a.steps, share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
-    elif mfma_fams:
-        k, (ms, n, fl, by) = mfma_fams[0]      # the entry point (all its shapes) with the largest total time in the timed region
-        traffic, src = pmc_traffic(k, n // a.steps, headline and a.math in ("f32", "f22"), PMC_SUMMARY_F22 if a.math == "f22" else PMC_SUMMARY)
-        # what actually limits the family (profiles/r04_sq_counters*.txt): the convolution kernels are paced by the f32 MFMA pipe
-        # (MFMA-busy ~80 %); the fused Swin kernels by VALU issue (LayerNorm / softmax / GELU share the issue slots with the f32
-        # MFMA, which does not co-execute with VALU work on gfx950) — their peak is the same 157.3 TFLOP/s f32 vector rate
-        # (f22: the f16 MFMA overlaps the VALU stream, the Swin kernels stay VALU-issue bound; FLOPs are the reference
-        # formulation's, so `achieved` is an f32-equivalent rate against the f32 vector peak)
-        bound = "valu" if k.startswith("idee_swin") else "mfma"
-        roof = dict(kernel=k + " (all launches of this entry point in the step)", bound=bound, achieved=round(fl / ms / 1e9, 3),
-                    peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
-                    traffic_source=src, avg_launch_ms=round(ms / n, 4), flops_per_launch=fl / n, launches_per_step=n // a.steps,
-                    share_of_step=round(ms / a.steps / (dt / a.steps * 1e3), 4))
+        print_breakdown(per, fam, a.steps, dt)
+    roof = roofline_of(fam, a.math, a.dtype, a.steps, dt, headline, a)
 
     # ---- second half of BASELINE.json's metric: forward ms per clip (eval mode, no autograd), outside the timed region ----
     fwd_ms_clip = float("nan")
@@ -495,49 +581,47 @@ def main():
             fwd_ms_clip = (time.perf_counter() - f0) / 5 / batch * 1e3
         ts.model.train()
 
-    # ---- --math f22: the exact-f32 line of the same workload, measured in this run and printed beside the headline ----
-    exact = None
-    if a.math == "f22" and a.dtype == "f32" and world == 1 and not a.no_exact_line:
-        _lib.set_option("IDEE_CONV_MATH", "f32")      # looked up by the library at every launch
-        _lib.set_option("IDEE_SWIN_MATH", "f32")
-        for _ in range(min(a.warmup, 5)):
-            ts.step(x, *masks)
-        barrier()
-        e0 = time.perf_counter()
-        for _ in range(a.steps):
-            ts.step(x, *masks)
-        barrier()
-        edt = time.perf_counter() - e0
-        _lib.set_option("IDEE_CONV_MATH", "f22")
-        _lib.set_option("IDEE_SWIN_MATH", "f22")
-        exact = dict(value=round(batch * a.steps / edt, 3), unit="samples/s", ms_per_step=round(edt / a.steps * 1e3, 3), steps=a.steps,
-                     dtype="f32", math=math_label("f32", cfg, a.dtype),
-                     note="same process, model, batch and step count, IDEE_SWIN_MATH = IDEE_CONV_MATH = f32 (the library's default "
-                          "arithmetic: every GEMM-shaped kernel on the exact-f32 MFMA), timed after the headline region")
+    # ---- the OTHER arithmetic of the same workload, measured in this run and printed beside the headline: the headline
+    # (`value`, `ms_per_step`, `roofline`) is the reference's arithmetic (exact f32, --math f32 = the default); the f16-piece
+    # line (`f22`: operand rounding 2^-22, narrower than f32) is a labelled side object with its own roofline.
+    # With --math f22 it is the other way round (`exact_f32` beside an f22 `value`).
+    side_key, side = None, None
+    if a.dtype == "f32" and a.math in ("f32", "f22") and world == 1 and not a.no_side_line and enc in ("Swin_3D", "CNN_3D"):
+        other = "f22" if a.math == "f32" else "f32"
+        _lib.set_option("IDEE_CONV_MATH", other)      # looked up by the library at every launch
+        _lib.set_option("IDEE_SWIN_MATH", other)
+        sdt, sstep_ms, slog = timed_region(a.steps, min(a.warmup, 5))
+        sper, sfam = family_table(slog)
+        if a.breakdown and rank == 0:
+            sys.stderr.write(f"==== side line: --math {other} ====\n")
+            print_breakdown(sper, sfam, a.steps, sdt)
+        sroof = roofline_of(sfam, other, a.dtype, a.steps, sdt, headline, a)
+        _lib.set_option("IDEE_CONV_MATH", math_opt)
+        _lib.set_option("IDEE_SWIN_MATH", math_opt)
+        side_key = "f22" if other == "f22" else "exact_f32"
+        side = dict(value=round(batch * a.steps / sdt, 3), unit="samples/s", ms_per_step=round(sdt / a.steps * 1e3, 3),
+                    ms_per_step_median=round(statistics.median(sstep_ms), 3), steps=a.steps,
+                    dtype="f32" if other == "f32" else DTYPE_TEXT["f22"], math=math_label(other, cfg, a.dtype), roofline=sroof,
+                    note=f"same process, model, batch and step count as `value`, IDEE_SWIN_MATH = IDEE_CONV_MATH = {other}, timed after the "
+                         "headline region with the same event bracketing" +
+                         ("; NOT the reference's arithmetic (two f16 pieces per GEMM operand: 22-23 of f32's 24 operand bits) — a side "
+                          "line, never `value`" if other == "f22" else "; the library's default arithmetic"))
 
     if rank != 0:
         return
     out = dict(metric="train samples/sec (TxHxW clips); one step = fwd+losses+bwd+Adam", value=round(world * batch * a.steps / dt, 3),
                unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
                ms_per_step_median=round(statistics.median(step_ms), 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype=("bf16" if a.dtype == "bf16" else "f32" if a.math == "f32" else
-                      "f32 storage/accumulate; forward convolutions and Swin linear layers on two-piece f16 split MFMAs (operand rounding "
-                      "2^-22), every backward pass exact f32" if a.math == "fwd22" else
-                      "f32 storage and accumulation; GEMM operands as two f16 pieces at f32 level (operand rounding 2^-22: weights prescaled by "
-                      "exact powers of two per tensor, gradients per tile, convolution inputs under a range guard) in the Swin block and the "
-                      "16->16 / 96-wide / (1,3,3)-forward convolutions; the backward's attention scores, the (1,3,3) data gradient and the Cout = 1 "
-                      "convolutions exact f32 (see `math`, `exact_f32`)"
-                      if a.math == "f22" else
-                      "f32 storage/accumulate; convolutions and Swin linear layers on two-piece f16 (forward) / bf16 (backward) split MFMAs"),
+               dtype=("bf16" if a.dtype == "bf16" else DTYPE_TEXT[a.math]),
                math=math_label(a.math, cfg, a.dtype),
                codebook=a.codebook,
                data="synthetic",
                config=dict(workload=f"#{a.config}: {label}, V={cfg.in_channels_dynamic}, batch {batch}/GPU" +
                                     (f", grid overridden to {H}x{W}" if a.hw else ""), global_batch=world * batch,
                            parallelism=f"dp{world}"),
-               exact_f32=exact, roofline=roof, fwd_ms_per_clip=None if a.no_fwd_eval else round(fwd_ms_clip, 3), peak_hbm_alloc_gb=round(torch.cuda.max_memory_allocated() / 1e9, 2))
-    if exact is None:
-        del out["exact_f32"]
+               roofline=roof, fwd_ms_per_clip=None if a.no_fwd_eval else round(fwd_ms_clip, 3), peak_hbm_alloc_gb=round(torch.cuda.max_memory_allocated() / 1e9, 2))
+    if side is not None:
+        out[side_key] = side
     if world > 1:
         out["backend"] = torch.distributed.get_backend()
         out["ranks"] = ranks_report

@@ -5,10 +5,10 @@ set -e
 T=$1
 COMMIT=${2:-unknown}
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out      # (every path below is relative to the repo root)
-bash tools/collect_config.sh ${T}_f22 $COMMIT                      # the default line (--math f22, exact_f32 beside it)
-bash tools/collect_config.sh ${T}_f32 $COMMIT --math f32           # exact f32 everywhere, stand-alone
-bash tools/pmc_sq.sh > gpurun_out/${T}_sq_f22.txt 2> gpurun_out/${T}_sq.err
-bash tools/pmc_sq.sh --math f32 > gpurun_out/${T}_sq_f32.txt 2>> gpurun_out/${T}_sq.err
+bash tools/collect_config.sh ${T}_f32 $COMMIT                      # the default line (--math f32 = exact f32, the `f22` side line beside it)
+bash tools/collect_config.sh ${T}_f22 $COMMIT --math f22           # f16 pieces (exact_f32 beside it)
+bash tools/pmc_sq.sh --math f32 > gpurun_out/${T}_sq_f32.txt 2> gpurun_out/${T}_sq.err
+bash tools/pmc_sq.sh --math f22 > gpurun_out/${T}_sq_f22.txt 2>> gpurun_out/${T}_sq.err
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${T}_lines
 mkdir -p $O

@@ -3,13 +3,13 @@
 #   bash tools/publish_round.sh <tag> <rNN>   -> copies the summaries profiles/README.md names into profiles/<rNN>_*
 set -e
 T=$1; R=$2; G=gpurun_out; P=profiles
-cp $G/${T}_f22/bench.json            $P/${R}_bench_default.json
-cp $G/${T}_f22/breakdown.txt         $P/${R}_bench_breakdown.txt
-cp $G/${T}_f22/kernel_stats.csv      $P/${R}_bench_kernel_stats.csv
+cp $G/${T}_f32/bench.json            $P/${R}_bench_default.json
+cp $G/${T}_f22/bench.json            $P/${R}_bench_f22.json
+cp $G/${T}_f22/breakdown.txt         $P/${R}_bench_f22_breakdown.txt
+cp $G/${T}_f22/kernel_stats.csv      $P/${R}_bench_f22_kernel_stats.csv
 cp $G/${T}_f22/pmc_traffic.json      $P/${R}_pmc_traffic_f22.json
 cp $G/${T}_f22/pmc_traffic.txt       $P/${R}_pmc_traffic_f22.txt
 cp $G/${T}_sq_f22.txt                $P/${R}_sq_counters_f22.txt
-cp $G/${T}_f32/bench.json            $P/${R}_bench_f32.json
 cp $G/${T}_f32/breakdown.txt         $P/${R}_bench_f32_breakdown.txt
 cp $G/${T}_f32/kernel_stats.csv      $P/${R}_bench_f32_kernel_stats.csv
 cp $G/${T}_f32/pmc_traffic.json      $P/${R}_pmc_traffic.json
