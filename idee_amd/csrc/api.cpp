@@ -72,7 +72,22 @@ int opt_int(const char* name) {
 
 }  // namespace idee
 
-extern "C" const char* idee_version(void) { return "idee_hip 0.2.0 (gfx950)"; }
+// A build with kernel timing-variant macros (IDEE_EXTRA_FLAGS="-DIDEE_DBG_SKIP=.." skips loads / MFMAs / stores in
+// conv16_split_kernel; -DIDEE_RD_DEPTH changes a read-ahead depth) says so in its version string: the test session
+// (tests/test_host_cpu.py) refuses a library whose version carries "TIMING-VARIANT".
+#define IDEE_STR2(x) #x
+#define IDEE_STR(x) IDEE_STR2(x)
+#if defined(IDEE_DBG_SKIP) && (IDEE_DBG_SKIP != 0)
+#define IDEE_VARIANT_TAG " TIMING-VARIANT IDEE_DBG_SKIP=" IDEE_STR(IDEE_DBG_SKIP) " (results invalid)"
+#else
+#define IDEE_VARIANT_TAG ""
+#endif
+#if defined(IDEE_RD_DEPTH)
+#define IDEE_RD_TAG " IDEE_RD_DEPTH=" IDEE_STR(IDEE_RD_DEPTH)
+#else
+#define IDEE_RD_TAG ""
+#endif
+extern "C" const char* idee_version(void) { return "idee_hip 0.3.0 (gfx950)" IDEE_VARIANT_TAG IDEE_RD_TAG; }
 extern "C" const char* idee_last_error(void) { return idee::err_buf(); }
 
 extern "C" int idee_set_option(const char* name, const char* value) {

@@ -3571,11 +3571,11 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
         a.tiles = a.To * a.hgroups;
       }
       const bool wide_f22 = (MODE == DGRAD_S2) && conv_f22_math();    // f16 pieces with the per-chunk gradient scale
-      if ((wide_f22 || conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2) && 3 * slab_bytes <= 156 * 1024) {
+      // (the split kernel keeps a tap's source offsets inside one batch item as 32-bit element counts: a larger batch item runs
+      // on the exact kernel below, whose offsets are 64-bit)
+      const bool off32 = (long)(a.Ti - 1) * a.i_sT + (long)(a.Hi - 1) * a.i_sH + (long)(a.Wi - 1) * a.i_sW < (1L << 31) - (1L << 24);
+      if ((wide_f22 || conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) && off32 && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2) && 3 * slab_bytes <= 156 * 1024) {
         const long lds2 = 3 * slab_bytes;      // two piece slabs + one raw slab
-        // (the kernel keeps a tap's source offsets inside one batch item as 32-bit element counts)
-        if ((long)(a.Ti - 1) * a.i_sT + (long)(a.Hi - 1) * a.i_sH + (long)(a.Wi - 1) * a.i_sW >= (1L << 31) - (1L << 24))
-          return idee::fail(IDEE_ERR_UNSUPPORTED, "conv (wide, split): a batch item of %d x %d x %d pixels exceeds the 32-bit source offsets", a.Ti, a.Hi, a.Wi);
 #define LCS(NT_)                                                                                               \
   do {                                                                                                         \
     auto kern = wide_f22 ? conv_wide_split_kernel<MODE, NT_, MODE == DGRAD_S2 ? SC_GRAD : SC_ACT> \
@@ -3639,7 +3639,7 @@ extern "C" int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, v
   if (int rc = check_desc(d)) return rc;
   IDEE_CHECK_ARG(w && (packed_fwd_ || packed_dgrad_), "conv_pack_weights: null argument");
   if (d->act_dtype == IDEE_DTYPE_BF16 && d->Cout != 1) {      // (Cout == 1: the streaming kernels read the f32 fragments)
-    bf16_pack(d, w, packed_fwd_, packed_dgrad_, (hipStream_t)stream);
+    if (int rc = bf16_pack(d, w, packed_fwd_, packed_dgrad_, (hipStream_t)stream)) return rc;
     IDEE_LAUNCH_CHECK("conv_pack_weights");
     return IDEE_OK;
   }
@@ -3677,7 +3677,7 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const void* x_, const void
   }
   if (bf) {
     if (int rc = check_bf16(d)) return rc;
-    bf16_fwd(d, x_, w_packed_, bias, y_, (hipStream_t)stream);
+    if (int rc = bf16_fwd(d, x_, w_packed_, bias, y_, (hipStream_t)stream)) return rc;
     IDEE_LAUNCH_CHECK("conv_fwd");
     return IDEE_OK;
   }
@@ -3692,8 +3692,8 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const void* x_, const void
   a.o_sB = d->y_sB; a.o_sT = d->y_sT; a.o_sH = d->y_sH; a.o_sW = d->y_sW; a.o_sG = d->y_sG;
   a.i_sU = d->x_sU; a.i_gpu = d->x_gpu > 0 ? d->x_gpu : (1 << 30); a.o_sU = d->y_sU; a.o_gpu = d->y_gpu > 0 ? d->y_gpu : (1 << 30);
   split_tiles(a, a.Wo);
-  if (d->mode == IDEE_CONV_K333_REPLICATE) launch_conv<FWD_REP>(a, false, (hipStream_t)stream);
-  else launch_conv<FWD_S2>(a, false, (hipStream_t)stream);
+  if (d->mode == IDEE_CONV_K333_REPLICATE) { if (int rc = launch_conv<FWD_REP>(a, false, (hipStream_t)stream)) return rc; }
+  else if (int rc = launch_conv<FWD_S2>(a, false, (hipStream_t)stream)) return rc;
   IDEE_LAUNCH_CHECK("conv_fwd");
   return IDEE_OK;
 }
@@ -3721,7 +3721,7 @@ extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const void* dy_, con
   }
   if (bf) {
     if (int rc = check_bf16(d)) return rc;
-    bf16_dgrad(d, dy_, w_packed_dgrad_, relu_ref_, addend_, dx_, (hipStream_t)stream);
+    if (int rc = bf16_dgrad(d, dy_, w_packed_dgrad_, relu_ref_, addend_, dx_, (hipStream_t)stream)) return rc;
     IDEE_LAUNCH_CHECK("conv_dgrad");
     return IDEE_OK;
   }
@@ -3751,7 +3751,7 @@ extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const void* dy_, con
     if (int rc = launch_conv<DGRAD_REP>(a, false, (hipStream_t)stream)) return rc;
   } else {
     split_tiles(a, a.Wo);
-    launch_conv<DGRAD_S2>(a, cin1, (hipStream_t)stream);
+    if (int rc = launch_conv<DGRAD_S2>(a, cin1, (hipStream_t)stream)) return rc;
   }
   IDEE_LAUNCH_CHECK("conv_dgrad");
   return IDEE_OK;
@@ -3772,7 +3772,7 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
   }
   if (bf) {
     if (int rc = check_bf16(d)) return rc;
-    bf16_wgrad(d, x_, dy_, dw_packed, dbias, (hipStream_t)stream);
+    if (int rc = bf16_wgrad(d, x_, dy_, dw_packed, dbias, (hipStream_t)stream)) return rc;
     IDEE_LAUNCH_CHECK("conv_wgrad");
     return IDEE_OK;
   }

@@ -1,10 +1,12 @@
 """Batch-sharded data parallelism over RCCL/xGMI: one process per GPU, launched by torchrun,
 replacing the reference's nn.DataParallel wrapper (train_synthetic.py:133-137).
 
-Per step exactly three collectives, all tiny:
-  1. class counts of the BCE target           (2 floats, SUM)   -> global-batch class weights
-  2. anomaly-loss denominator                 (1 float,  SUM)   -> global-batch normalisation
-  3. the flat gradient buffer                 (2.14 MB,  SUM; the optimizer divides by world)
+Per step exactly TWO collectives:
+  1. the loss statistics, ONE vector of 4 floats (SUM): the BCE target's two class counts (-> global-batch class weights),
+     the valid-pixel count (-> BCE normalisation on real data) and the anomaly loss' weight sum (-> its normalisation).  All
+     four are functions of the step's MASKS only, so the all-reduce is issued asynchronously BEFORE the forward pass and
+     waited for when the losses are formed: it is never on the critical path between forward and backward (`LossStats`);
+  2. the flat gradient buffer                 (2.14 MB,  SUM; the optimizer divides by world)
 The 535,892 parameters are one flat bucket: on a fully connected 8-GPU xGMI mesh this is a
 latency-bound exchange, so it is issued once, un-bucketed, after backward.  Backend "nccl" is RCCL
 on ROCm; the same code runs on gloo/CPU tensors for the tests.  `loss_z_q` (LFQ aux loss) is the
@@ -76,6 +78,46 @@ def shard_batch(n_global, rank=None, world=None):
         raise ValueError(f"global batch {n_global} is not divisible by world size {world}")
     per = n_global // world
     return rank * per, (rank + 1) * per
+
+
+class LossStats:
+    """The step's loss statistics, all-reduced in ONE collective (see the module docstring).
+
+    local / total: (4,) f32 = [n_class0, n_class1, n_valid_pixels, anomaly_weight_sum]; with one rank `total is local`.
+    counts(): global class counts for the BCE weights (models/losses.py:80,115 on the gathered batch).
+    valid_scale() / anomaly_scale(): den_r * world / sum_r den_r — the factor that turns a rank's ratio-type loss num_r / den_r into
+    its share of the global-batch loss sum_r num_r / sum_r den_r under gradient AVERAGING (1.0 with one rank)."""
+
+    def __init__(self, local):
+        self.local = local
+        self.total = local
+        self.work = None
+        w = world_size()
+        if w > 1:
+            self.total = local.clone()
+            self.work = dist.all_reduce(self.total, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def counts(self):
+        self._wait()
+        return self.total[:2]
+
+    def _scale(self, i):
+        w = world_size()
+        if w == 1:
+            return None
+        self._wait()
+        return self.local[i] * w / self.total[i]
+
+    def valid_scale(self):
+        return self._scale(2)
+
+    def anomaly_scale(self):
+        return self._scale(3)
 
 
 def global_anomaly_scale(den_local):

@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+def pytest_sessionstart(session):
+    """No test session runs against a timing-variant build of the library (idee_version() names it; csrc/api.cpp)."""
+    from idee_amd import _lib
+    if os.path.exists(_lib.LIB_PATH):
+        v = _lib.load().idee_version().decode()
+        if "TIMING-VARIANT" in v:
+            raise pytest.UsageError(f"{_lib.LIB_PATH} is a timing-variant build ({v}): its results are invalid; rebuild without IDEE_EXTRA_FLAGS")
+
+
 def load_golden(name):
     """-> (arrays dict as torch tensors, state dict under 'sd/', grads under 'grad/')."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)

@@ -108,7 +108,19 @@ def main():
     grad = (ts.opt.flat_g * ts.opt.grad_scale).clone()
     ts.opt.step()
     p1 = ts.opt.flat_p.clone()
-    total2, _, _ = ts.step(x, *masks)
+    # step 2 through .step(), counting its collectives: exactly two with world > 1 (the 4-float loss statistics, issued before the
+    # forward pass, and the flat gradient bucket), none with one rank
+    import torch.distributed as dist
+    calls, real_all_reduce = [], dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append(int(t.numel()))
+        return real_all_reduce(t, *a, **k)
+    dist.all_reduce = counting_all_reduce
+    try:
+        total2, _, _ = ts.step(x, *masks)
+    finally:
+        dist.all_reduce = real_all_reduce
     # with world > 1 a rank reports its rescaled SHARE of every loss term: their mean over the ranks is the global-batch loss
     names = sorted(parts)
     vec = torch.stack([total.detach().reshape(()), total2.detach().reshape(())] + [parts[k].detach().reshape(()) for k in names]).double()
@@ -117,7 +129,7 @@ def main():
         vec /= world
     res = dict(world=world, p0=p0.cpu(), grad=grad.cpu(), p1=p1.cpu(), p2=ts.opt.flat_p.cpu(),
                parts={k: float(v) for k, v in zip(names, vec[2:])}, total1=float(vec[0]), total2=float(vec[1]),
-               weight_decay=float(cfg.weight_decay), lr=float(cfg.lr))
+               weight_decay=float(cfg.weight_decay), lr=float(cfg.lr), step_collectives=calls)
     if world > 1:
         # every rank must hold identical parameters after the steps
         mine = ts.opt.flat_p.clone()

@@ -22,6 +22,9 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.idee_version().decode().startswith("idee_hip")
+    # a library built with kernel timing-variant macros (IDEE_EXTRA_FLAGS=-DIDEE_DBG_SKIP=..: loads / MFMAs / stores skipped) says
+    # so in its version string and is refused here
+    assert "TIMING-VARIANT" not in lib.idee_version().decode(), lib.idee_version().decode()
     assert _lib.last_error() == ""
 
 

@@ -1,4 +1,4 @@
-"""world_size-2 gloo (CPU) tests of the data-parallel path: the three collectives of
+"""world_size-2 gloo (CPU) tests of the data-parallel path: the two collectives per step of
 idee_amd/parallel.py and the loss algebra that makes a 2-rank x N=2 step equal a 1-rank x N=4 step
 (checked with the CPU oracle standing in for the kernels: the collectives are device-agnostic)."""
 import os
@@ -43,6 +43,21 @@ def _worker_collectives(rank, world, port, q):
             P.shard_batch(7)
         den = torch.tensor(10.0 if rank == 0 else 30.0)
         assert torch.allclose(P.global_anomaly_scale(den), den * 2 / 40.0)
+        # the loss statistics of a step: ONE (asynchronous) all-reduce of [n0, n1, n_valid, anomaly weight sum]
+        calls, real = [], dist.all_reduce
+
+        def counting(t, *a, **k):
+            calls.append(int(t.numel()))
+            return real(t, *a, **k)
+        dist.all_reduce = counting
+        try:
+            st = P.LossStats(torch.tensor([3.0 + rank, 1.0, 4.0 + rank, 10.0 if rank == 0 else 30.0]))
+            assert torch.equal(st.counts(), torch.tensor([7.0, 2.0]))
+            assert torch.allclose(st.valid_scale(), torch.tensor((4.0 + rank) * 2 / 9.0))
+            assert torch.allclose(st.anomaly_scale(), den * 2 / 40.0)
+        finally:
+            dist.all_reduce = real
+        assert calls == [4], calls
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))
@@ -81,11 +96,21 @@ def _worker_step_equivalence(rank, world, port, q):
             return torch.cat([s[k].grad.reshape(-1) for k in names])
 
         lo, hi = P.shard_batch(4)
-        counts = P.all_reduce_sum_(torch.histc(me[lo:hi].unsqueeze(1), bins=2))
-        den_local = (1 - ml[lo:hi]).sum() * (2 * 16 * 8)
-        flat = grads(x[lo:hi], me[lo:hi], ml[lo:hi], counts, P.global_anomaly_scale(den_local))
+        calls, real = [], dist.all_reduce
+
+        def counting(t, *a, **k):
+            calls.append(int(t.numel()))
+            return real(t, *a, **k)
+        dist.all_reduce = counting
+        # the step's collectives as idee_amd/train.py issues them: the mask-only statistics in one vector (before the forward
+        # pass), then the gradient bucket
+        local_counts = torch.histc(me[lo:hi].unsqueeze(1), bins=2)
+        stats = P.LossStats(torch.cat([local_counts, local_counts.sum().reshape(1), (1 - ml[lo:hi]).sum().reshape(1)]))
+        flat = grads(x[lo:hi], me[lo:hi], ml[lo:hi], stats.counts(), stats.anomaly_scale())
         opt = _FakeOpt(flat)
         P.sync_gradients(opt)
+        dist.all_reduce = real
+        assert calls == [4, flat.numel()], calls      # exactly two collectives per step
         ddp = opt.flat_g * opt.grad_scale
         ref = grads(x, me, ml)                      # the same 4 clips in one process
         torch.testing.assert_close(ddp, ref, rtol=2e-4, atol=2e-6)

@@ -43,6 +43,9 @@ def test_two_ranks_product_step_equals_one_rank(kind, tmp_path):
     two = _run_world(kind, 2, str(tmp_path / "w2.pt"))
     one = _run_world(kind, 1, str(tmp_path / "w1.pt"))
     assert two["world"] == 2 and one["world"] == 1 and two["replicas_equal"]
+    # exactly two collectives per step — the 4-float loss statistics and the flat gradient bucket
+    assert len(two["step_collectives"]) == 2 and two["step_collectives"][0] == 4 and two["step_collectives"][1] > 1000, two["step_collectives"]
+    assert one["step_collectives"] == []
     assert torch.equal(two["p0"], one["p0"]), "rank 0's replica must have been broadcast"
     g2, g1 = two["grad"], one["grad"]
     tol = 2e-4 * float(g1.abs().max())
