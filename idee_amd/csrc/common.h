@@ -132,24 +132,30 @@ __device__ __forceinline__ Split split2(f32x4 x) {
   } else if (F16 == PM_F16X2) {
     p.h01 = cvt_pk_f16(x[0], x[1]);
     p.h23 = cvt_pk_f16(x[2], x[3]);
-    // residual x - float(hi), exact, one v_fma_mix_f32 per element (the f16 half is read in place: no conversion back)
-    float r0, r1, r2, r3;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p.h01), "v"(x[0]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p.h01), "v"(x[1]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(p.h23), "v"(x[2]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(p.h23), "v"(x[3]));
+    // residual x - float(hi), exact, one v_fma_mix_f32 per element (the f16 half is read in place: no conversion back; hipcc does
+    // not select this instruction by itself: fma((float)h, -1, x) compiles to v_cvt_f32_f16 + v_pk_add_f32, twice the count).
+    // The statement computes IN PLACE ("+v": the register that holds x[i] — or the compiler's own copy of it — is source and
+    // destination).  An `asm` statement is invisible to the compiler's MFMA hazard padding (tools/isa_hazards.py):
+    // a fresh "=v" destination can be a register that an MFMA still in flight is going to write (the dead vDst of a chain link
+    // with C != D), and the VALU result is then overwritten when the MFMA retires — the hardware needs 4 wait states there and
+    // nobody inserts them.  A destination that already holds a live, compiler-visible value cannot be the vDst of an MFMA in
+    // flight; if that value is itself an MFMA result, the v_cvt_pk above — which the compiler does pad — has read it first.
+    float r0 = x[0], r1 = x[1], r2 = x[2], r3 = x[3];
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(r0) : "v"(p.h01));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r1) : "v"(p.h01));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(r2) : "v"(p.h23));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r3) : "v"(p.h23));
     p.l01 = cvt_pk_f16(r0, r1);
     p.l23 = cvt_pk_f16(r2, r3);
   } else {
     p.h01 = cvt_pk_bf16(x[0], x[1]);
     p.h23 = cvt_pk_bf16(x[2], x[3]);
-    // residual x - float(hi), exact; as v_pk_add_f32 with a negated source (LLVM scalarises a v2f32 fsub, hence the asm)
+    // residual x - float(hi), exact; written as x + (-hi) on float2 so that hipcc emits v_pk_add_f32 with neg_lo / neg_hi itself
+    // (a float2 subtraction is scalarised; an `asm` statement would hide the instruction from the compiler's hazard padding)
     const f32x2 hf01 = {__uint_as_float(p.h01 << 16), __uint_as_float(p.h01 & 0xffff0000u)};
     const f32x2 hf23 = {__uint_as_float(p.h23 << 16), __uint_as_float(p.h23 & 0xffff0000u)};
     const f32x2 x01 = {x[0], x[1]}, x23 = {x[2], x[3]};
-    f32x2 r01, r23;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r01) : "v"(x01), "v"(hf01));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r23) : "v"(x23), "v"(hf23));
+    const f32x2 r01 = x01 + (-hf01), r23 = x23 + (-hf23);
     p.l01 = cvt_pk_bf16(r01[0], r01[1]);
     p.l23 = cvt_pk_bf16(r23[0], r23[1]);
   }
@@ -181,11 +187,11 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
 }
 __device__ __forceinline__ int imax_dev(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
-// am = max(am, |v0|, |v1|, |v2|, |v3|) in two v_max3_f32 with |.| as source modifiers (fmaxf() on loaded values costs a
-// canonicalising v_max(x, x) per operand in IEEE mode: 7 instructions per f32x4 instead of 2)
+// am = max(am, |v0|, |v1|, |v2|, |v3|): hipcc folds each line into one v_max3_f32 with |.| source modifiers (no `asm`: the compiler
+// must see every VALU instruction that may sit behind an MFMA)
 __device__ __forceinline__ float amax_acc(float am, f32x4 v) {
-  asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(v[0]), "v"(v[1]));
-  asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(v[2]), "v"(v[3]));
+  am = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), am);
+  am = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])), am);
   return am;
 }
 __device__ __forceinline__ float amax4(f32x4 v) {
