@@ -38,6 +38,7 @@ Opt g_opts[] = {
     {"IDEE_CONV_BF16", ""},       // direct | lds: bf16 path kernel choice
     {"IDEE_CONV_HRUN", ""},       // test knob: rows per work unit
     {"IDEE_WGRAD_WIDE_SEG", ""},  // tuning knob: 32 | 64
+    {"IDEE_WGRAD_WIDE", ""},      // regs: the register-staged exact wide weight gradient (default: LDS-DMA staged)
 };
 constexpr int kNumOpts = sizeof(g_opts) / sizeof(g_opts[0]);
 std::shared_mutex g_opt_mu;

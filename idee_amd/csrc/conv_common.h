@@ -39,6 +39,11 @@ struct ConvArgs {
   // row shift between the two lanes that hold them — they share a 16-column tile unless W % 16 == 15) instead of with atomics on
   // top of a pre-initialised edge: set by idee_conv_dgrad_add for the kernels that implement it (conv16_split_kernel)
   int no_edge_atomics;
+  // wide split kernels (conv_wide_split_kernel, f16 pieces): the weights as READY piece fragments, written once per step by
+  // idee_conv_pack_weights behind the f32 fragments of the same buffer — per weight set and tap the LDS image of the kernel's piece
+  // slab [group pair][output block][hi | lo][lane][4 words] — and the sets' power-of-two scale exponents; null: not packed
+  const unsigned* wpieces;
+  const int* wscale_k;
 };
 
 struct Slot { int src, tap; bool ok; };

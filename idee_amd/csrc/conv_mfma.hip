@@ -486,8 +486,19 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 // SC_ACT (forward): the ACTIVATION operands of a wave's chunk are range-guarded the same way (common.h ActGuard): split as they are
 // until an operand's largest |x| reaches 2^15, then scaled by 2^k, k < 0, the chunk's accumulators multiplied along.
 __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst);     // (LDS-DMA of 64 x 16 bytes: defined with conv16_glds_kernel)
+// exponent of the scale from the set's largest |w| (bit pattern): |w| 2^k in [2^13, 2^14)
+__device__ __forceinline__ int wscale_exp(unsigned bm) {
+  const int e = (int)(bm >> 23) - 127;
+  if (bm == 0u || e > 127) return 0;
+  return 13 - e < -60 ? -60 : (13 - e > 60 ? 60 : 13 - e);
+}
 enum { SC_NONE = 0, SC_GRAD = 1, SC_ACT = 2 };   // scale carried by the f16-piece operand that has no a-priori range
-template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT, int SC = SC_NONE>
+// PRE (f16 pieces only): the piece fragments of every tap and the weight set's scale come READY from the packed buffer
+// (ConvArgs::wpieces / wscale_k, written once per step by idee_conv_pack_weights): the next tap's piece slab is copied into the
+// other LDS buffer by LDS-DMA while this tap is multiplied — no weight scan in the prologue (166 k floats per workgroup and
+// launch), no conversion pass (48 vector instructions per thread and tap), ONE workgroup barrier per tap instead of two, two LDS
+// slabs instead of three.
+template <int MODE /*FWD_S2 or DGRAD_S2*/, int NT, int SC = SC_NONE, bool PRE = false>
 __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
   constexpr bool GSC = SC == SC_GRAD, ASC = SC == SC_ACT;
   static_assert(!GSC || MODE == DGRAD_S2, "gradient scale: data-gradient mode");
@@ -503,7 +514,11 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
   const int slab = a.Gk * NT * 256;                       // f32 floats per tap in the packed buffer == words per split slab
   const float* wp = a.wp + (long)wset * a.ntaps * slab;
   float wscale = 1.f, winv = 1.f;
-  if constexpr (F16) {
+  static_assert(!PRE || F16, "pre-split pieces: f16 pieces");
+  if constexpr (PRE) {
+    const int k = wscale_exp((unsigned)a.wscale_k[wset]);      // (the packed buffer holds the set's largest |w| as a bit pattern)
+    wscale = pow2i(k); winv = pow2i(-k);
+  } else if constexpr (F16) {
     __shared__ unsigned s_wmax[WAVES];
     float mx = 0.f;
     {   // eight loads in flight per trip (one load and its wait per trip: ~80 serialized memory round trips per workgroup)
@@ -583,7 +598,19 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       return (tt * 3 + oh) * 3 + ow;
     };
     __syncthreads();                                     // previous tile's readers done
-    for (int u = tid; u < npu; u += 512) { f32x4 fa, fb; load_unit(tap_of(0), u, fa, fb); store_unit(s_ws, u, fa, fb); }
+    // (PRE) piece slab of tap `tp` -> LDS buffer `dstw` by LDS-DMA: Gk * NT blocks of 1 KB, dealt to the 8 waves
+    auto dma_pieces = [&](int tp, unsigned* dstw) __attribute__((always_inline)) {
+      const float* psrc = reinterpret_cast<const float*>(a.wpieces) + ((long)wset * a.ntaps + tp) * slab + lane * 4;
+      const unsigned pdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dstw);
+      for (int blk_ = __builtin_amdgcn_readfirstlane(wave); blk_ < a.Gk * NT; blk_ += WAVES)
+        glds16(psrc + blk_ * 256, __builtin_amdgcn_readfirstlane(pdst + (unsigned)blk_ * 1024u));
+    };
+    if constexpr (PRE) {
+      dma_pieces(tap_of(0), s_ws);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      for (int u = tid; u < npu; u += 512) { f32x4 fa, fb; load_unit(tap_of(0), u, fa, fb); store_unit(s_ws, u, fa, fb); }
+    }
     __syncthreads();
 
     struct TapSrc { int off[MT]; bool okm[MT]; };     // (element offsets inside one batch item: 32 bits, checked by the host)
@@ -616,7 +643,8 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       // the 8 waves) and is converted to piece fragments from there at the end of the tap: as 2 x 3 fragments per thread in
       // registers through the whole tap it was 24 registers in a kernel that spills
       const bool more = it + 1 < ntap_it;
-      if (more) {
+      if (PRE && more) dma_pieces(tap_of(it + 1), wnext);      // (its readers finished at the barrier that ended tap it - 1)
+      if (!PRE && more) {
         const float* rsrc = wp + (long)tap_of(it + 1) * slab + lane * 4;
         const unsigned rdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(s_ws + 2 * slab));
         for (int blk_ = __builtin_amdgcn_readfirstlane(wave); blk_ < a.Gk * NT; blk_ += WAVES)
@@ -702,7 +730,8 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
         for (int m = 0; m < MT; ++m) { xa[m] = na[m]; xb[m] = nb_[m]; }
       }
       cur = nxt;
-      if (more) {
+      if (PRE && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA blocks have landed (the barrier below: all)
+      if (!PRE && more) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA blocks have landed
         __syncthreads();                                      // ... and every other wave's
         const float* raw = reinterpret_cast<const float*>(s_ws + 2 * slab);
@@ -2656,6 +2685,151 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_lds_kernel(WgradArgs a,
 }
 
 // ---------------------------------------------------------------------------------------------
+// wgrad_wide_dma_kernel: wgrad_wide_lds_kernel (exact f32 MFMA) with the NEXT row's operands staged by LDS-DMA while this row is
+// multiplied.  The register-staged kernel loads a row, writes it to LDS and waits at two workgroup barriers per output row with
+// its one workgroup per CU idle on the MFMA side meanwhile (MFMA-busy 0.60, SQ_WAIT_ANY 27 %, round 4); a register-staged
+// prefetch spilled (round 2).  Here: a ring of FOUR x rows and TWO dy rows, pixel-major WITHOUT padding (the DMA writes 64
+// consecutive 16-byte chunks), the row of iteration h + 1 in flight during iteration h, ONE barrier per row.  Bank conflicts of the
+// 4-byte operand reads (16 lanes = 16 consecutive channels, the 4 lane groups = 4 consecutive pixels; pixel stride 16 G floats)
+// are avoided on the SOURCE side: with an even group count G the 16-channel group g of pixel p sits at position g ^ ((p >> 1) & 1)
+// — the four pixels of a read then cover four different 16-bank groups (32 (p & 1) + 16 ((p >> 1) & 1) mod 64); with G = 3 the
+// stride 48 does that by itself.  Out-of-frame pixels read a 16-byte zero constant.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const float kZeroQuad[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int GA, int GB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wgrad_wide_dma_kernel(WgradArgs a, int seg, int nseg, int hrun, int nhrun) {
+  constexpr int CI = 16 * GA, CO = 16 * GB;
+  constexpr bool ROTX = GA % 2 == 0, ROTY = GB % 2 == 0;
+  constexpr int NFRAG = 9 * GA;
+  constexpr int FPW = (NFRAG + WAVES - 1) / WAVES;
+  extern __shared__ __attribute__((aligned(1024))) float s_dyn[];
+  const int rowlen = seg + 2, segp = (seg + 3) & ~3;
+  const int xrow = rowlen * CI, yrow = segp * CO;         // floats per staged row
+  float* s_x = s_dyn;                                     // [4][rowlen][CI]
+  float* s_dy = s_dyn + 4 * xrow;                         // [2][segp][CO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int wset = blockIdx.y;
+
+  f32x4 acc[FPW][GB];
+  float bsum[GB];
+#pragma unroll
+  for (int f = 0; f < FPW; ++f)
+#pragma unroll
+    for (int n = 0; n < GB; ++n) acc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < GB; ++n) bsum[n] = 0.f;
+
+  const int kt = blockIdx.z % a.kt;
+  const int nys = a.CoutPad / CO;
+  const int xg0 = ((blockIdx.z / a.kt) / nys) * GA, yg0 = ((blockIdx.z / a.kt) % nys) * GB;
+  const int nb = a.B / a.wsets;
+  const long nchunks = (long)nb * a.To * nhrun * nseg;
+  const unsigned lds_x = (unsigned)(size_t)s_x, lds_y = (unsigned)(size_t)s_dy;
+  const int nqx = rowlen * (CI / 4), nqy = segp * (CO / 4);     // 16-byte chunks per staged row
+
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    long r = ch;
+    const int sg = (int)(r % nseg); r /= nseg;
+    const int hr = (int)(r % nhrun); r /= nhrun;
+    const int t = (int)(r % a.To);
+    const int b = (int)(r / a.To) * a.wsets + wset;
+    const int w0 = sg * seg;
+    const int h0 = hr * hrun, h1 = min(a.H, h0 + hrun);
+    const float* x_bt = a.x + (long)b * a.x_sB + (long)(a.kt * t + kt) * a.x_sT;
+    const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
+
+    // source row hs of x -> ring slot hs & 3 (rows outside the frame are never staged: their taps are skipped)
+    auto dma_x = [&](int hs) __attribute__((always_inline)) {
+      if (hs < 0 || hs >= a.H) return;
+      const float* src = x_bt + (long)hs * a.x_sH;
+      const unsigned dst = lds_x + (unsigned)((hs & 3) * xrow) * 4u;
+      for (int q0 = wave * 64; q0 < nqx; q0 += WAVES * 64) {
+        const int q = q0 + lane;
+        const int px = q / (CI / 4), rem = q - px * (CI / 4);
+        const int g = (rem >> 2) ^ (ROTX ? ((px >> 1) & 1) : 0);
+        const int w = w0 + px - 1;
+        const float* sp = (w >= 0 && w < a.W) ? src + (long)w * a.x_sW + goff(xg0 + g, a.x_gpu, a.x_sU, a.x_sG) + 4 * (rem & 3) : kZeroQuad;
+        if (q < nqx) glds16(sp, __builtin_amdgcn_readfirstlane(dst + (unsigned)q0 * 16u));
+      }
+    };
+    auto dma_dy = [&](int h) __attribute__((always_inline)) {
+      const float* src = dy_b + (long)h * a.y_sH;
+      const unsigned dst = lds_y + (unsigned)((h & 1) * yrow) * 4u;
+      for (int q0 = wave * 64; q0 < nqy; q0 += WAVES * 64) {
+        const int q = q0 + lane;
+        const int px = q / (CO / 4), rem = q - px * (CO / 4);
+        const int g = (rem >> 2) ^ (ROTY ? ((px >> 1) & 1) : 0);
+        const int w = w0 + px;
+        const float* sp = (px < seg && w < a.W) ? src + (long)w * a.y_sW + goff(yg0 + g, a.y_gpu, a.y_sU, a.y_sG) + 4 * (rem & 3) : kZeroQuad;
+        if (q < nqy) glds16(sp, __builtin_amdgcn_readfirstlane(dst + (unsigned)q0 * 16u));
+      }
+    };
+    __syncthreads();                                      // the previous chunk's readers are done
+    dma_x(h0 - 1); dma_x(h0); dma_x(h0 + 1); dma_dy(h0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int h = h0; h < h1; ++h) {
+      if (h + 1 < h1) { dma_x(h + 2); dma_dy(h + 1); }    // (slots (h + 2) & 3 and (h + 1) & 1: last read in iteration h - 1)
+      int base[FPW];
+      bool okf[FPW];
+#pragma unroll
+      for (int f = 0; f < FPW; ++f) {
+        const int fr = wave + f * WAVES;            // fragment id = tap9 * GA + ga
+        const int tap9 = fr / GA, ga = fr % GA;
+        const int oh = (tap9 / 3) % 3, ow = tap9 % 3;
+        const int hs = h + oh - 1;
+        okf[f] = fr < NFRAG && hs >= 0 && hs < a.H;
+        const int px = ow + kq;                     // (+ 4 s: does not change bit 1 of the pixel index... see rot below)
+        base[f] = ((hs & 3) * rowlen + px) * CI + 16 * (ga ^ (ROTX ? ((px >> 1) & 1) : 0)) + r16;
+      }
+      const float* yb = s_dy + (h & 1) * yrow + kq * CO + r16;
+      const int yrot = ROTY ? ((kq >> 1) & 1) : 0;
+      const int steps = segp >> 2;
+#pragma unroll 2
+      for (int s = 0; s < steps; ++s) {
+        float bf[GB];
+#pragma unroll
+        for (int n = 0; n < GB; ++n) { bf[n] = yb[s * 4 * CO + 16 * (n ^ yrot)]; bsum[n] += bf[n]; }
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+          if (!okf[f]) continue;
+          const float af = s_x[base[f] + s * 4 * CI];
+#pragma unroll
+          for (int n = 0; n < GB; ++n) acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[f][n], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA blocks of the next row have landed
+      __syncthreads();                                    // ... every wave's; and this row's readers are done
+    }
+  }
+  float* dw = a.dwp + (long)wset * a.ntaps * a.Cin * a.CoutPad;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int f = 0; f < FPW; ++f) {
+    const int fr = wave + f * WAVES;
+    if (fr >= NFRAG) continue;
+    const int tap = kt * 9 + fr / GA, ga = fr % GA;
+#pragma unroll
+    for (int n = 0; n < GB; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(dw + ((long)tap * a.Cin + 16 * (xg0 + ga) + r0 + r) * a.CoutPad + 16 * (yg0 + n) + col, acc[f][n][r]);
+  }
+  if (a.dbias && wave == 0 && kt == 0 && xg0 == 0) {
+#pragma unroll
+    for (int n = 0; n < GB; ++n) {
+      float v = bsum[n];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) atomicAdd(a.dbias + (long)wset * a.CoutPad + 16 * (yg0 + n) + lane, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // wgrad_wide_lds_kernel on f16 pieces at f32 level (IDEE_CONV_MATH=f22): the same work decomposition (a workgroup owns one
 // (batch item, t_out, kt) and a run of rows of one 64-pixel segment; the 9 GA (tap, input block) fragments dealt round-robin to
 // the 8 waves, every wave forming all GB output blocks for its fragments), K = 32 PIXELS per v_mfma_f32_16x16x32_f16 and three
@@ -2980,6 +3154,53 @@ __global__ void init_w_edges_kernel(float* __restrict__ dx, const float* __restr
 // ---------------------------------------------------------------------------------------------
 // weight packing (reference layout (wsets, Cout, Cin, kt, kh, kw) -> MFMA fragment order)
 // ---------------------------------------------------------------------------------------------
+// f16 piece fragments for conv_wide_split_kernel (PRE): one power-of-two scale per weight set (largest |w| 2^k in [2^13, 2^14), as the
+// kernel's own prologue scan chose it) ...
+__global__ __launch_bounds__(256) void pack_wscale_kernel(const float* __restrict__ pf, unsigned* __restrict__ mout, long per_set,
+                                                          int parts) {
+  // grid = (parts, wsets): every workgroup scans 1 / parts of a set, eight loads in flight per trip, and adds its maximum (the
+  // bit pattern of a non-negative float orders like an unsigned) to the set's slot, zeroed by the caller
+  __shared__ unsigned s_m[4];
+  const float* w = pf + (long)blockIdx.y * per_set;
+  const long n4 = per_set / 4, lo = n4 * blockIdx.x / parts, hi = n4 * (blockIdx.x + 1) / parts;
+  float mx = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 8 * 256) {
+    f32x4 f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const long iu = i + (long)u * 256; f[u] = ld4(w + 4 * (iu < hi ? iu : i)); }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mx = amax_acc(mx, f[u]);
+  }
+  const unsigned m = wave_umax(__float_as_uint(mx));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned bm = 0u;
+    for (int i = 0; i < 4; ++i) bm = bm > s_m[i] ? bm : s_m[i];
+    atomicMax(mout + blockIdx.y, bm);
+  }
+}
+// ... and the piece image of every (weight set, tap): [group pair gp][output block n][hi | lo][lane][4 words], the two pieces of
+// the fragments of K groups 2 gp and 2 gp + 1 side by side — exactly what the kernel's conversion pass wrote to LDS per tap
+__global__ __launch_bounds__(256) void pack_pieces_kernel(const float* __restrict__ pf, const unsigned* __restrict__ mx_bits,
+                                                          unsigned* __restrict__ pieces, int wsets, int ntaps, int Gk, int NT) {
+  const int GP = Gk / 2;
+  const long units = (long)wsets * ntaps * GP * NT * 64;
+  const long slab = (long)Gk * NT * 256;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
+    const int l = (int)(u & 63);
+    long r = u >> 6;
+    const int n = (int)(r % NT); r /= NT;
+    const int gp = (int)(r % GP); r /= GP;                 // r = wset * ntaps + tap
+    const int ws = (int)(r / ntaps);
+    const float sc = pow2i(wscale_exp(mx_bits[ws]));
+    const float* src = pf + r * slab + ((2 * gp) * NT + n) * 256 + l * 4;
+    const Split sa = split2<PM_F16X2>(ld4(src) * sc), sb = split2<PM_F16X2>(ld4(src + NT * 256) * sc);
+    unsigned* dst = pieces + r * slab + (((long)(gp * NT + n) * 2) * 64 + l) * 4;
+    *reinterpret_cast<u32x4*>(dst) = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
+    *reinterpret_cast<u32x4*>(dst + 256) = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
+  }
+}
 __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int wsets,
                             int Cout, int Cin, int ntaps) {
   const int Gi = Cin / 16, Go = (Cout + 15) / 16;
@@ -3382,6 +3603,20 @@ inline int out_T(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K233_S2_
 inline int n_taps(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K333_REPLICATE ? 27 : d->mode == IDEE_CONV_K233_S2_ZERO ? 18 : 9; }
 inline int mode_kt(const idee_conv_desc* d) { return d->mode == IDEE_CONV_K133_ZERO ? 1 : 2; }
 inline int pick_nt(int G) { return G % 6 == 0 ? 6 : G % 3 == 0 ? 3 : G % 2 == 0 ? 2 : 1; }
+// (Gk K groups, Gn output groups) that conv_wide_split_kernel takes (launch_conv): all output blocks in one workgroup, K in
+// pairs, both piece slabs + the raw slab within the LDS
+inline bool wide_split_shape(int Gk, int Gn) {
+  const int NT = pick_nt(Gn);
+  const long slab_bytes = (long)Gk * NT * 256 * 4;
+  return Gn / NT == 1 && (NT == 6 || NT == 3 || NT == 2) && Gk % 2 == 0 && Gk * NT <= 36 && 3 * slab_bytes <= 156 * 1024 &&
+         Gk * NT * 64 <= 5 * 512;
+}
+// the packed weight buffers of a convolution carry ready f16 piece fragments (+ 64 ints: the sets' scale exponents) behind the
+// f32 fragments when either direction can run on conv_wide_split_kernel
+inline bool packs_pieces(const idee_conv_desc* d) {
+  if (d->act_dtype != IDEE_DTYPE_F32 || d->mode == IDEE_CONV_K333_REPLICATE || d->Cin % 16 || d->Cout % 16 || d->wsets > 64) return false;
+  return wide_split_shape(d->Cin / 16, d->Cout / 16) || wide_split_shape(d->Cout / 16, d->Cin / 16);
+}
 
 // resident workgroups per CU of a kernel (occupancy API; advisory, only steers the grid size)
 template <class K>
@@ -3574,11 +3809,16 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
       // (the split kernel keeps a tap's source offsets inside one batch item as 32-bit element counts: a larger batch item runs
       // on the exact kernel below, whose offsets are 64-bit)
       const bool off32 = (long)(a.Ti - 1) * a.i_sT + (long)(a.Hi - 1) * a.i_sH + (long)(a.Wi - 1) * a.i_sW < (1L << 31) - (1L << 24);
-      if ((wide_f22 || conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) && off32 && a.Gk % 2 == 0 && a.Gk * NT <= 36 && (NT == 6 || NT == 3 || NT == 2) && 3 * slab_bytes <= 156 * 1024) {
-        const long lds2 = 3 * slab_bytes;      // two piece slabs + one raw slab
+      if ((wide_f22 || conv_split_math(MODE == FWD_REP || MODE == FWD_S2)) && off32 && wide_split_shape(a.Gk, a.GnTot)) {
+        // f16 pieces (forward; data gradient under f22) with the piece fragments of the packed buffer: two piece slabs; bf16 pieces
+        // (data gradient under `split`) and buffers packed without pieces: two piece slabs + one raw slab
+        const bool f16p = MODE == FWD_S2 || wide_f22;
+        const bool pre = f16p && a.wpieces != nullptr;
+        const long lds2 = pre ? 2 * slab_bytes : 3 * slab_bytes;
 #define LCS(NT_)                                                                                               \
   do {                                                                                                         \
-    auto kern = wide_f22 ? conv_wide_split_kernel<MODE, NT_, MODE == DGRAD_S2 ? SC_GRAD : SC_ACT> \
+    auto kern = pre ? conv_wide_split_kernel<MODE, NT_, MODE == DGRAD_S2 ? SC_GRAD : SC_ACT, true> \
+                : wide_f22 ? conv_wide_split_kernel<MODE, NT_, MODE == DGRAD_S2 ? SC_GRAD : SC_ACT> \
                          : conv_wide_split_kernel<MODE, NT_, MODE == FWD_S2 ? SC_ACT : SC_NONE>; \
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) \
       return idee::fail(IDEE_ERR_LAUNCH, "conv: cannot reserve %ld bytes of LDS", lds2);                         \
@@ -3625,9 +3865,11 @@ int launch_conv(ConvArgs& a, bool cin1, hipStream_t stream) {
 
 }  // namespace
 
+static long frag_floats(const idee_conv_desc* d) { return (long)d->wsets * n_taps(d) * (d->Cin / 16) * ((d->Cout + 15) / 16) * 256; }
 extern "C" long idee_conv_packed_floats(const idee_conv_desc* d) {
   if (!d || d->Cin % 16) return -1;
-  return (long)d->wsets * n_taps(d) * (d->Cin / 16) * ((d->Cout + 15) / 16) * 256;
+  const long n = frag_floats(d);
+  return packs_pieces(d) ? 2 * n + 64 : n;      // [f32 fragments][f16 piece fragments][scale exponents]
 }
 extern "C" long idee_conv_wgrad_floats(const idee_conv_desc* d) {
   if (!d) return -1;
@@ -3645,9 +3887,28 @@ extern "C" int idee_conv_pack_weights(const idee_conv_desc* d, const float* w, v
   }
   float* packed_fwd = (float*)packed_fwd_;
   float* packed_dgrad = (float*)packed_dgrad_;
-  const long total = idee_conv_packed_floats(d);
+  const long total = frag_floats(d);
   hipLaunchKernelGGL(pack_kernel, dim3(imin(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, w, packed_fwd,
                      packed_dgrad, d->wsets, d->Cout, d->Cin, n_taps(d));
+  if (packs_pieces(d)) {      // ready f16 piece fragments for the wide split kernels (whatever the arithmetic option says NOW: the
+                              // library looks its options up at launch time)
+    const int Gi = d->Cin / 16, Go = d->Cout / 16;
+    float* bufs[2] = {packed_fwd, packed_dgrad};
+    const int gk[2] = {Gi, Go}, gn[2] = {Go, Gi};
+    for (int i = 0; i < 2; ++i) {
+      if (!bufs[i] || !wide_split_shape(gk[i], gn[i])) continue;
+      unsigned* mbuf = reinterpret_cast<unsigned*>(bufs[i] + 2 * total);
+      unsigned* pieces = reinterpret_cast<unsigned*>(bufs[i] + total);
+      if (hipMemsetAsync(mbuf, 0, 64 * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
+        return idee::fail(IDEE_ERR_LAUNCH, "conv_pack_weights: hipMemsetAsync failed");
+      const long per_set = total / d->wsets;
+      const int parts = (int)imin(imax(per_set / 8192, 1), 32);
+      hipLaunchKernelGGL(pack_wscale_kernel, dim3(parts, d->wsets), dim3(256), 0, (hipStream_t)stream, bufs[i], mbuf, per_set, parts);
+      const long units = total / 8;
+      hipLaunchKernelGGL(pack_pieces_kernel, dim3(imin(cdiv(units, 256), 1024)), dim3(256), 0, (hipStream_t)stream, bufs[i], mbuf,
+                         pieces, d->wsets, n_taps(d), gk[i], pick_nt(gn[i]));
+    }
+  }
   IDEE_LAUNCH_CHECK("conv_pack_weights");
   return IDEE_OK;
 }
@@ -3684,6 +3945,10 @@ extern "C" int idee_conv_fwd(const idee_conv_desc* d, const void* x_, const void
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = x; a.wp = w_packed; a.bias = bias; a.relu_ref = nullptr; a.out = y;
+  if (packs_pieces(d) && wide_split_shape(d->Cin / 16, d->Cout / 16)) {
+    a.wpieces = reinterpret_cast<const unsigned*>(w_packed + frag_floats(d));
+    a.wscale_k = reinterpret_cast<const int*>(w_packed + 2 * frag_floats(d));
+  }
   a.B = d->B; a.wsets = d->wsets;
   a.Ti = d->T; a.Hi = d->H; a.Wi = d->W;
   a.To = out_T(d); a.Ho = d->H; a.Wo = d->W;
@@ -3728,6 +3993,10 @@ extern "C" int idee_conv_dgrad_add(const idee_conv_desc* d, const void* dy_, con
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = dy; a.wp = w_packed_dgrad; a.bias = nullptr; a.relu_ref = relu_ref; a.out = dx; a.addend = addend;
+  if (packs_pieces(d) && wide_split_shape(d->Cout / 16, d->Cin / 16)) {
+    a.wpieces = reinterpret_cast<const unsigned*>(w_packed_dgrad + frag_floats(d));
+    a.wscale_k = reinterpret_cast<const int*>(w_packed_dgrad + 2 * frag_floats(d));
+  }
   a.B = d->B; a.wsets = d->wsets;
   a.Ti = out_T(d); a.Hi = d->H; a.Wi = d->W;
   a.To = d->T; a.Ho = d->H; a.Wo = d->W;
@@ -3907,6 +4176,29 @@ extern "C" int idee_conv_wgrad(const idee_conv_desc* d, const void* x_, const vo
     } else
     // 16 input channels (the sign field): one tap per wave, 9 waves
     if (Ga == 1) { if (Gb == 6) LWW(1, 6, 9); else if (Gb == 3) LWW(1, 3, 9); else LWW(1, 2, 9); }
+    else if (!env_is("IDEE_WGRAD_WIDE", "regs")) {
+      // exact f32, LDS-DMA staged one row ahead (wgrad_wide_dma_kernel): 4 x rows + 2 dy rows, unpadded
+      const int ci = 16 * ga_k, co = 16 * gb_k;
+      int segm = (int)((150L * 1024 / 4 - 8L * ci) / (4L * ci + 2L * co)) & ~3;
+      if (segm > 256) segm = 256;
+      const int nsegd = cdiv(d->W, segm);
+      const int segd = ((cdiv(d->W, nsegd) + 3) / 4) * 4;
+      int hrund = d->H;
+      while (hrund > 8 && btk * cdiv(d->H, hrund) * nsegd * d->wsets * nsubz < 3L * kCUs) hrund = (hrund + 1) / 2;
+      const int nhrund = cdiv(d->H, hrund);
+      const long nchunksd = (long)(d->B / d->wsets) * a.To * nhrund * nsegd;
+      const size_t ldsd = (size_t)(4L * (segd + 2) * ci + 2L * segd * co) * 4;
+      const dim3 gridd(one_round(nchunksd, (long)a.kt * d->wsets * nsubz, 1), d->wsets, a.kt * nsubz);
+#define LWD(GA_, GB_)                                                                                                 \
+  do {                                                                                                                \
+    auto kern = wgrad_wide_dma_kernel<GA_, GB_, 8>;                                                                   \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd) != hipSuccess)  \
+      return idee::fail(IDEE_ERR_LAUNCH, "conv_wgrad: cannot reserve %zu bytes of LDS", ldsd);                         \
+    hipLaunchKernelGGL(kern, gridd, dim3(512), ldsd, st, a, segd, nsegd, hrund, nhrund);                              \
+  } while (0)
+      if (ga_k == 6) LWD(6, 6); else if (Ga == 3) LWD(3, 3); else LWD(2, 2);
+#undef LWD
+    }
     else if (ga_k == 6) LWW(6, 6, 8); else if (Ga == 3) LWW(3, 3, 8); else LWW(2, 2, 8);
 #undef LWW
   }

@@ -99,7 +99,9 @@ class CNN_3D(_stacked.StackedModule):
             elif has_ds:      # a width change between blocks: the same bias-free 1x1x1 conv + non-affine LN on tokens (:112-118)
                 t = ops.StageEmbedLN.apply(t, getattr(self, f"l{l}_ds_w"), None)
             elif l == 0:
-                raise NotImplementedError("idee_amd CNN_3D: in_channels == out_channels[0] (no patch embedding) is not built")
+                # in_channels == out_channels[0]: the reference's first conv_block has no `downsample` (encoder/CNN_3D.py:112-118);
+                # the input in the kernels' channels-last token layout (data movement only)
+                t = x.permute(0, 1, 3, 4, 5, 2).contiguous()
             for u in (1, 2):
                 ps = None
                 if self.training and self.drop_path_rate > 0:

@@ -196,7 +196,10 @@ class Swin_3D(_stacked.StackedModule):
                     # (an f32 kernel: under bf16 activation storage the tokens are widened for this one stage boundary)
                     t = ops.StageEmbedLN.apply(t.float(), getattr(self, f"s{s}_ds_w"), getattr(self, f"s{s}_ds_b")).to(self.act_dtype)
             elif s == 0:
-                raise NotImplementedError("idee_amd Swin_3D: in_chans == embed_dim[0] (no patch embedding) is not built")
+                # in_chans == embed_dim[0] with patch (1,1,1): the reference builds stage 0 without a `downsample` (Swin_3D.py:417-420)
+                # and its blocks read the input channels directly; here: the input in the kernels' channels-last token layout
+                # (data movement only)
+                t = x.permute(0, 1, 3, 4, 5, 2).contiguous().to(self.act_dtype)
             wsz = self.window_size[s]
             shift = tuple(i // 2 for i in wsz)
             index = getattr(self, f"s{s}_index")

@@ -57,6 +57,7 @@ KERNEL_VARIANTS = {
     "wgrad16_regs": {"IDEE_WGRAD16_REGS": "1"},                      # register-staged 3^3 weight gradient
     "conv32_generic": {"IDEE_CONV32": "generic"},                    # 32->32 on the generic kernel
     "dgrad_to16_wide": {"IDEE_DGRAD_TO16": "wide"},                  # (1,3,3) data gradient on conv_wide_kernel
+    "wgrad_wide_regs": {"IDEE_WGRAD_WIDE": "regs"},                  # exact wide weight gradient, register-staged (default: LDS-DMA)
     "conv_bf16_direct": {"IDEE_CONV_BF16": "direct"},                # bf16 path: narrow-input convs without LDS staging
     "conv_bf16_lds": {"IDEE_CONV_BF16": "lds"},                      # bf16 path: 32->32 on the LDS kernel, weights from L1
 }
@@ -69,7 +70,7 @@ def variants(*names):
 
 
 VARIANT_OPTIONS = ("IDEE_SWIN_MATH", "IDEE_CONV_MATH", "IDEE_CONV16", "IDEE_WGRAD16_REGS", "IDEE_CONV32", "IDEE_DGRAD_TO16",
-                   "IDEE_CONV_BF16")
+                   "IDEE_CONV_BF16", "IDEE_WGRAD_WIDE")
 
 
 @pytest.fixture

@@ -182,6 +182,46 @@ def fx_swin_patch(tag, patch, in_chans, shape, seed):
     save("swin_patch_" + tag, **out)
 
 
+def fx_swin_nopatch(seed):
+    """Swin_3D with in_chans == embed_dim[0] and patch (1,1,1): BasicLayer builds stage 0 WITHOUT a downsample (Swin_3D.py:417-420),
+    the blocks read the input channels directly; whole encoder, forward + every gradient (incl. the input's)."""
+    enc = ref_swin.Swin_3D(in_vars=2, in_chans=16, depths=[2, 1], num_heads=[2, 2])
+    assert enc.layers_var[0][0].downsample is None
+    rerandomise(enc, seed)
+    x = rand((1, 2, 16, 8, 8, 12), seed + 1).requires_grad_()
+    with relu_record() as rec:
+        y = enc(x)
+    assert rec.ties() == 0, f"swin_nopatch: seed {seed} has a ReLU tie; pick another seed"
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x.detach(), y=y.detach(), r=r, dx=x.grad)
+    out.update(sd_arrays(enc))
+    out.update({"grad/" + k: p.grad for k, p in enc.named_parameters()})
+    save("swin_nopatch_c16", **out)
+
+
+def fx_cnn_nopatch(seed):
+    """CNN_3D encoder with in_channels == out_channels[0]: the first conv_block has no downsample (encoder/CNN_3D.py:112-118)."""
+    enc = ref_cnn.CNN_3D(in_vars=2, in_channels=16, out_channels=[16, 16])
+    assert enc.layers_var[0][0].downsample is None
+    rerandomise(enc, seed)
+    x = rand((1, 2, 16, 4, 6, 10), seed + 1).requires_grad_()
+    with relu_record() as rec:
+        y = enc(x)
+    assert rec.ties() == 0, f"cnn_nopatch: seed {seed} has a ReLU tie; pick another seed"
+    r = rand(y.shape, seed + 2)
+    (y * r).sum().backward()
+    out = dict(x=x.detach(), y=y.detach(), r=r, dx=x.grad)
+    out.update(sd_arrays(enc))
+    out.update({"grad/" + k: p.grad for k, p in enc.named_parameters()})
+    save("cnn_nopatch_c16", **out)
+
+
+if __name__ == "__main__" and "--nopatch-only" in sys.argv:
+    fx_swin_nopatch(1800)
+    fx_cnn_nopatch(1810)
+
+
 if __name__ == "__main__" and "--patch-only" in sys.argv:
     fx_swin_patch("122", (1, 2, 2), 1, (8, 9, 14), 1600)
     fx_swin_patch("222_c2", (2, 2, 2), 2, (16, 8, 10), 1610)
@@ -754,7 +794,7 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
                                                                 "--era5-only", "--hier-only", "--vqema-only", "--misc-only", "--era5items-only",
-                                                                "--cnnhier-only", "--patch-only", "--clsk-only")):
+                                                                "--cnnhier-only", "--patch-only", "--clsk-only", "--nopatch-only")):
     main()
     fx_classifier(1700, V=2, n_classes=3)
     fx_swin_hier("16_32", (16, 32), 1200)
@@ -763,6 +803,8 @@ if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "
     fx_cnn_hier("32_16", (32, 16), 1510)
     fx_swin_patch("122", (1, 2, 2), 1, (8, 9, 14), 1600)
     fx_swin_patch("222_c2", (2, 2, 2), 2, (16, 8, 10), 1610)
+    fx_swin_nopatch(1800)
+    fx_cnn_nopatch(1810)
     fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
     fx_patch_mergings()
     fx_dataset_items()

@@ -556,7 +556,7 @@ def _classifier(sd, V):
 
 
 @pytest.mark.parametrize("tag", ["classifier_v2", "classifier_v2_k3"])       # _k3: n_classes = 3 (joint head only, as the reference)
-@variants('default', 'conv_split', 'conv_f22')
+@variants('default', 'conv_split', 'conv_f22', 'wgrad_wide_regs')
 def test_classifier_golden(tag, kernel_variant):
     a, sd, grads = load_golden(tag)
     c = _classifier(sd, 2)
@@ -577,7 +577,7 @@ def test_classifier_golden(tag, kernel_variant):
 
 @pytest.mark.parametrize("V,H,W,E", [(3, 7, 72, 16), (6, 5, 40, 16), (1, 3, 3, 16), (5, 4, 20, 16), (6, 6, 200, 16), (2, 3, 200, 16),
                                      (6, 4, 24, 32), (3, 3, 20, 32), (2, 19, 40, 16), (3, 5, 24, 16), (2, 3, 31, 16), (2, 2, 30, 16)])
-@variants('default', 'conv_split', 'conv_f22')
+@variants('default', 'conv_split', 'conv_f22', 'wgrad_wide_regs')
 def test_classifier_vs_oracle(V, H, W, E, set_opt, kernel_variant):
     """Plain path (convolutions on z_q).  W = 200: the frame-wide row-wrapping column-block numbering of conv_wide,
     its zero borders, the wide weight-gradient kernel and the heads' strip kernels at both frame edges.  E = 32 (config #4's
@@ -1135,6 +1135,40 @@ def test_swin_hierarchical_encoder_golden(tag, kernel_variant):
         g = ps[base].grad
         g = g.view(*g.shape, 1, 1, 1) if name.endswith("_ds_w5") else g
         gclose("d" + key, g if idx is None else g[idx], grads[key], rtol=2e-3, floor=2e-4)
+        checked += 1
+    assert checked == len(grads)
+
+
+@pytest.mark.parametrize("enc_name", ["Swin_3D", "CNN_3D"])
+def test_encoder_without_patch_embedding_golden(enc_name):
+    """in_chans == embed_dim[0] with patch (1,1,1): the reference builds stage 0 (Swin_3D.py:417-420) / the first conv_block
+    (encoder/CNN_3D.py:112-118) without a `downsample`; state-dict keys as the reference's, outputs, every parameter gradient and
+    the INPUT gradient against the reference's own."""
+    if enc_name == "Swin_3D":
+        from idee_amd.models.encoder.Swin_3D import Swin_3D
+        a, sd, grads = load_golden("swin_nopatch_c16")
+        enc = Swin_3D(in_vars=2, in_chans=16, depths=[2, 1], num_heads=[2, 2])
+    else:
+        from idee_amd.models.encoder.CNN_3D import CNN_3D
+        a, sd, grads = load_golden("cnn_nopatch_c16")
+        enc = CNN_3D(in_vars=2, in_channels=16, out_channels=[16, 16])
+    msd = enc.state_dict()
+    assert list(msd) == list(sd) and all(tuple(msd[k].shape) == tuple(sd[k].shape) for k in sd)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(DEV).train()
+    x = dev(a["x"]).requires_grad_()
+    y = enc(x)
+    close("y", y, a["y"])
+    (y * dev(a["r"])).sum().backward()
+    gclose("dx", x.grad, a["dx"], rtol=2e-3, floor=2e-4)
+    ps = dict(enc.named_parameters())
+    checked = 0
+    for key, name, idx in enc._key_map():
+        if name.endswith("_index") or key not in grads:
+            continue
+        g = ps[name].grad
+        g = g if idx is None else g[idx]
+        gclose("d" + key, g.reshape(grads[key].shape), grads[key], rtol=2e-3, floor=2e-4)
         checked += 1
     assert checked == len(grads)
 

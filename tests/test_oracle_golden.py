@@ -253,6 +253,22 @@ def test_swin_hierarchical_encoder(tag):
     check_grads(sdl, {"encoder." + k: v for k, v in grads.items()}, atol=2e-5, rtol=1e-3)
 
 
+def test_encoders_without_patch_embedding():
+    """in_chans == embed_dim[0] with patch (1,1,1): the reference builds stage 0 (Swin_3D.py:417-420) / the first conv_block
+    (encoder/CNN_3D.py:112-118) WITHOUT a downsample — oracle against the reference's outputs, parameter and input gradients."""
+    for name, enc_fn, kw in (("swin_nopatch_c16", O.swin_encoder, dict()), ("cnn_nopatch_c16", O.cnn_encoder, dict(encoder="CNN_3D"))):
+        a, sd, grads = load_golden(name)
+        assert not any("layers_var.0.0.downsample" in k for k in sd)
+        cfg = O.default_cfg(in_channels_dynamic=2, in_channels=16, **kw)
+        sdl = leaf({"encoder." + k: v for k, v in sd.items()})
+        x = a["x"].clone().requires_grad_()
+        y = enc_fn(x, sdl, cfg)
+        close(y, a["y"])
+        (y * a["r"]).sum().backward()
+        check_grads(sdl, {"encoder." + k: v for k, v in grads.items()}, atol=2e-5, rtol=1e-3)
+        torch.testing.assert_close(x.grad, a["dx"], atol=2e-5, rtol=1e-3)
+
+
 @pytest.mark.parametrize("tag", ["122", "222_c2"])
 def test_swin_encoder_patch_size(tag):
     """en_patch_size != (1,1,1): stage-0 PatchEmbed3D with kernel = stride = patch and zero padding to a multiple of the patch
