@@ -2708,7 +2708,10 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_dma_kernel(WgradArgs a,
   const int xrow = rowlen * CI, yrow = segp * CO;         // floats per staged row
   float* s_x = s_dyn;                                     // [4][rowlen][CI]
   float* s_dy = s_dyn + 4 * xrow;                         // [2][segp][CO]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (wave index as a SCALAR: with `tid >> 6` in a vector register the per-fragment validity test below compiled to an EXEC-mask
+  //  branch per fragment — s_and_saveexec / s_cbranch_execz around every group of GB MFMAs, each group behind its own ds_read +
+  //  s_waitcnt lgkmcnt(0): the LDS round trip exposed 7 times per K step, MFMA-busy 0.60 in the register-staged kernel)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
   const int wset = blockIdx.y;
 
@@ -2788,18 +2791,31 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_dma_kernel(WgradArgs a,
       const float* yb = s_dy + (h & 1) * yrow + kq * CO + r16;
       const int yrot = ROTY ? ((kq >> 1) & 1) : 0;
       const int steps = segp >> 2;
-#pragma unroll 2
+      // the operands of K step s + 1 are read from LDS while step s is multiplied (scheduling fences: left alone the compiler
+      // sinks every read to just before its MFMAs); a fragment whose source row lies outside the frame multiplies zeros
+      float afn[FPW], bfn[GB];
+      auto rd = [&](int s_, float (&af_)[FPW], float (&bf_)[GB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) af_[f] = s_x[base[f] + s_ * 4 * CI];
+#pragma unroll
+        for (int n = 0; n < GB; ++n) bf_[n] = yb[s_ * 4 * CO + 16 * (n ^ yrot)];
+      };
+#pragma unroll
+      for (int f = 0; f < FPW; ++f) if (!okf[f]) base[f] = base[0];     // (any valid address; its product is masked below)
+      rd(0, afn, bfn);
       for (int s = 0; s < steps; ++s) {
-        float bf[GB];
+        float af[FPW], bf[GB];
 #pragma unroll
-        for (int n = 0; n < GB; ++n) { bf[n] = yb[s * 4 * CO + 16 * (n ^ yrot)]; bsum[n] += bf[n]; }
+        for (int f = 0; f < FPW; ++f) af[f] = okf[f] ? afn[f] : 0.f;
 #pragma unroll
-        for (int f = 0; f < FPW; ++f) {
-          if (!okf[f]) continue;
-          const float af = s_x[base[f] + s * 4 * CI];
+        for (int n = 0; n < GB; ++n) { bf[n] = bfn[n]; bsum[n] += bf[n]; }
+        if (s + 1 < steps) rd(s + 1, afn, bfn);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int n = 0; n < GB; ++n) acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[f][n], 0, 0, 0);
-        }
+        for (int f = 0; f < FPW; ++f)
+#pragma unroll
+          for (int n = 0; n < GB; ++n) acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], bf[n], acc[f][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA blocks of the next row have landed
       __syncthreads();                                    // ... every wave's; and this row's readers are done
