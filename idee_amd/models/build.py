@@ -68,12 +68,11 @@ class VQ_model(nn.Module):
         if ad not in ("f32", "bf16"):
             raise ValueError(f"config.act_dtype must be 'f32' or 'bf16', got {ad!r}")
         self.act_dtype = torch.bfloat16 if ad == "bf16" else torch.float32
-        if self.act_dtype == torch.bfloat16 and config.encoder != "Swin_3D":
-            raise NotImplementedError("bf16 activation storage is built for the Swin_3D encoder (BASELINE config #4)")
-        if self.act_dtype == torch.bfloat16 and (config.en_drop_rate > 0 or config.en_attn_drop_rate > 0):
-            raise NotImplementedError("element-wise dropout inside the Swin block (en_drop_rate / en_attn_drop_rate > 0) is built for f32 "
-                                      "activation storage only; with config.act_dtype = 'bf16' set both rates to 0")
-        self.encoder.act_dtype = self.act_dtype
+        # bf16 storage with the CNN_3D encoder: its LayerNorm / ReLU / residual units (idee_ln_relu_res_*) are f32-storage kernels, so
+        # the encoder keeps f32 tokens INSIDE and hands bf16 tokens on (codebook, classifier and their gradients in bf16 storage);
+        # element-wise dropout inside a Swin block (en_drop_rate / en_attn_drop_rate > 0) is built in the exact-f32 block kernels: under
+        # bf16 storage such a block widens its tokens to f32 for the block and narrows them again (models/encoder/Swin_3D.py)
+        self.encoder.act_dtype = self.act_dtype if config.encoder == "Swin_3D" else torch.float32
         # IDEE_SIGN_FIELD=0 runs the classifier on z_q itself, convolution for convolution as build.py:157
         self.sign_field_classifier = os.environ.get("IDEE_SIGN_FIELD", "1") != "0" and self.codebook_impl == "LFQ"
         self._init_weights()
@@ -109,6 +108,8 @@ class VQ_model(nn.Module):
         """x_d (N,V,C,T,H,W) -> z (N,1,H,W), y [V x (N,1,H,W)], anomaly int64 (N,V,T,H,W),
         z_q (N,V,C,T,H,W), loss_z_q (1,)   — build.py:130-159."""
         z = self.encoder.forward_tokens(x_d)                 # (N,V,T,H,W,E)
+        if z.dtype != self.act_dtype:                        # (CNN_3D under bf16 storage: f32 inside the encoder, see __init__)
+            z = z.to(self.act_dtype)
         if self.sign_field_classifier and self.cls.dim // self.cls.in_var % 16 == 0:
             # z_q has rank codebook_dim per variable: the classifier's first convolutions read the +-1 code bits
             # with weights folded through project_out (exact refactoring, DESIGN.md "rank-d classifier input")

@@ -209,11 +209,16 @@ class Swin_3D(_stacked.StackedModule):
                 if self.training and dpr[blk] > 0.0:
                     ps = drop_path_factors(t.shape[0] * t.shape[1], dpr[blk], t.device)
                 blk += 1
-                t = ops.SwinBlock.apply(t, *(getattr(self, p + n) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w",
-                                                                           "fc1_b", "fc2_w", "fc2_b", "table")),
+                # (dropout blocks run on the exact-f32 kernels: under bf16 storage the tokens are widened for the block)
+                widen = use_drop and t.dtype != torch.float32
+                t = ops.SwinBlock.apply(t.float() if widen else t,
+                                        *(getattr(self, p + n) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w",
+                                                                         "fc1_b", "fc2_w", "fc2_b", "table")),
                                         index, self.num_heads[s], wsz, (0, 0, 0) if b % 2 == 0 else shift, self.qk_scale, ps,
                                         self.drop_rate if use_drop else 0.0, self.attn_drop_rate if use_drop else 0.0,
                                         int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if use_drop else 0)
+                if widen:
+                    t = t.to(self.act_dtype)
         return ops.ProjVar.apply(t, self.pv_w1, self.pv_b1, self.pv_w2, self.pv_b2)
 
     def forward(self, x):

@@ -282,6 +282,71 @@ def test_e2e_bf16_train_steps_reduce_the_loss(impl):
     assert (losses[-1] < losses[0]) if impl == "LFQ" else (min(losses[1:]) < losses[0])
 
 
+def test_bf16_storage_with_elementwise_dropout():
+    """config.act_dtype = "bf16" with en_drop_rate / en_attn_drop_rate > 0 (reference: Swin_3D.py:34-41, 138-140, 172, 176): the
+    dropout blocks run on the exact-f32 block kernels with their tokens widened for the block (models/encoder/Swin_3D.py).  Eval
+    mode equals the rate-0 bf16 model bit for bit; training steps differ from step to step, every gradient is finite and the
+    tokens handed on are bf16."""
+    from idee_amd.train import SyntheticTrainStep
+    a, sd, cfg, m = _bf16_model(en_drop_rate=0.1, en_attn_drop_rate=0.1)
+    _, _, _, m0 = _bf16_model()
+    m.load_state_dict(sd, strict=True); m0.load_state_dict(sd, strict=True)
+    m, m0 = m.to(DEV), m0.to(DEV)
+    x = a["x_d"].to(DEV)
+    m.eval(); m0.eval()
+    with torch.no_grad():
+        o, o0 = m(x), m0(x)
+    assert torch.equal(o[0], o0[0]) and torch.equal(o[2], o0[2]) and o[3].dtype == BF
+    m.train()
+    torch.manual_seed(1)
+    z1 = m.encoder.forward_tokens(x); z2 = m.encoder.forward_tokens(x)
+    assert z1.dtype == BF and float((z1.float() - z2.float()).abs().max()) > 1e-3
+    ts = SyntheticTrainStep(cfg, device=DEV, model=m)
+    g = torch.Generator().manual_seed(3)
+    N, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+    me = (torch.rand((N, H, W), generator=g) < 0.3).float().to(DEV)
+    ml = (torch.rand((N, H, W), generator=g) < 0.4).float().to(DEV)
+    total, parts, _ = ts.step(x, me, ml)
+    assert torch.isfinite(total) and torch.isfinite(ts.opt.flat_g).all()
+
+
+def test_bf16_storage_with_cnn3d_encoder():
+    """config.act_dtype = "bf16" with encoder = CNN_3D (reference: models/encoder/CNN_3D.py:74-237): the encoder keeps f32 tokens
+    inside (its LayerNorm / ReLU / residual kernels are f32-storage kernels) and hands bf16 tokens to the codebook and the classifier.
+    Against the reference's own f32 outputs (golden e2e fixture): LFQ code flips counted, logits at flip-free pixels at 5e-2 of
+    their scale; one train step with finite gradients for every parameter."""
+    from conftest import load_golden
+    from idee_amd.config import default_config
+    from idee_amd.models.build import VQ_model
+    from idee_amd.train import SyntheticTrainStep
+    a, sd, _ = load_golden("e2e_cnn_v2_12x16")
+    cfg = default_config(encoder="CNN_3D", in_channels=int(a["cfg_C"]), in_channels_dynamic=int(a["cfg_V"]), act_dtype="bf16")
+    m = VQ_model(cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        z, y, an, zq, lz = m(a["x_d"].to(DEV))
+    assert zq.dtype == BF and z.dtype == torch.float32
+    flips = (an.cpu() != a["eval/anomaly"].long())
+    frac = float(flips.float().mean())
+    print(f"[bf16 cnn e2e] LFQ code flips vs the f32 reference: {int(flips.sum())}/{flips.numel()} ({100 * frac:.3f} %)")
+    assert frac < 0.02
+    ok = (F.max_pool2d(flips.any(dim=(1, 2)).float().unsqueeze(1), 7, 1, 3) == 0)
+    assert float(ok.float().mean()) > 0.2
+    zr = a["eval/z"]
+    err = ((z.cpu() - zr).abs() * ok).max()
+    assert float(err) <= 5e-2 * float(zr.abs().max()) + 1e-3
+    m.train()
+    ts = SyntheticTrainStep(cfg, device=DEV, model=m)
+    x = a["x_d"].to(DEV)
+    g = torch.Generator().manual_seed(3)
+    N, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+    me = (torch.rand((N, H, W), generator=g) < 0.3).float().to(DEV)
+    ml = (torch.rand((N, H, W), generator=g) < 0.4).float().to(DEV)
+    total, parts, _ = ts.step(x, me, ml)
+    assert torch.isfinite(total) and torch.isfinite(ts.opt.flat_g).all()
+
+
 def test_bf16_and_f32_gradients_agree_on_the_small_model():
     """The flat gradient of one train step with bf16 activation storage against the f32 path on the same parameters and batch:
     cosine similarity >= 0.99 and a relative l2 error <= 0.15 (the LFQ flips and bf16 rounding of ~40 chained units)."""

@@ -1363,10 +1363,10 @@ def test_swin_block_elementwise_dropout_vs_oracle(C, window, shift, D, H, W, ker
     assert float((y0 - y.detach()).abs().max()) > 1e-3
 
 
-def test_swin_encoder_dropout_module_flags_and_bf16_refusal(set_opt):
+def test_swin_encoder_dropout_module_flags(set_opt):
     """Swin_3D(drop_rate, attn_drop_rate): training forward / backward run with fresh masks per step (two steps differ), eval is
-    deterministic and equals the rate-0 encoder; under IDEE_SWIN_MATH=f22 the dropout blocks run (on the exact kernels); bf16
-    activation storage with a non-zero rate is refused when the MODEL is built."""
+    deterministic and equals the rate-0 encoder; under IDEE_SWIN_MATH=f22 the dropout blocks run (on the exact kernels).  (bf16
+    activation storage with a non-zero rate: tests/test_bf16_path.py.)"""
     from idee_amd.models.encoder.Swin_3D import Swin_3D
     from idee_amd import _lib as L
     torch.manual_seed(5)
@@ -1387,10 +1387,6 @@ def test_swin_encoder_dropout_module_flags_and_bf16_refusal(set_opt):
     yf = enc(x)
     yf.sum().backward()
     assert torch.isfinite(yf).all() and float((yf - y1).abs().max()) > 1e-4
-    from idee_amd.config import default_config
-    from idee_amd.models.build import VQ_model
-    with pytest.raises(NotImplementedError, match="dropout"):
-        VQ_model(default_config(encoder="Swin_3D", in_channels=1, act_dtype="bf16", en_drop_rate=0.1))
 
 
 @variants('default', 'swin_split', 'swin_f22')
