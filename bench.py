@@ -36,9 +36,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")             # --math f32
-PMC_SUMMARY_F22 = os.path.join(ROOT, "profiles", "r04_pmc_traffic_f22.json")     # --math f22 (the default line)
-PMC_SUMMARY_BF16 = os.path.join(ROOT, "profiles", "r03_pmc_traffic_config4_bf16.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")             # --math f32 (the default line)
+PMC_SUMMARY_F22 = os.path.join(ROOT, "profiles", "r05_pmc_traffic_f22.json")     # --math f22 (the `f22` side line)
+PMC_SUMMARY_BF16 = os.path.join(ROOT, "profiles", "r05_pmc_traffic_config4_bf16.json")
 
 CONFIGS = {
     # id: (encoder, H, W, T, C_in, per-GPU batch, model overrides, step kind, label)
@@ -474,7 +474,7 @@ def roofline_of(fam, math, dtype, steps, dt, headline, a):
     else:
         traffic, src = pmc_traffic(k, lps, headline and math in ("f32", "f22"), PMC_SUMMARY_F22 if math == "f22" else PMC_SUMMARY)
     gbs, tf_eq = by / ms / 1e6, fl / ms / 1e9
-    if dtype == "f32" and math == "f32":
+    if dtype == "f32" and (math == "f32" or pf == 0):      # (pf == 0: every launch of the family ran on the exact-f32 MFMA)
         return dict(common, bound="mfma", achieved=round(tf_eq, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(tf_eq / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=src,
                     pipe="v_mfma_f32_16x16x4_f32 (f32 MFMA = f32 vector rate; it does not co-execute with the VALU stream, so "

@@ -80,9 +80,9 @@ _SIGS = {
     "idee_ln_relu_res_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
     "idee_ln_relu_res_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
     "idee_dropout_mask_": (_I, [_P, _L, _F, C.c_uint64, _I, _P]),
-    "idee_lfq_workspace_floats": (_L, [_L, _I]),
-    "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _I, _P]),
-    "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _I, _P]),
+    "idee_lfq_workspace_floats": (_L, [_L, _I, _I]),
+    "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _F, _I, _P]),
+    "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _I, _P]),
     "idee_patch_merging_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "idee_patch_merging_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "idee_lfq_sign_field_fwd": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _I, _P]),

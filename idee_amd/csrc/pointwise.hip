@@ -440,38 +440,41 @@ __device__ __forceinline__ void lfq_probs(const float (&s)[D], float (&p)[1 << D
 }
 
 
-// E/4 adjacent lanes per token, each owning 4 channels: every access is a 16-byte piece of a contiguous stream
-template <int E, int D, typename AT>
+// E/4 adjacent lanes per token, each owning 4 channels: every access is a 16-byte piece of a contiguous stream.
+// NCB codebooks of D bits each (LFQ.py num_codebooks: the projected token is split 'b n (c d) -> b n c d', :215): DT = NCB D code
+// bits per token; every codebook has its own softmax over its 2^D codes, the quantisation, straight-through path and commitment
+// term are per bit.  sums per block: [0] sum over tokens and codebooks of H  [1] sum (s-q)^2  [2 + c K + k] sum_tokens p_c[k]
+template <int E, int D, int NCB, typename AT>
 __global__ __launch_bounds__(256) void lfq_fwd_kernel(const AT* __restrict__ z, const float* __restrict__ w_in,
                                                       const float* __restrict__ b_in, const float* __restrict__ w_out,
                                                       const float* __restrict__ b_out, AT* __restrict__ zq,
                                                       long long* __restrict__ indices, float* __restrict__ partials,
                                                       float* __restrict__ qs, long M, int training) {
-  constexpr int K = 1 << D, R = 2 + K, QE = E / 4;
+  constexpr int K = 1 << D, DT = D * NCB, R = 2 + NCB * K, QE = E / 4;
   __shared__ float smem[R * 4];
   float acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
   const int q = threadIdx.x % QE;
-  f32x4 wi[D], wo[D], bo;
+  f32x4 wi[DT], wo[DT], bo;
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
+  for (int i = 0; i < DT; ++i) {
     wi[i] = ld4(w_in + i * E + 4 * q);
-    wo[i] = f32x4{w_out[(4 * q) * D + i], w_out[(4 * q + 1) * D + i], w_out[(4 * q + 2) * D + i], w_out[(4 * q + 3) * D + i]};
+    wo[i] = f32x4{w_out[(4 * q) * DT + i], w_out[(4 * q + 1) * DT + i], w_out[(4 * q + 2) * DT + i], w_out[(4 * q + 3) * DT + i]};
   }
   bo = ld4(b_out + 4 * q);
   for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
     const long tok = u / QE;
     const f32x4 zi = ldx4<AT>(z + tok * E + 4 * q);
-    float s[D], qv[D];
+    float s[DT], qv[DT];
     long long idx = 0;
     f32x4 o = bo;
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
+    for (int i = 0; i < DT; ++i) {
       const float a = tok_sum<QE>(zi[0] * wi[i][0] + zi[1] * wi[i][1] + zi[2] * wi[i][2] + zi[3] * wi[i][3]) + b_in[i];
       s[i] = a;
       qv[i] = a > 0.f ? 1.f : -1.f;                // strict > (LFQ.py:222,234)
-      idx |= (long long)(a > 0.f) << (D - 1 - i);
+      idx |= (long long)(a > 0.f) << (DT - 1 - i);  // (the NCB per-codebook indices, most significant codebook first: D bits each)
       o += wo[i] * qv[i];
     }
     stx4<AT>(zq + tok * E + 4 * q, o);
@@ -479,14 +482,19 @@ __global__ __launch_bounds__(256) void lfq_fwd_kernel(const AT* __restrict__ z, 
       indices[tok] = idx;
       if (qs)
 #pragma unroll
-        for (int i = 0; i < D; ++i) qs[tok * D + i] = qv[i];
+        for (int i = 0; i < DT; ++i) qs[tok * DT + i] = qv[i];
       if (training) {
-        float p[K];
-        lfq_probs<D>(s, p);
 #pragma unroll
-        for (int k = 0; k < K; ++k) { acc[0] -= p[k] * __logf(fmaxf(p[k], kLogEps)); acc[2 + k] += p[k]; }
+        for (int c = 0; c < NCB; ++c) {
+          float sc[D], p[K];
 #pragma unroll
-        for (int i = 0; i < D; ++i) { const float d = s[i] - qv[i]; acc[1] = fmaf(d, d, acc[1]); }
+          for (int i = 0; i < D; ++i) sc[i] = s[c * D + i];
+          lfq_probs<D>(sc, p);
+#pragma unroll
+          for (int k = 0; k < K; ++k) { acc[0] -= p[k] * __logf(fmaxf(p[k], kLogEps)); acc[2 + c * K + k] += p[k]; }
+        }
+#pragma unroll
+        for (int i = 0; i < DT; ++i) { const float d = s[i] - qv[i]; acc[1] = fmaf(d, d, acc[1]); }
       }
     }
   }
@@ -498,11 +506,12 @@ __global__ __launch_bounds__(256) void lfq_fwd_kernel(const AT* __restrict__ z, 
   }
 }
 
-// stats out: [0] aux loss, [1] per-sample entropy, [2] batch entropy, [3] commit, [4..4+K) avg prob
-template <int D>
+// stats out: [0] aux loss, [1] per-sample entropy (mean over tokens and codebooks), [2] codebook entropy (mean over codebooks of
+// H(avg prob)), [3] commit, [4 + c K + k] avg prob of code k of codebook c   (LFQ.py:258-262)
+template <int D, int NCB>
 __global__ void lfq_finalize_kernel(const float* __restrict__ partials, int nblocks, float* __restrict__ stats, long M,
                                     float w_ent, float gamma, float w_commit) {
-  constexpr int K = 1 << D, R = 2 + K;
+  constexpr int K = 1 << D, R = 2 + NCB * K;
   __shared__ double sm[R][64];
   const int t = threadIdx.x;   // 64 threads
   for (int r = 0; r < R; ++r) {
@@ -515,21 +524,26 @@ __global__ void lfq_finalize_kernel(const float* __restrict__ partials, int nblo
   if (t == 0) {
     double tot[R];
     for (int r = 0; r < R; ++r) { double s = 0.0; for (int i = 0; i < 64; ++i) s += sm[r][i]; tot[r] = s; }
-    const float per_sample = (float)(tot[0] / (double)M);
-    const float commit = (float)(tot[1] / ((double)M * D));
-    float hb = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float a = (float)(tot[2 + k] / (double)M);
-      stats[4 + k] = a;
-      hb -= a * logf(fmaxf(a, kLogEps));
+    const float per_sample = (float)(tot[0] / ((double)M * NCB));
+    const float commit = (float)(tot[1] / ((double)M * D * NCB));
+    float hbs = 0.f;
+    for (int c = 0; c < NCB; ++c) {
+      float hb = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float a = (float)(tot[2 + c * K + k] / (double)M);
+        stats[4 + c * K + k] = a;
+        hb -= a * logf(fmaxf(a, kLogEps));
+      }
+      hbs += hb;
     }
-    stats[1] = per_sample; stats[2] = hb; stats[3] = commit;
-    stats[0] = commit * w_commit + w_ent * per_sample - gamma * hb;
+    hbs *= 1.f / NCB;
+    stats[1] = per_sample; stats[2] = hbs; stats[3] = commit;
+    stats[0] = commit * w_commit + w_ent * per_sample - gamma * hbs;
   }
 }
 
 // backward.  gscal[0] = upstream gradient of the aux loss.  grads accumulate with atomics.
-template <int E, int D, bool HASG /*a dense d z_q exists*/, typename AT>
+template <int E, int D, int NCB, bool HASG /*a dense d z_q exists*/, typename AT>
 __global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, const AT* __restrict__ dzq,
                                                       const float* __restrict__ w_in, const float* __restrict__ b_in,
                                                       const float* __restrict__ w_out, const float* __restrict__ stats,
@@ -538,19 +552,21 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, 
                                                       float* __restrict__ db_in, float* __restrict__ dw_out,
                                                       float* __restrict__ db_out, long M, float w_ent, float gamma,
                                                       float w_commit) {
-  constexpr int K = 1 << D, QE = E / 4;
+  constexpr int K = 1 << D, DT = D * NCB, QE = E / 4;
   const float g = gscal[0];
   const float invM = 1.f / (float)M;
-  float ub[K];   // d Hbatch / d a_k
+  float ub[NCB][K];   // d Hcodebook_c / d a_ck
 #pragma unroll
-  for (int k = 0; k < K; ++k) { const float a = stats[4 + k]; ub[k] = -(logf(fmaxf(a, kLogEps)) + (a >= kLogEps ? 1.f : 0.f)); }
+  for (int c = 0; c < NCB; ++c)
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const float a = stats[4 + c * K + k]; ub[c][k] = -(logf(fmaxf(a, kLogEps)) + (a >= kLogEps ? 1.f : 0.f)); }
   const int q = threadIdx.x % QE;
-  f32x4 wi[D], wo[D], gwi[D], gwo[D], gbo = {0.f, 0.f, 0.f, 0.f};
-  float gbi[D];
+  f32x4 wi[DT], wo[DT], gwi[DT], gwo[DT], gbo = {0.f, 0.f, 0.f, 0.f};
+  float gbi[DT];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
+  for (int i = 0; i < DT; ++i) {
     wi[i] = ld4(w_in + i * E + 4 * q);
-    wo[i] = f32x4{w_out[(4 * q) * D + i], w_out[(4 * q + 1) * D + i], w_out[(4 * q + 2) * D + i], w_out[(4 * q + 3) * D + i]};
+    wo[i] = f32x4{w_out[(4 * q) * DT + i], w_out[(4 * q + 1) * DT + i], w_out[(4 * q + 2) * DT + i], w_out[(4 * q + 3) * DT + i]};
     gwi[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gwo[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gbi[i] = 0.f;
   }
   // UN tokens per lane and trip: 2 UN sixteen-byte loads in flight before the first dependent instruction
@@ -559,7 +575,7 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, 
   for (long u0 = (long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += UN * stride) {
    long tokq[UN];
    f32x4 ziq[UN], goq[UN];
-   float dqq[UN][D];
+   float dqq[UN][DT];
 #pragma unroll
    for (int r = 0; r < UN; ++r) {
      const long u = u0 + r * stride;
@@ -567,41 +583,46 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, 
      ziq[r] = ldx4<AT>(z + tokq[r] * E + 4 * q);
      goq[r] = HASG ? ldx4<AT>(dzq + tokq[r] * E + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};   // no dense consumer of z_q: no read
 #pragma unroll
-     for (int i = 0; i < D; ++i) dqq[r][i] = dqs ? dqs[tokq[r] * D + i] : 0.f;
+     for (int i = 0; i < DT; ++i) dqq[r][i] = dqs ? dqs[tokq[r] * DT + i] : 0.f;
    }
 #pragma unroll
    for (int half = 0; half < UN; ++half) {
     if (u0 + half * stride >= total) break;
     const long tok = tokq[half];
     const f32x4 zi = ziq[half], go = goq[half];
-    float s[D], qv[D], ds[D];
+    float s[DT], qv[DT], ds[DT];
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
+    for (int i = 0; i < DT; ++i) {
       const float a = tok_sum<QE>(zi[0] * wi[i][0] + zi[1] * wi[i][1] + zi[2] * wi[i][2] + zi[3] * wi[i][3]) + b_in[i];
       s[i] = a; qv[i] = a > 0.f ? 1.f : -1.f;
       // straight-through: d x_ste = W_out^T dz_q
       const float d = HASG ? tok_sum<QE>(go[0] * wo[i][0] + go[1] * wo[i][1] + go[2] * wo[i][2] + go[3] * wo[i][3]) : 0.f;
-      ds[i] = d + dqq[half][i] + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / D);
-    }
-    float p[K];
-    lfq_probs<D>(s, p);
-    float us = 0.f, ubs = 0.f, uu[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      uu[k] = -(__logf(fmaxf(p[k], kLogEps)) + (p[k] >= kLogEps ? 1.f : 0.f));
-      us = fmaf(uu[k], p[k], us);
-      ubs = fmaf(ub[k], p[k], ubs);
+      ds[i] = d + dqq[half][i] + g * w_commit * 2.f * (s[i] - qv[i]) * invM * (1.f / DT);
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      // d/dlogit_k of (w_ent * H_i / M - gamma * Hbatch)
-      const float dl = p[k] * (w_ent * (uu[k] - us) - gamma * (ub[k] - ubs)) * invM * g * kInvTemp2;
+    for (int c = 0; c < NCB; ++c) {
+      float sc[D], p[K];
 #pragma unroll
-      for (int i = 0; i < D; ++i) ds[i] += ((k >> (D - 1 - i)) & 1) ? dl : -dl;
+      for (int i = 0; i < D; ++i) sc[i] = s[c * D + i];
+      lfq_probs<D>(sc, p);
+      float us = 0.f, ubs = 0.f, uu[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        uu[k] = -(__logf(fmaxf(p[k], kLogEps)) + (p[k] >= kLogEps ? 1.f : 0.f));
+        us = fmaf(uu[k], p[k], us);
+        ubs = fmaf(ub[c][k], p[k], ubs);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        // d/dlogit_k of (w_ent * H_c(token) / (M NCB) - gamma * Hcodebook_c / NCB)
+        const float dl = p[k] * (w_ent * (uu[k] - us) - gamma * (ub[c][k] - ubs)) * invM * (1.f / NCB) * g * kInvTemp2;
+#pragma unroll
+        for (int i = 0; i < D; ++i) ds[c * D + i] += ((k >> (D - 1 - i)) & 1) ? dl : -dl;
+      }
     }
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
+    for (int i = 0; i < DT; ++i) {
       o += wi[i] * ds[i];
       gwi[i] += zi * ds[i];
       if (HASG) gwo[i] += go * qv[i];
@@ -619,29 +640,29 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, 
     for (int o = QE; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
   };
-  constexpr int NV = D + 2 * D * E + E;          // [db_in: D][dw_in: D x E][dw_out: E x D][db_out: E]
+  constexpr int NV = DT + 2 * DT * E + E;          // [db_in: DT][dw_in: DT x E][dw_out: E x DT][db_out: E]
   __shared__ float s_fl[4][NV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* fl = s_fl[wave];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
+  for (int i = 0; i < DT; ++i) {
     const float bi = same_q_sum(gbi[i]);
     if (lane == 0) fl[i] = bi;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float a = same_q_sum(gwi[i][c]), b2 = same_q_sum(gwo[i][c]);
-      if (lane < QE) { fl[D + i * E + 4 * q + c] = a; fl[D + D * E + (4 * q + c) * D + i] = b2; }
+      if (lane < QE) { fl[DT + i * E + 4 * q + c] = a; fl[DT + DT * E + (4 * q + c) * DT + i] = b2; }
     }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float a = same_q_sum(gbo[c]);
-    if (lane < QE) fl[D + 2 * D * E + 4 * q + c] = a;
+    if (lane < QE) fl[DT + 2 * DT * E + 4 * q + c] = a;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NV; i += 256) {
     const float v = (s_fl[0][i] + s_fl[1][i]) + (s_fl[2][i] + s_fl[3][i]);
-    float* dst = i < D ? db_in + i : i < D + D * E ? dw_in + (i - D) : i < D + 2 * D * E ? dw_out + (i - D - D * E) : db_out + (i - D - 2 * D * E);
+    float* dst = i < DT ? db_in + i : i < DT + DT * E ? dw_in + (i - DT) : i < DT + 2 * DT * E ? dw_out + (i - DT - DT * E) : db_out + (i - DT - 2 * DT * E);
     atomicAdd(dst, v);
   }
 }
@@ -1798,35 +1819,38 @@ extern "C" int idee_stage_embed_ln_bwd(const float* x, const float* w, const flo
 
 static int log2i(int k) { int d = 0; while ((1 << d) < k) ++d; return d; }
 
-extern "C" long idee_lfq_workspace_floats(long M, int codebook_size) {
-  return (long)stream_grid(M * 4) * (2 + codebook_size);
+extern "C" long idee_lfq_workspace_floats(long M, int codebook_size, int num_codebooks) {
+  return (long)stream_grid(M * 4) * (2 + (long)(num_codebooks > 0 ? num_codebooks : 1) * codebook_size);
 }
 
+// (dim E, D bits per codebook, NCB codebooks): what models/build.py constructs (one codebook of 2 .. 8 codes) and the
+// several-codebook forms of LFQ.py:92-101 with up to 4 code bits per token
 #define LFQ_DISPATCH(CALL)                                                                             \
-  if (E == 16 && D == 1) { CALL(16, 1); } else if (E == 16 && D == 2) { CALL(16, 2); }                   \
-  else if (E == 16 && D == 3) { CALL(16, 3); } else if (E == 32 && D == 1) { CALL(32, 1); }              \
-  else if (E == 32 && D == 2) { CALL(32, 2); }                                                           \
-  else return idee::fail(IDEE_ERR_UNSUPPORTED, "lfq: (dim=%d, codebook_size=%d) not built", E, 1 << D);
-
-
+  if (E == 16 && D == 1 && NCB == 1) { CALL(16, 1, 1); } else if (E == 16 && D == 2 && NCB == 1) { CALL(16, 2, 1); }   \
+  else if (E == 16 && D == 3 && NCB == 1) { CALL(16, 3, 1); } else if (E == 32 && D == 1 && NCB == 1) { CALL(32, 1, 1); } \
+  else if (E == 32 && D == 2 && NCB == 1) { CALL(32, 2, 1); }                                          \
+  else if (E == 16 && D == 1 && NCB == 2) { CALL(16, 1, 2); } else if (E == 16 && D == 2 && NCB == 2) { CALL(16, 2, 2); } \
+  else if (E == 16 && D == 1 && NCB == 4) { CALL(16, 1, 4); } else if (E == 32 && D == 1 && NCB == 2) { CALL(32, 1, 2); } \
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "lfq: (dim=%d, codebook_size=%d, num_codebooks=%d) not built", E, 1 << D, NCB);
 
 extern "C" int idee_lfq_fwd(const void* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
                             void* zq, int64_t* indices, float* stats, float* workspace, float* signs, long M, int E,
-                            int codebook_size, int training, float w_entropy, float gamma, float w_commit, int act_dtype,
-                            idee_stream_t stream) {
+                            int codebook_size, int num_codebooks, int training, float w_entropy, float gamma, float w_commit,
+                            int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(z && w_in && b_in && w_out && b_out && zq && indices && M > 0, "lfq_fwd: bad argument");
   IDEE_CHECK_ARG(!training || (stats && workspace), "lfq_fwd: training needs stats and workspace");
-  const int D = log2i(codebook_size);
+  const int D = log2i(codebook_size), NCB = num_codebooks;
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
+  IDEE_CHECK_ARG(NCB >= 1, "lfq: num_codebooks %d", NCB);
   const int nb = stream_grid(M * 4);
   hipStream_t st = (hipStream_t)stream;
-#define CALL(E_, D_)                                                                                           \
+#define CALL(E_, D_, C_)                                                                                       \
   if (act_dtype == IDEE_DTYPE_BF16)                                                                            \
-    hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)z, w_in, b_in, w_out, b_out, \
+    hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_, C_, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)z, w_in, b_in, w_out, b_out, \
                        (bf16_t*)zq, (long long*)indices, workspace, signs, M, training);                       \
-  else hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_, float>), dim3(nb), dim3(256), 0, st, (const float*)z, w_in, b_in, w_out, b_out, \
+  else hipLaunchKernelGGL((lfq_fwd_kernel<E_, D_, C_, float>), dim3(nb), dim3(256), 0, st, (const float*)z, w_in, b_in, w_out, b_out, \
                      (float*)zq, (long long*)indices, workspace, signs, M, training);                          \
-  if (training) hipLaunchKernelGGL((lfq_finalize_kernel<D_>), dim3(1), dim3(64), 0, st, workspace, nb, stats, M, \
+  if (training) hipLaunchKernelGGL((lfq_finalize_kernel<D_, C_>), dim3(1), dim3(64), 0, st, workspace, nb, stats, M, \
                                    w_entropy, gamma, w_commit)
   LFQ_DISPATCH(CALL)
 #undef CALL
@@ -1836,20 +1860,21 @@ extern "C" int idee_lfq_fwd(const void* z, const float* w_in, const float* b_in,
 
 extern "C" int idee_lfq_bwd(const void* z, const void* dzq, const float* w_in, const float* b_in, const float* w_out,
                             const float* stats, const float* gloss, const float* dsigns, void* dz, float* dw_in, float* db_in,
-                            float* dw_out, float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma,
-                            float w_commit, int act_dtype, idee_stream_t stream) {
+                            float* dw_out, float* db_out, long M, int E, int codebook_size, int num_codebooks, float w_entropy,
+                            float gamma, float w_commit, int act_dtype, idee_stream_t stream) {
   IDEE_CHECK_ARG(z && w_in && b_in && w_out && stats && gloss && dz && dw_in && db_in && dw_out && db_out && M > 0,
                  "lfq_bwd: bad argument");     // dzq may be null: z_q had no dense consumer (gradients arrive through dsigns)
-  const int D = log2i(codebook_size);
+  const int D = log2i(codebook_size), NCB = num_codebooks;
   IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
-#define CALL2(E_, D_, AT_)                                                                                         \
-  if (dzq) hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, true, AT_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const AT_*)z, (const AT_*)dzq, w_in, b_in, \
+  IDEE_CHECK_ARG(NCB >= 1, "lfq: num_codebooks %d", NCB);
+#define CALL2(E_, D_, C_, AT_)                                                                                     \
+  if (dzq) hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, C_, true, AT_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const AT_*)z, (const AT_*)dzq, w_in, b_in, \
                      w_out, stats, gloss, dsigns, (AT_*)dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit);  \
-  else hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, false, AT_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const AT_*)z, (const AT_*)dzq, w_in, b_in,    \
+  else hipLaunchKernelGGL((lfq_bwd_kernel<E_, D_, C_, false, AT_>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const AT_*)z, (const AT_*)dzq, w_in, b_in,    \
                      w_out, stats, gloss, dsigns, (AT_*)dz, dw_in, db_in, dw_out, db_out, M, w_entropy, gamma, w_commit)
-#define CALL(E_, D_)                                                                                               \
-  const int nb = imin(cdiv(M * 4, 256), kCUs * wg_per_cu(lfq_bwd_kernel<E_, D_, true, float>));                    \
-  if (act_dtype == IDEE_DTYPE_BF16) { CALL2(E_, D_, bf16_t); } else { CALL2(E_, D_, float); }
+#define CALL(E_, D_, C_)                                                                                           \
+  const int nb = imin(cdiv(M * 4, 256), kCUs * wg_per_cu(lfq_bwd_kernel<E_, D_, C_, true, float>));                \
+  if (act_dtype == IDEE_DTYPE_BF16) { CALL2(E_, D_, C_, bf16_t); } else { CALL2(E_, D_, C_, float); }
   LFQ_DISPATCH(CALL)
 #undef CALL
 #undef CALL2

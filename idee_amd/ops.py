@@ -618,7 +618,10 @@ class LFQQuantize(torch.autograd.Function):
     BEFORE project_out, with the same straight-through gradient: consumers may read them instead of z_q."""
 
     @staticmethod
-    def forward(ctx, z, w_in, b_in, w_out, b_out, codebook_size, training, w_entropy, gamma, w_commit, want_signs=False):
+    def forward(ctx, z, w_in, b_in, w_out, b_out, codebook_size, training, w_entropy, gamma, w_commit, want_signs=False,
+                num_codebooks=1):
+        """num_codebooks > 1 (LFQ.py:92-101, :215): `codebook_size` codes PER codebook, w_in (num_codebooks * log2 K, E); `idx` then
+        packs the per-codebook indices, most significant codebook first (LFQ.split_indices unpacks them)."""
         z = _act(z)       # bf16 tokens stay bf16 (z_q and dz then are bf16 too); projections, bits and statistics are f32
         w_in, b_in, w_out, b_out = (_f32c(t) for t in (w_in, b_in, w_out, b_out))
         E = z.shape[-1]
@@ -626,14 +629,14 @@ class LFQQuantize(torch.autograd.Function):
         dev = z.device
         zq = torch.empty_like(z)
         idx = torch.empty(z.shape[:-1], device=dev, dtype=torch.int64)
-        stats = _zeros(4 + codebook_size, dev)
-        ws = torch.empty(L.load().idee_lfq_workspace_floats(M, codebook_size), device=dev, dtype=torch.float32)
-        D = max(1, codebook_size.bit_length() - 1)
+        stats = _zeros(4 + num_codebooks * codebook_size, dev)
+        ws = torch.empty(L.load().idee_lfq_workspace_floats(M, codebook_size, num_codebooks), device=dev, dtype=torch.float32)
+        D = max(1, codebook_size.bit_length() - 1) * num_codebooks
         signs = torch.empty(z.shape[:-1] + (D,), device=dev, dtype=torch.float32) if want_signs else None
         L.call("idee_lfq_fwd", ptr(z), ptr(w_in), ptr(b_in), ptr(w_out), ptr(b_out), ptr(zq), ptr(idx), ptr(stats), ptr(ws),
-               ptr(signs), M, E, codebook_size, int(training), w_entropy, gamma, w_commit, L.act_dtype(z), L.stream())
+               ptr(signs), M, E, codebook_size, num_codebooks, int(training), w_entropy, gamma, w_commit, L.act_dtype(z), L.stream())
         ctx.save_for_backward(z, w_in, b_in, w_out, stats)
-        ctx.cfg = (M, E, codebook_size, w_entropy, gamma, w_commit)
+        ctx.cfg = (M, E, codebook_size, num_codebooks, w_entropy, gamma, w_commit)
         ctx.mark_non_differentiable(idx)
         # an output nobody differentiates (z_q in a train step whose classifier and anomaly loss read the code bits) must reach
         # backward as None, not as a materialised zero tensor: that is what lets idee_lfq_bwd skip the dense d z_q stream
@@ -643,7 +646,7 @@ class LFQQuantize(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dzq, _didx, dloss, dsigns=None):
         z, w_in, b_in, w_out, stats = ctx.saved_tensors
-        M, E, K, w_entropy, gamma, w_commit = ctx.cfg
+        M, E, K, ncb, w_entropy, gamma, w_commit = ctx.cfg
         dzq = _like(dzq, z) if dzq is not None else None   # None: no dense consumer of z_q (its users read the signs)
         gl = _f32c(dloss).reshape(1) if dloss is not None else torch.zeros(1, device=z.device)
         dz = torch.empty_like(z)
@@ -651,8 +654,8 @@ class LFQQuantize(torch.autograd.Function):
         db_out = _zeros(E, z.device)
         dsigns = _f32c(dsigns) if dsigns is not None else None
         L.call("idee_lfq_bwd", ptr(z), ptr(dzq), ptr(w_in), ptr(b_in), ptr(w_out), ptr(stats), ptr(gl), ptr(dsigns), ptr(dz),
-               ptr(dw_in), ptr(db_in), ptr(dw_out), ptr(db_out), M, E, K, w_entropy, gamma, w_commit, L.act_dtype(z), L.stream())
-        return dz, dw_in, db_in, dw_out, db_out, None, None, None, None, None, None
+               ptr(dw_in), ptr(db_in), ptr(dw_out), ptr(db_out), M, E, K, ncb, w_entropy, gamma, w_commit, L.act_dtype(z), L.stream())
+        return dz, dw_in, db_in, dw_out, db_out, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------

@@ -230,15 +230,17 @@ int idee_ln_relu_res_bwd(const float* c, const float* gamma, const float* beta, 
 int idee_dropout_mask_(void* x, long n, float p, uint64_t seed, int act_dtype, idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Lookup-free quantisation with projections (dim -> log2 K -> dim), straight-through gradient,
- * entropy + commitment auxiliary loss.  Replaces LFQ.forward, models/codebook/LFQ.py:183-307.
- *   z, zq, dz, dzq: (M, E) tokens; indices int64 (M)
- *   w_in (D, E), b_in (D), w_out (E, D), b_out (E),  D = log2(codebook_size)
- *   stats (4 + K floats): [aux loss, per-sample entropy, batch entropy, commit, avg prob[K]]
- *   workspace: idee_lfq_workspace_floats(M, K) floats
+ * Lookup-free quantisation with projections (dim -> num_codebooks * log2 K -> dim), straight-through gradient,
+ * entropy + commitment auxiliary loss.  Replaces LFQ.forward, models/codebook/LFQ.py:183-307 (num_codebooks: :92-101, :215).
+ *   z, zq, dz, dzq: (M, E) tokens; indices int64 (M): the num_codebooks per-codebook indices of a token packed most significant
+ *   codebook first, log2 K bits each (num_codebooks = 1: the reference's index)
+ *   w_in (D, E), b_in (D), w_out (E, D), b_out (E),  D = num_codebooks * log2(codebook_size) code bits per token
+ *   stats (4 + num_codebooks * K floats): [aux loss, per-sample entropy (mean over tokens and codebooks), codebook entropy (mean over
+ *   codebooks), commit, avg prob[codebook][K]]
+ *   workspace: idee_lfq_workspace_floats(M, K, num_codebooks) floats
  * bwd: gloss = device pointer to d(loss)/d(aux loss); dw_in, db_in, dw_out, db_out accumulate.
  * ---------------------------------------------------------------------------------------- */
-long idee_lfq_workspace_floats(long M, int codebook_size);
+long idee_lfq_workspace_floats(long M, int codebook_size, int num_codebooks);
 /* signs (M, D) | NULL: the +-1 code bits per token; dsigns (M, D) | NULL: an additional gradient on them (straight-through),
  * coming from consumers that read the sign field instead of z_q (the rank-d classifier input and anomaly loss below).
  * dzq | NULL: NULL when z_q has no dense consumer (every gradient arrives through dsigns): the 64-byte-per-token read is skipped. */
@@ -246,11 +248,11 @@ long idee_lfq_workspace_floats(long M, int codebook_size);
  * every parameter gradient are f32 in either case ("fp32 LFQ") */
 int idee_lfq_fwd(const void* z, const float* w_in, const float* b_in, const float* w_out, const float* b_out, void* zq,
                  int64_t* indices, float* stats, float* workspace, float* signs, long M, int E, int codebook_size,
-                 int training, float w_entropy, float gamma, float w_commit, int act_dtype, idee_stream_t stream);
+                 int num_codebooks, int training, float w_entropy, float gamma, float w_commit, int act_dtype, idee_stream_t stream);
 int idee_lfq_bwd(const void* z, const void* dzq, const float* w_in, const float* b_in, const float* w_out,
                  const float* stats, const float* gloss, const float* dsigns, void* dz, float* dw_in, float* db_in,
-                 float* dw_out, float* db_out, long M, int E, int codebook_size, float w_entropy, float gamma, float w_commit,
-                 int act_dtype, idee_stream_t stream);
+                 float* dw_out, float* db_out, long M, int E, int codebook_size, int num_codebooks, float w_entropy, float gamma,
+                 float w_commit, int act_dtype, idee_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rank-d classifier input (algebraic refactoring; exact in real arithmetic, disclosed in DESIGN.md):

@@ -355,6 +355,39 @@ def lfq(z, sd, cfg, training, pre="vq."):
     return out, indices, commit * cfg.lambda_commitment + ent_aux                         # :300
 
 
+def lfq_multi(z, sd, K, ncb, training, w_entropy, gamma, w_commit, pre=""):
+    """LFQ.forward with num_codebooks = ncb > 1 (LFQ.py:92-101, :215-300): the projected token is split into ncb groups of
+    d = log2 K bits; every codebook has its own softmax over its K codes; per-sample entropy = mean over (tokens, codebooks),
+    codebook entropy = mean over codebooks of H(mean prob) (:258-262); commit = mean over every bit (:270-274).
+    Returns z_q (b,n,dim), indices int64 (b,n,ncb), aux loss scalar."""
+    codebook, bitmask = lfq_codebook(K)
+    d = codebook.shape[1]
+    x = F.linear(z.float(), sd[pre + "project_in.weight"], sd[pre + "project_in.bias"])
+    x = x.reshape(*x.shape[:-1], ncb, d)                                                  # :215
+    q = torch.where(x > 0, torch.ones_like(x), -torch.ones_like(x))
+    xs = x + (q - x).detach() if training else q
+    indices = ((xs > 0).long() * bitmask).sum(-1)                                         # (b, n, c)
+    if training:
+        prob = (2.0 * torch.einsum("...id,jd->...ij", x, codebook) * 100.0).softmax(-1)   # (b, n, c, K)
+        prob = prob.reshape(-1, ncb, K)                                                   # 'b n ... -> (b n) ...'
+        per_sample = _entropy(prob).mean()
+        batch = _entropy(prob.mean(0)).mean()                                             # avg over tokens per codebook, then mean
+        ent_aux = w_entropy * per_sample - gamma * batch
+        commit = ((x - q.detach()) ** 2).mean()
+    else:
+        ent_aux = commit = torch.zeros(())
+    out = F.linear(xs.reshape(*xs.shape[:-2], ncb * d), sd[pre + "project_out.weight"], sd[pre + "project_out.bias"])
+    return out, indices, commit * w_commit + ent_aux
+
+
+def lfq_multi_indices_to_codes(indices, sd, K, pre=""):
+    """LFQ.indices_to_codes for (..., ncb) index tensors with project_out (LFQ.py:152-181)."""
+    codebook, _ = lfq_codebook(K)
+    codes = codebook[indices]
+    codes = codes.reshape(*codes.shape[:-2], -1)
+    return F.linear(codes, sd[pre + "project_out.weight"], sd[pre + "project_out.bias"])
+
+
 def lfq_indices_to_codes(indices, sd, cfg, pre="vq."):
     """LFQ.indices_to_codes with project_out, for a 1-D index tensor. LFQ.py:152-181."""
     codebook, _ = lfq_codebook(cfg.codebook_size)

@@ -295,6 +295,37 @@ def fx_lfq(tag, K, training, seed):
     save("lfq_" + tag, **out)
 
 
+def fx_lfq_multi(tag, K, ncb, training, seed):
+    """LFQ with SEVERAL codebooks (num_codebooks > 1, LFQ.py:92-101: the projected token is split 'b n (c d) -> b n c d', every
+    codebook has its own softmax over its K codes; indices come back as (b, n, c), :293-298), forward + every gradient."""
+    q = RefLFQ(dim=16, codebook_size=K, num_codebooks=ncb, entropy_loss_weight=0.1, diversity_gamma=0.1, commitment_loss_weight=3.0)
+    assert q.has_projections and q.keep_num_codebooks_dim
+    rerandomise(q, seed)
+    q.train(training)
+    x = rand((2, 300, 16), seed + 1)
+    x[0, :7] = 0.0
+    with torch.no_grad():
+        q.project_in.bias[0] = 0.0
+    x.requires_grad_()
+    zq, idx, aux = q(x)
+    r = rand(zq.shape, seed + 2)
+    code_idx = torch.tensor([[0] * ncb, [K - 1] * ncb, list(range(ncb))]) % K
+    out = dict(x=x.detach(), z_q=zq.detach(), indices=idx, aux=aux.detach(), r=r, K=np.array(K), ncb=np.array(ncb),
+               training=np.array(int(training)), code_idx=code_idx, codes=q.indices_to_codes(code_idx).detach())
+    if training:
+        ((zq * r).sum() + 2.5 * aux).backward()
+        out["dx"] = x.grad
+        out.update({"grad/" + k: p.grad for k, p in q.named_parameters()})
+    out.update(sd_arrays(q))
+    save("lfq_multi_" + tag, **out)
+
+
+if __name__ == "__main__" and "--lfqmulti-only" in sys.argv:
+    fx_lfq_multi("k2_c2_train", 2, 2, True, 230)
+    fx_lfq_multi("k4_c2_train", 4, 2, True, 240)
+    fx_lfq_multi("k2_c4_eval", 2, 4, False, 250)
+
+
 def fx_classifier(seed, V=2, n_classes=1):
     c = RefCls(in_var=V, embed_dim=16, dim=16, n_classes=n_classes, drop_rate=0.0)
     rerandomise(c, seed)
@@ -794,7 +825,7 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
                                                                 "--era5-only", "--hier-only", "--vqema-only", "--misc-only", "--era5items-only",
-                                                                "--cnnhier-only", "--patch-only", "--clsk-only", "--nopatch-only")):
+                                                                "--cnnhier-only", "--patch-only", "--clsk-only", "--nopatch-only", "--lfqmulti-only")):
     main()
     fx_classifier(1700, V=2, n_classes=3)
     fx_swin_hier("16_32", (16, 32), 1200)
@@ -805,6 +836,9 @@ if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "
     fx_swin_patch("222_c2", (2, 2, 2), 2, (16, 8, 10), 1610)
     fx_swin_nopatch(1800)
     fx_cnn_nopatch(1810)
+    fx_lfq_multi("k2_c2_train", 2, 2, True, 230)
+    fx_lfq_multi("k4_c2_train", 4, 2, True, 240)
+    fx_lfq_multi("k2_c4_eval", 2, 4, False, 250)
     fx_e2e_era5("era5_swin_v3_c2_10x12", ref_cfg(in_channels_dynamic=3, in_channels=2), N=2, T=8, H=10, W=12, seed=1100)
     fx_patch_mergings()
     fx_dataset_items()

@@ -548,6 +548,36 @@ def test_lfq_golden(tag):
             gclose("d" + n, p.grad, grads[n])
 
 
+@pytest.mark.parametrize("tag", ["k2_c2_train", "k4_c2_train", "k2_c4_eval"])
+def test_lfq_several_codebooks_golden(tag):
+    """LFQ(num_codebooks > 1) (LFQ.py:92-101, :215-300: per-codebook softmax, indices (b, n, c), mean-over-codebooks entropies) against
+    the reference's own outputs and gradients; state-dict keys and shapes as the reference's."""
+    from idee_amd.models.codebook.LFQ import LFQ
+    a, sd, grads = load_golden("lfq_multi_" + tag)
+    K, ncb, training = int(a["K"]), int(a["ncb"]), bool(int(a["training"]))
+    q = LFQ(dim=16, codebook_size=K, num_codebooks=ncb, entropy_loss_weight=0.1, diversity_gamma=0.1, commitment_loss_weight=3.0)
+    msd = q.state_dict()
+    assert list(msd) == list(sd) and all(tuple(msd[k].shape) == tuple(sd[k].shape) for k in sd)
+    q.load_state_dict(sd, strict=True)
+    q = q.to(DEV)
+    q.train(training)
+    x = dev(a["x"]).requires_grad_()
+    zq, idx, aux = q(x)
+    assert tuple(idx.shape) == tuple(a["indices"].shape)
+    s = a["x"] @ sd["project_in.weight"].t() + sd["project_in.bias"]
+    safe = (s.abs() > 1e-5).all(-1)
+    assert int((~safe).sum()) <= 8
+    assert torch.equal(idx.cpu()[safe], a["indices"].long()[safe])
+    close("z_q", zq.cpu()[safe], a["z_q"][safe])
+    close("aux", aux, a["aux"], atol=1e-5, rtol=5e-4)
+    close("codes", q.indices_to_codes(a["code_idx"].long().to(DEV)), a["codes"])
+    if training:
+        ((zq * dev(a["r"])).sum() + 2.5 * aux).backward()
+        gclose("dx", x.grad.cpu()[safe], a["dx"][safe])
+        for n, p in q.named_parameters():
+            gclose("d" + n, p.grad, grads[n])
+
+
 def _classifier(sd, V):
     from idee_amd.models.classifier.CNN_3D import CNN_3D
     c = CNN_3D(in_var=V, embed_dim=16, dim=16, n_classes=sd["conv3.weight"].shape[0], drop_rate=0.0)

@@ -109,6 +109,24 @@ def test_lfq(tag):
         check_grads(sd, grads)
 
 
+@pytest.mark.parametrize("tag", ["k2_c2_train", "k4_c2_train", "k2_c4_eval"])
+def test_lfq_several_codebooks(tag):
+    """LFQ(num_codebooks > 1) (LFQ.py:92-101, :215-300) in the oracle against the reference's outputs and gradients."""
+    a, sd, grads = load_golden("lfq_multi_" + tag)
+    sd = leaf(sd)
+    K, ncb, training = int(a["K"]), int(a["ncb"]), bool(int(a["training"]))
+    x = a["x"].clone().requires_grad_()
+    zq, idx, aux = O.lfq_multi(x, sd, K, ncb, training, 0.1, 0.1, 3.0)
+    close(zq, a["z_q"])
+    assert torch.equal(idx, a["indices"].long())
+    close(aux, a["aux"])
+    close(O.lfq_multi_indices_to_codes(a["code_idx"].long(), sd, K), a["codes"])
+    if training:
+        ((zq * a["r"]).sum() + 2.5 * aux).backward()
+        close(x.grad, a["dx"], 1e-5, 1e-3)
+        check_grads(sd, grads)
+
+
 @pytest.mark.parametrize("tag", ["classifier_v2", "classifier_v2_k3"])       # _k3: n_classes = 3
 def test_classifier(tag):
     a, sd, grads = load_golden(tag)
