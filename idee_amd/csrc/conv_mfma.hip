@@ -2744,6 +2744,8 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_dma_kernel(WgradArgs a,
     const float* dy_b = a.dy + (long)b * a.y_sB + (long)t * a.y_sT;
 
     // source row hs of x -> ring slot hs & 3 (rows outside the frame are never staged: their taps are skipped)
+    // (the per-lane source offsets do not depend on the row, but kept in registers across the row loop — 8 values — they spilled
+    //  next to the 168 accumulators: recomputed per row)
     auto dma_x = [&](int hs) __attribute__((always_inline)) {
       if (hs < 0 || hs >= a.H) return;
       const float* src = x_bt + (long)hs * a.x_sH;
@@ -2792,29 +2794,45 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_dma_kernel(WgradArgs a,
       const int yrot = ROTY ? ((kq >> 1) & 1) : 0;
       const int steps = segp >> 2;
       // the operands of K step s + 1 are read from LDS while step s is multiplied (scheduling fences: left alone the compiler
-      // sinks every read to just before its MFMAs); a fragment whose source row lies outside the frame multiplies zeros
-      float afn[FPW], bfn[GB];
+      // sinks every read to just before its MFMAs); a fragment whose source row
+      // lies outside the frame multiplies zeros — only the frame's first and last row have such fragments, and only the waves
+      // whose last fragment id exceeds the fragment count: the masking selects and the bias sums live in wave-uniform branches
       auto rd = [&](int s_, float (&af_)[FPW], float (&bf_)[GB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < FPW; ++f) af_[f] = s_x[base[f] + s_ * 4 * CI];
 #pragma unroll
         for (int n = 0; n < GB; ++n) bf_[n] = yb[s_ * 4 * CO + 16 * (n ^ yrot)];
       };
+      bool all_ok = true;
 #pragma unroll
-      for (int f = 0; f < FPW; ++f) if (!okf[f]) base[f] = base[0];     // (any valid address; its product is masked below)
+      for (int f = 0; f < FPW; ++f) { all_ok = all_ok && okf[f]; if (!okf[f]) base[f] = base[0]; }   // (any valid address; masked below)
+      const bool want_bias = a.dbias && wave == 0 && kt == 0 && xg0 == 0;                              // (scalar)
+      auto mma = [&](float (&af_)[FPW], float (&bf_)[GB]) __attribute__((always_inline)) {
+        if (!all_ok) {
+#pragma unroll
+          for (int f = 0; f < FPW; ++f) af_[f] = okf[f] ? af_[f] : 0.f;
+        }
+        if (want_bias) {
+#pragma unroll
+          for (int n = 0; n < GB; ++n) bsum[n] += bf_[n];
+        }
+#pragma unroll
+        for (int f = 0; f < FPW; ++f)
+#pragma unroll
+          for (int n = 0; n < GB; ++n) acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[f], bf_[n], acc[f][n], 0, 0, 0);
+      };
+      // (two alternating register sets instead of the copy spilled 17 - 19 registers next to the 168 accumulators)
+      float afn[FPW], bfn[GB];
       rd(0, afn, bfn);
       for (int s = 0; s < steps; ++s) {
         float af[FPW], bf[GB];
 #pragma unroll
-        for (int f = 0; f < FPW; ++f) af[f] = okf[f] ? afn[f] : 0.f;
+        for (int f = 0; f < FPW; ++f) af[f] = afn[f];
 #pragma unroll
-        for (int n = 0; n < GB; ++n) { bf[n] = bfn[n]; bsum[n] += bf[n]; }
+        for (int n = 0; n < GB; ++n) bf[n] = bfn[n];
         if (s + 1 < steps) rd(s + 1, afn, bfn);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < FPW; ++f)
-#pragma unroll
-          for (int n = 0; n < GB; ++n) acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], bf[n], acc[f][n], 0, 0, 0);
+        mma(af, bf);
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA blocks of the next row have landed
