@@ -189,7 +189,10 @@ typedef struct {
 } idee_conv_desc;
 
 /* floats in a packed (fragment-ordered) weight buffer / in a packed weight-gradient buffer (the latter holds several partial
- * copies over which the kernels spread their atomic flushes; zero it before idee_conv_wgrad, idee_conv_unpack_wgrad sums them) */
+ * copies over which the kernels spread their atomic flushes; zero it before idee_conv_wgrad, idee_conv_unpack_wgrad sums them).
+ * A packed WEIGHT buffer of a wide zero-padded convolution (e.g. 96 -> 96) carries, behind its f32 fragments, the same weights as
+ * ready f16 piece fragments (hi | lo per K group pair and output block, the LDS image of conv_wide_split_kernel's per-tap slab) and
+ * 64 words with each weight set's largest |w|: idee_conv_pack_weights writes all three, the size below covers them. */
 long idee_conv_packed_floats(const idee_conv_desc* d);
 long idee_conv_wgrad_floats(const idee_conv_desc* d);
 /* w: reference layout (wsets, Cout, Cin, kt, kh, kw) -> fragment order for fwd and/or dgrad */
