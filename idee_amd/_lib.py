@@ -83,6 +83,9 @@ _SIGS = {
     "idee_lfq_workspace_floats": (_L, [_L, _I, _I]),
     "idee_lfq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _F, _I, _P]),
     "idee_lfq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _I, _P]),
+    "idee_lfq_noproj_workspace_floats": (_L, [_L, _I, _I]),
+    "idee_lfq_noproj_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _I, _P]),
+    "idee_lfq_noproj_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _I, _P]),
     "idee_patch_merging_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "idee_patch_merging_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "idee_lfq_sign_field_fwd": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _I, _P]),

@@ -668,6 +668,123 @@ __global__ __launch_bounds__(256) void lfq_bwd_kernel(const AT* __restrict__ z, 
 }
 
 // -------------------------------------------------------------------------------------------
+// LFQ WITHOUT projections (LFQ.py:98-101: dim == num_codebooks * log2(codebook_size) -> project_in / project_out are nn.Identity):
+// the token's E channels ARE its code bits, D consecutive channels per codebook (D = 1, 2 or 4: a codebook lies inside one lane's 4
+// channels), NCB = E / D codebooks.  z_q = sign(z) with the straight-through gradient; entropy / commitment terms as above, per
+// codebook.  Block sums per lane quad q: [0] sum H, [1] sum (z - q)^2, [2 + (q (4 / D) + c) K + k] sum_tokens p.
+// -------------------------------------------------------------------------------------------
+template <int E, int D, typename AT>
+__global__ __launch_bounds__(256) void lfq_np_fwd_kernel(const AT* __restrict__ z, AT* __restrict__ zq, long long* __restrict__ indices,
+                                                         float* __restrict__ partials, long M, int training) {
+  constexpr int K = 1 << D, QE = E / 4, CL = 4 / D, NCB = E / D, R = 2 + NCB * K, RL = 2 + CL * K;
+  __shared__ float smem[4][QE][RL];
+  float acc[RL];
+#pragma unroll
+  for (int r = 0; r < RL; ++r) acc[r] = 0.f;
+  const int q = threadIdx.x % QE;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const f32x4 zi = ldx4<AT>(z + tok * E + 4 * q);
+    f32x4 o;
+    unsigned nib = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = zi[i] > 0.f ? 1.f : -1.f; nib |= (unsigned)(zi[i] > 0.f) << (3 - i); }   // strict > (LFQ.py:222,234)
+    stx4<AT>(zq + tok * E + 4 * q, o);
+    // the token's E bits, channel 0 most significant: every lane contributes its nibble
+    unsigned long long idx = (unsigned long long)nib << (E - 4 - 4 * q);
+#pragma unroll
+    for (int off = 1; off < QE; off <<= 1) idx |= __shfl_xor((unsigned long long)idx, off, 64);
+    if (q == 0) indices[tok] = (long long)idx;
+    if (training) {
+#pragma unroll
+      for (int c = 0; c < CL; ++c) {
+        float sc[D], p[K];
+#pragma unroll
+        for (int i = 0; i < D; ++i) sc[i] = zi[c * D + i];
+        lfq_probs<D>(sc, p);
+#pragma unroll
+        for (int k = 0; k < K; ++k) { acc[0] -= p[k] * __logf(fmaxf(p[k], kLogEps)); acc[2 + c * K + k] += p[k]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float d = zi[i] - o[i]; acc[1] = fmaf(d, d, acc[1]); }
+    }
+  }
+  if (training) {
+    // lanes with equal q hold the same codebooks: reduce over them inside the wave, then over the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < RL; ++r) {
+      float v = acc[r];
+#pragma unroll
+      for (int o = QE; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (lane < QE) smem[wave][q][r] = v;
+    }
+    __syncthreads();
+    float* out = partials + (long)blockIdx.x * R;
+    for (int i = threadIdx.x; i < R; i += 256) {
+      float v = 0.f;
+      if (i < 2) {
+        for (int w = 0; w < 4; ++w) for (int qq = 0; qq < QE; ++qq) v += smem[w][qq][i];
+      } else {
+        const int bin = i - 2, qq = bin / (CL * K), r = 2 + bin % (CL * K);
+        for (int w = 0; w < 4; ++w) v += smem[w][qq][r];
+      }
+      out[i] = v;
+    }
+  }
+}
+
+template <int E, int D, bool HASG, typename AT>
+__global__ __launch_bounds__(256) void lfq_np_bwd_kernel(const AT* __restrict__ z, const AT* __restrict__ dzq, const float* __restrict__ stats,
+                                                         const float* __restrict__ gscal, const float* __restrict__ dqs,
+                                                         AT* __restrict__ dz, long M, float w_ent, float gamma, float w_commit) {
+  constexpr int K = 1 << D, QE = E / 4, CL = 4 / D, NCB = E / D;
+  const float g = gscal[0];
+  const float invM = 1.f / (float)M;
+  const int q = threadIdx.x % QE;
+  float ub[CL][K];
+#pragma unroll
+  for (int c = 0; c < CL; ++c)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float a = stats[4 + (q * CL + c) * K + k];
+      ub[c][k] = -(logf(fmaxf(a, kLogEps)) + (a >= kLogEps ? 1.f : 0.f));
+    }
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < M * QE; u += (long)gridDim.x * 256) {
+    const long tok = u / QE;
+    const f32x4 zi = ldx4<AT>(z + tok * E + 4 * q);
+    f32x4 ds = HASG ? ldx4<AT>(dzq + tok * E + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};      // straight-through: d z_q / d z = 1
+    if (dqs) ds += ld4(dqs + tok * E + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float qv = zi[i] > 0.f ? 1.f : -1.f;
+      ds[i] += g * w_commit * 2.f * (zi[i] - qv) * invM * (1.f / E);
+    }
+#pragma unroll
+    for (int c = 0; c < CL; ++c) {
+      float sc[D], p[K];
+#pragma unroll
+      for (int i = 0; i < D; ++i) sc[i] = zi[c * D + i];
+      lfq_probs<D>(sc, p);
+      float us = 0.f, ubs = 0.f, uu[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        uu[k] = -(__logf(fmaxf(p[k], kLogEps)) + (p[k] >= kLogEps ? 1.f : 0.f));
+        us = fmaf(uu[k], p[k], us);
+        ubs = fmaf(ub[c][k], p[k], ubs);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float dl = p[k] * (w_ent * (uu[k] - us) - gamma * (ub[c][k] - ubs)) * invM * (1.f / NCB) * g * kInvTemp2;
+#pragma unroll
+        for (int i = 0; i < D; ++i) ds[c * D + i] += ((k >> (D - 1 - i)) & 1) ? dl : -dl;
+      }
+    }
+    stx4<AT>(dz + tok * E + 4 * q, ds);
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // class-frequency-weighted BCE with logits (models/losses.py:64-124)
 // -------------------------------------------------------------------------------------------
 // counts[0..1] = torch.histc(target[valid], bins=2) with its data-derived range (min==max -> [min-1,max+1])
@@ -1879,6 +1996,62 @@ extern "C" int idee_lfq_bwd(const void* z, const void* dzq, const float* w_in, c
 #undef CALL
 #undef CALL2
   IDEE_LAUNCH_CHECK("lfq_bwd");
+  return IDEE_OK;
+}
+
+// ---- LFQ without projections ----
+#define LFQNP_DISPATCH(CALL)                                                                           \
+  if (E == 16 && D == 1) { CALL(16, 1); } else if (E == 16 && D == 2) { CALL(16, 2); }                   \
+  else if (E == 16 && D == 4) { CALL(16, 4); } else if (E == 32 && D == 1) { CALL(32, 1); }              \
+  else if (E == 32 && D == 2) { CALL(32, 2); } else if (E == 32 && D == 4) { CALL(32, 4); }              \
+  else return idee::fail(IDEE_ERR_UNSUPPORTED, "lfq (no projections): (dim=%d, codebook_size=%d) not built", E, 1 << D);
+
+extern "C" long idee_lfq_noproj_workspace_floats(long M, int E, int codebook_size) {
+  const int D = log2i(codebook_size);
+  return (long)stream_grid(M * 4) * (2 + (long)(E / (D > 0 ? D : 1)) * codebook_size);
+}
+
+extern "C" int idee_lfq_noproj_fwd(const void* z, void* zq, int64_t* indices, float* stats, float* workspace, long M, int E,
+                                   int codebook_size, int training, float w_entropy, float gamma, float w_commit, int act_dtype,
+                                   idee_stream_t stream) {
+  IDEE_CHECK_ARG(z && zq && indices && M > 0, "lfq_noproj_fwd: bad argument");
+  IDEE_CHECK_ARG(!training || (stats && workspace), "lfq_noproj_fwd: training needs stats and workspace");
+  const int D = log2i(codebook_size);
+  IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
+  const int nb = stream_grid(M * 4);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(E_, D_)                                                                                           \
+  if (act_dtype == IDEE_DTYPE_BF16)                                                                            \
+    hipLaunchKernelGGL((lfq_np_fwd_kernel<E_, D_, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)z, (bf16_t*)zq, \
+                       (long long*)indices, workspace, M, training);                                           \
+  else hipLaunchKernelGGL((lfq_np_fwd_kernel<E_, D_, float>), dim3(nb), dim3(256), 0, st, (const float*)z, (float*)zq, \
+                          (long long*)indices, workspace, M, training);                                        \
+  if (training) hipLaunchKernelGGL((lfq_finalize_kernel<D_, E_ / D_>), dim3(1), dim3(64), 0, st, workspace, nb, stats, M, \
+                                   w_entropy, gamma, w_commit)
+  LFQNP_DISPATCH(CALL)
+#undef CALL
+  IDEE_LAUNCH_CHECK("lfq_noproj_fwd");
+  return IDEE_OK;
+}
+
+extern "C" int idee_lfq_noproj_bwd(const void* z, const void* dzq, const float* stats, const float* gloss, const float* dsigns,
+                                   void* dz, long M, int E, int codebook_size, float w_entropy, float gamma, float w_commit,
+                                   int act_dtype, idee_stream_t stream) {
+  IDEE_CHECK_ARG(z && stats && gloss && dz && M > 0, "lfq_noproj_bwd: bad argument");
+  const int D = log2i(codebook_size);
+  IDEE_CHECK_ARG((1 << D) == codebook_size && D >= 1, "lfq: codebook size %d is not a power of two", codebook_size);
+  const int nb = stream_grid(M * 4);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL2(E_, D_, AT_)                                                                                     \
+  if (dzq) hipLaunchKernelGGL((lfq_np_bwd_kernel<E_, D_, true, AT_>), dim3(nb), dim3(256), 0, st, (const AT_*)z, (const AT_*)dzq, stats, \
+                              gloss, dsigns, (AT_*)dz, M, w_entropy, gamma, w_commit);                         \
+  else hipLaunchKernelGGL((lfq_np_bwd_kernel<E_, D_, false, AT_>), dim3(nb), dim3(256), 0, st, (const AT_*)z, (const AT_*)dzq, stats, \
+                          gloss, dsigns, (AT_*)dz, M, w_entropy, gamma, w_commit)
+#define CALL(E_, D_) if (act_dtype == IDEE_DTYPE_BF16) { CALL2(E_, D_, bf16_t); } else { CALL2(E_, D_, float); }
+  LFQNP_DISPATCH(CALL)
+#undef CALL
+#undef CALL2
+  IDEE_LAUNCH_CHECK("lfq_noproj_bwd");
   return IDEE_OK;
 }
 

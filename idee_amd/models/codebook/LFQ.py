@@ -28,16 +28,19 @@ class LFQ(nn.Module):
                                       "activation other than Identity are not built")
         codebook_dim = int(log2(codebook_size))
         codebook_dims = codebook_dim * num_codebooks               # LFQ.py:95-96
-        if dim == codebook_dims:
-            raise NotImplementedError("idee_amd LFQ: dim == num_codebooks * log2(codebook_size) (no projections) is not built")
-        if codebook_dims > 4:
-            raise NotImplementedError("idee_amd LFQ: more than 4 code bits per token (num_codebooks * log2(codebook_size)) is not built")
+        has_projections = dim != codebook_dims                     # LFQ.py:98
+        if has_projections and codebook_dims > 4:
+            raise NotImplementedError("idee_amd LFQ: more than 4 projected code bits per token (num_codebooks * log2(codebook_size)) "
+                                      "is not built")
+        if not has_projections and (dim not in (16, 32) or codebook_dim not in (1, 2, 4)):
+            raise NotImplementedError("idee_amd LFQ without projections: built for dim 16 / 32 and codebook_size 2 / 4 / 16 "
+                                      f"(got dim {dim}, codebook_size {codebook_size})")
         keep_num_codebooks_dim = (num_codebooks > 1) if keep_num_codebooks_dim is None else keep_num_codebooks_dim      # :108
         assert not (num_codebooks > 1 and not keep_num_codebooks_dim)                                                  # :109
         self.dim, self.dim_out, self.codebook_dim, self.codebook_size = dim, dim_out, codebook_dim, codebook_size
-        self.num_codebooks, self.keep_num_codebooks_dim, self.has_projections = num_codebooks, keep_num_codebooks_dim, True
-        self.project_in = nn.Linear(dim, codebook_dims)
-        self.project_out = nn.Linear(codebook_dims, dim)
+        self.num_codebooks, self.keep_num_codebooks_dim, self.has_projections = num_codebooks, keep_num_codebooks_dim, has_projections
+        self.project_in = nn.Linear(dim, codebook_dims) if has_projections else nn.Identity()      # :99-100
+        self.project_out = nn.Linear(codebook_dims, dim) if has_projections else nn.Identity()
         self.diversity_gamma = diversity_gamma
         self.entropy_loss_weight = entropy_loss_weight
         self.commitment_loss_weight = commitment_loss_weight
@@ -64,7 +67,7 @@ class LFQ(nn.Module):
         codes = self.codebook[indices]                                         # (..., c, d)
         codes = codes.reshape(*codes.shape[:-2], -1)                           # '... c d -> ... (c d)'
         if project_out:
-            codes = codes @ self.project_out.weight.t() + self.project_out.bias
+            codes = self.project_out(codes)
         if is_img_or_video:      # image / video index maps: codes come back channels-first, 'b ... d -> b d ...' (:177-179)
             codes = codes.permute(0, codes.ndim - 1, *range(1, codes.ndim - 1))
         return codes
@@ -77,6 +80,10 @@ class LFQ(nn.Module):
         """-> (z_q, indices, aux loss, signs (..., codebook_dim) | None): `signs` are the +-1 bits before project_out,
         carrying the same straight-through gradient as z_q (for the classifier's rank-d input path)."""
         assert z.shape[-1] == self.dim, f"expected dimension of {self.dim} but received {z.shape[-1]}"
+        if not self.has_projections:     # the tokens are the code bits: z_q = sign(z) is its own sign field
+            zq, idx, aux = ops.LFQQuantizeNoProj.apply(z, self.codebook_size, self.training, float(self.entropy_loss_weight),
+                                                       float(self.diversity_gamma), float(self.commitment_loss_weight))
+            return zq, idx, aux, (zq if want_signs else None)
         return ops.LFQQuantize.apply(z, self.project_in.weight, self.project_in.bias, self.project_out.weight,
                                      self.project_out.bias, self.codebook_size, self.training,
                                      float(self.entropy_loss_weight), float(self.diversity_gamma),

@@ -658,6 +658,42 @@ class LFQQuantize(torch.autograd.Function):
         return dz, dw_in, db_in, dw_out, db_out, None, None, None, None, None, None, None
 
 
+class LFQQuantizeNoProj(torch.autograd.Function):
+    """LFQ without projections (LFQ.py:98-101, dim == num_codebooks * log2 K): z (..., E) -> z_q = sign(z) (..., E) with the
+    straight-through gradient, indices int64 (...) packing the E bits (channel 0 most significant: LFQ.split_indices unpacks the
+    per-codebook indices), aux loss ()."""
+
+    @staticmethod
+    def forward(ctx, z, codebook_size, training, w_entropy, gamma, w_commit):
+        z = _act(z)
+        E = z.shape[-1]
+        M = z.numel() // E
+        dev = z.device
+        zq = torch.empty_like(z)
+        idx = torch.empty(z.shape[:-1], device=dev, dtype=torch.int64)
+        ncb = E // max(1, codebook_size.bit_length() - 1)
+        stats = _zeros(4 + ncb * codebook_size, dev)
+        ws = torch.empty(L.load().idee_lfq_noproj_workspace_floats(M, E, codebook_size), device=dev, dtype=torch.float32)
+        L.call("idee_lfq_noproj_fwd", ptr(z), ptr(zq), ptr(idx), ptr(stats), ptr(ws), M, E, codebook_size, int(training),
+               w_entropy, gamma, w_commit, L.act_dtype(z), L.stream())
+        ctx.save_for_backward(z, stats)
+        ctx.cfg = (M, E, codebook_size, w_entropy, gamma, w_commit)
+        ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
+        return zq, idx, stats[0]
+
+    @staticmethod
+    def backward(ctx, dzq, _didx, dloss):
+        z, stats = ctx.saved_tensors
+        M, E, K, w_entropy, gamma, w_commit = ctx.cfg
+        dzq = _like(dzq, z) if dzq is not None else None
+        gl = _f32c(dloss).reshape(1) if dloss is not None else torch.zeros(1, device=z.device)
+        dz = torch.empty_like(z)
+        L.call("idee_lfq_noproj_bwd", ptr(z), ptr(dzq), ptr(stats), ptr(gl), None, ptr(dz), M, E, K, w_entropy, gamma, w_commit,
+               L.act_dtype(z), L.stream())
+        return dz, None, None, None, None, None
+
+
 # ----------------------------------------------------------------------------------------
 # losses
 # ----------------------------------------------------------------------------------------

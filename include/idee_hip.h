@@ -257,6 +257,16 @@ int idee_lfq_bwd(const void* z, const void* dzq, const float* w_in, const float*
                  float* dw_out, float* db_out, long M, int E, int codebook_size, int num_codebooks, float w_entropy, float gamma,
                  float w_commit, int act_dtype, idee_stream_t stream);
 
+/* LFQ WITHOUT projections (LFQ.py:98-101: dim == num_codebooks * log2(codebook_size), project_in / project_out = nn.Identity):
+ * the token's E channels are its code bits, log2(codebook_size) in {1, 2, 4} consecutive channels per codebook.
+ *   z, zq, dz, dzq, dsigns: (M, E); indices int64 (M): the E bits, channel 0 most significant (per-codebook indices = its bit fields)
+ *   stats (4 + (E / log2 K) * K floats) as idee_lfq_fwd's; workspace idee_lfq_noproj_workspace_floats(M, E, K) floats */
+long idee_lfq_noproj_workspace_floats(long M, int E, int codebook_size);
+int idee_lfq_noproj_fwd(const void* z, void* zq, int64_t* indices, float* stats, float* workspace, long M, int E, int codebook_size,
+                        int training, float w_entropy, float gamma, float w_commit, int act_dtype, idee_stream_t stream);
+int idee_lfq_noproj_bwd(const void* z, const void* dzq, const float* stats, const float* gloss, const float* dsigns, void* dz, long M,
+                        int E, int codebook_size, float w_entropy, float gamma, float w_commit, int act_dtype, idee_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Rank-d classifier input (algebraic refactoring; exact in real arithmetic, disclosed in DESIGN.md):
  * z_q = b_out + sum_i q_i w_out[:, i], so the first (2,3,3)-stride-2 convolutions of the classifier

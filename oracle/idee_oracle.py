@@ -362,7 +362,8 @@ def lfq_multi(z, sd, K, ncb, training, w_entropy, gamma, w_commit, pre=""):
     Returns z_q (b,n,dim), indices int64 (b,n,ncb), aux loss scalar."""
     codebook, bitmask = lfq_codebook(K)
     d = codebook.shape[1]
-    x = F.linear(z.float(), sd[pre + "project_in.weight"], sd[pre + "project_in.bias"])
+    proj = (pre + "project_in.weight") in sd       # dim == ncb * d: project_in / project_out are nn.Identity (:98-101)
+    x = F.linear(z.float(), sd[pre + "project_in.weight"], sd[pre + "project_in.bias"]) if proj else z.float()
     x = x.reshape(*x.shape[:-1], ncb, d)                                                  # :215
     q = torch.where(x > 0, torch.ones_like(x), -torch.ones_like(x))
     xs = x + (q - x).detach() if training else q
@@ -376,7 +377,9 @@ def lfq_multi(z, sd, K, ncb, training, w_entropy, gamma, w_commit, pre=""):
         commit = ((x - q.detach()) ** 2).mean()
     else:
         ent_aux = commit = torch.zeros(())
-    out = F.linear(xs.reshape(*xs.shape[:-2], ncb * d), sd[pre + "project_out.weight"], sd[pre + "project_out.bias"])
+    out = xs.reshape(*xs.shape[:-2], ncb * d)
+    if proj:
+        out = F.linear(out, sd[pre + "project_out.weight"], sd[pre + "project_out.bias"])
     return out, indices, commit * w_commit + ent_aux
 
 
@@ -385,6 +388,8 @@ def lfq_multi_indices_to_codes(indices, sd, K, pre=""):
     codebook, _ = lfq_codebook(K)
     codes = codebook[indices]
     codes = codes.reshape(*codes.shape[:-2], -1)
+    if (pre + "project_out.weight") not in sd:
+        return codes
     return F.linear(codes, sd[pre + "project_out.weight"], sd[pre + "project_out.bias"])
 
 

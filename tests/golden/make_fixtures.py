@@ -326,6 +326,38 @@ if __name__ == "__main__" and "--lfqmulti-only" in sys.argv:
     fx_lfq_multi("k2_c4_eval", 2, 4, False, 250)
 
 
+def fx_lfq_noproj(tag, dim, K, training, seed):
+    """LFQ WITHOUT projections (dim == num_codebooks * log2 K, LFQ.py:98-101: project_in / project_out are nn.Identity): the
+    token's channels are the code bits.  Half the tokens are small (|200 z| ~ 1: soft probabilities, live entropy gradients)."""
+    d = int(np.log2(K))
+    q = RefLFQ(dim=dim, codebook_size=K, num_codebooks=dim // d, entropy_loss_weight=0.1, diversity_gamma=0.1,
+               commitment_loss_weight=3.0)
+    assert not q.has_projections
+    q.train(training)
+    x = rand((2, 300, dim), seed + 1)
+    x[:, ::2] *= 0.01
+    x[0, :7] = 0.0
+    x.requires_grad_()
+    zq, idx, aux = q(x)
+    r = rand(zq.shape, seed + 2)
+    ncb = dim // d
+    code_idx = torch.tensor([[0] * ncb, [K - 1] * ncb, list(range(ncb))]) % K
+    out = dict(x=x.detach(), z_q=zq.detach(), indices=idx, aux=aux.detach(), r=r, K=np.array(K), dim=np.array(dim),
+               training=np.array(int(training)), code_idx=code_idx, codes=q.indices_to_codes(code_idx).detach())
+    if training:
+        ((zq * r).sum() + 2.5 * aux).backward()
+        out["dx"] = x.grad
+    out.update(sd_arrays(q))
+    save("lfq_noproj_" + tag, **out)
+
+
+if __name__ == "__main__" and "--lfqnoproj-only" in sys.argv:
+    fx_lfq_noproj("e16_k2_train", 16, 2, True, 260)
+    fx_lfq_noproj("e16_k4_train", 16, 4, True, 270)
+    fx_lfq_noproj("e32_k16_train", 32, 16, True, 280)
+    fx_lfq_noproj("e16_k16_eval", 16, 16, False, 290)
+
+
 def fx_classifier(seed, V=2, n_classes=1):
     c = RefCls(in_var=V, embed_dim=16, dim=16, n_classes=n_classes, drop_rate=0.0)
     rerandomise(c, seed)
@@ -825,7 +857,7 @@ if __name__ == "__main__" and "--data-only" in sys.argv:
 
 if __name__ == "__main__" and not any(a in sys.argv for a in ("--config-only", "--vq-only", "--eval-only", "--pm-only", "--data-only",
                                                                 "--era5-only", "--hier-only", "--vqema-only", "--misc-only", "--era5items-only",
-                                                                "--cnnhier-only", "--patch-only", "--clsk-only", "--nopatch-only", "--lfqmulti-only")):
+                                                                "--cnnhier-only", "--patch-only", "--clsk-only", "--nopatch-only", "--lfqmulti-only", "--lfqnoproj-only")):
     main()
     fx_classifier(1700, V=2, n_classes=3)
     fx_swin_hier("16_32", (16, 32), 1200)

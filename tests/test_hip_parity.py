@@ -578,6 +578,50 @@ def test_lfq_several_codebooks_golden(tag):
             gclose("d" + n, p.grad, grads[n])
 
 
+@pytest.mark.parametrize("tag", ["e16_k2_train", "e16_k4_train", "e32_k16_train", "e16_k16_eval"])
+def test_lfq_without_projections_golden(tag):
+    """LFQ with dim == num_codebooks * log2 K (LFQ.py:98-101: project_in / project_out = nn.Identity; the token's channels are
+    the code bits) against the reference's own outputs and gradient; the state dict holds only `mask`, as the reference's."""
+    from idee_amd.models.codebook.LFQ import LFQ
+    a, sd, _ = load_golden("lfq_noproj_" + tag)
+    K, dim, training = int(a["K"]), int(a["dim"]), bool(int(a["training"]))
+    d = K.bit_length() - 1
+    q = LFQ(dim=dim, codebook_size=K, num_codebooks=dim // d, entropy_loss_weight=0.1, diversity_gamma=0.1, commitment_loss_weight=3.0)
+    assert not q.has_projections and list(q.state_dict()) == list(sd) == ["mask"]
+    q.load_state_dict(sd, strict=True)
+    q = q.to(DEV)
+    q.train(training)
+    x = dev(a["x"]).requires_grad_()
+    zq, idx, aux = q(x)
+    assert tuple(idx.shape) == tuple(a["indices"].shape) and idx.dtype == torch.int64
+    assert torch.equal(idx.cpu(), a["indices"].long())          # no projection arithmetic: the bits are exact
+    assert torch.equal(zq.cpu(), a["z_q"])
+    close("aux", aux, a["aux"], atol=1e-5, rtol=5e-4)
+    close("codes", q.indices_to_codes(a["code_idx"].long().to(DEV)), a["codes"])
+    if training:
+        ((zq * dev(a["r"])).sum() + 2.5 * aux).backward()
+        gclose("dx", x.grad, a["dx"])
+
+
+def test_lfq_without_projections_bf16_and_no_dense_consumer():
+    """bf16 tokens (z_q and dz stay bf16; statistics f32 from the bf16-rounded values) and a backward with only the aux loss
+    (no d z_q stream) against the f32 path on the same rounded tokens."""
+    from idee_amd.models.codebook.LFQ import LFQ
+    q = LFQ(dim=16, codebook_size=4, num_codebooks=8).to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, 257, 16, generator=g) * 0.01).bfloat16()
+    xf = dev(x.float()).requires_grad_()
+    xb = dev(x).requires_grad_()
+    zf, i_f, af = q(xf)
+    zb, i_b, ab = q(xb)
+    assert zb.dtype == torch.bfloat16 and torch.equal(i_f, i_b) and torch.equal(zf, zb.float())
+    close("aux", ab, af, atol=1e-6, rtol=1e-5)
+    af.backward()
+    ab.backward()
+    assert xb.grad.dtype == torch.bfloat16
+    close("dx", xb.grad.float(), xf.grad, atol=1e-6, rtol=1e-2)
+
+
 def _classifier(sd, V):
     from idee_amd.models.classifier.CNN_3D import CNN_3D
     c = CNN_3D(in_var=V, embed_dim=16, dim=16, n_classes=sd["conv3.weight"].shape[0], drop_rate=0.0)

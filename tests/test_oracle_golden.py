@@ -127,6 +127,24 @@ def test_lfq_several_codebooks(tag):
         check_grads(sd, grads)
 
 
+@pytest.mark.parametrize("tag", ["e16_k2_train", "e16_k4_train", "e32_k16_train", "e16_k16_eval"])
+def test_lfq_without_projections(tag):
+    """LFQ with dim == num_codebooks * log2 K (LFQ.py:98-101: Identity projections) in the oracle against the reference."""
+    a, sd, _ = load_golden("lfq_noproj_" + tag)
+    assert list(sd) == ["mask"]
+    K, dim, training = int(a["K"]), int(a["dim"]), bool(int(a["training"]))
+    ncb = dim // (K.bit_length() - 1)
+    x = a["x"].clone().requires_grad_()
+    zq, idx, aux = O.lfq_multi(x, sd, K, ncb, training, 0.1, 0.1, 3.0)
+    close(zq, a["z_q"])
+    assert torch.equal(idx, a["indices"].long())
+    close(aux, a["aux"])
+    close(O.lfq_multi_indices_to_codes(a["code_idx"].long(), sd, K), a["codes"])
+    if training:
+        ((zq * a["r"]).sum() + 2.5 * aux).backward()
+        close(x.grad, a["dx"], 1e-5, 1e-3)
+
+
 @pytest.mark.parametrize("tag", ["classifier_v2", "classifier_v2_k3"])       # _k3: n_classes = 3
 def test_classifier(tag):
     a, sd, grads = load_golden(tag)
