@@ -16,6 +16,8 @@
 // gradient uses the exact (q, tap) pair lists in T and H (tile-uniform) and a padded frame with
 // float atomics on the two edge columns in W.
 #include "common.h"
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace {
@@ -270,10 +272,13 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
   for (int wgp = blockIdx.x; wgp < a.To * a.hgroups; wgp += gridDim.x) {
    const int t = wgp / a.hgroups, rg = wgp - t * a.hgroups;
    const int r_lo = (int)((long)rg * nblk / a.hgroups), r_hi = (int)((long)(rg + 1) * nblk / a.hgroups);
-   for (int c0 = r_lo; c0 < r_hi; c0 += WAVES * MT) {
-    const int blk0 = c0 + wave * MT;
-    const int nm = __builtin_amdgcn_readfirstlane(min(max(r_hi - blk0, 0), MT));
-    const bool row_ok = nm > 0;
+   // A chunk's blocks are dealt EVENLY to the 8 waves (waves w < cextra take one more: one per SIMD first), so the ragged last chunk
+   // of a range costs the most any SIMD holds of it, not a full chunk (2.54 chunks per workgroup at the headline shape ran as 3; the
+   // data gradient's 5.08 as 6).  The chunk body is compiled once per block count of a wave (MT = 1..4: arrays, loads and MFMA
+   // blocks sized to it; the waves of a chunk may run different copies — every copy passes the same barriers).
+   auto chunk = [&](auto mtc, const int blk0, const bool row_ok) __attribute__((always_inline)) {
+    constexpr int MT = decltype(mtc)::value;
+    const int nm = row_ok ? MT : 0;
     int hm[MT], wm[MT];
     bool vm[MT];
 #pragma unroll
@@ -311,9 +316,10 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 
     // activations are prefetched one (tap, channel-block) step ahead, ACROSS tap boundaries: a source pixel outside
     // the frame loads nothing and multiplies zeros
-    struct TapSrc { long off[MT]; bool okm[MT]; };
+    struct TapSrc { long off[MT]; unsigned ok; __device__ bool okm(int m) const { return (ok >> m) & 1u; } };     // (a bool array here is copied through scratch)
     auto tap_src = [&](int it) {
       TapSrc s;
+      s.ok = 0;
       const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
       const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
 #pragma unroll
@@ -321,8 +327,9 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
         const Slot sh = slot_h<MODE>(oh, hm[m], a.Hi);
         bool ok;
         const int q = src_w<MODE>(ow, wm[m], a.Wi, ok);
-        s.okm[m] = vm[m] && st.ok && sh.ok && ok;
-        s.off[m] = s.okm[m] ? (long)st.src * a.i_sT + (long)sh.src * a.i_sH + (long)q * a.i_sW : 0;
+        const bool okm = vm[m] && st.ok && sh.ok && ok;
+        s.ok |= okm ? 1u << m : 0u;
+        s.off[m] = okm ? (long)st.src * a.i_sT + (long)sh.src * a.i_sH + (long)q * a.i_sW : 0;
       }
       return s;
     };
@@ -379,10 +386,15 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
         }
       }
     } else {
+      // Activation loads are UNCONDITIONAL (an absent pixel's offset is 0: a valid address) and masked when they become the current
+      // operand: a load inside a branch leaves the count of outstanding loads unknown, and every wait on the previous step's
+      // operands became vmcnt(0) — a wait for the loads of the NEXT step just issued (WAIT_ANY was 30 % of this kernel's wave cycles)
       TapSrc cur = tap_src(0);
       f32x4 xc[MT], xn[MT];
+      unsigned okn = 0;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   #pragma unroll
-      for (int m = 0; m < MT; ++m) xc[m] = cur.okm[m] ? ld4(in_b + cur.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MT; ++m) { xc[m] = ld4(in_b + cur.off[m]); xc[m] = cur.okm(m) ? xc[m] : zero4; }
 
       for (int it = 0; it < ntap_it; ++it) {
         const float* wcur = RES ? s_wd + tap_of(it) * slab : s_wd + (it & 1) * slab;
@@ -393,30 +405,39 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
         if (more && !RES) {
           const float* src = wp + (long)tap_of(it + 1) * slab;
   #pragma unroll
-          for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (u < slab4) pre[q] = ld4(src + 4 * u); }
+          for (int q = 0; q < 5; ++q) { const int u = tid + q * 512; if (q * 512 < slab4) pre[q] = ld4(src + 4 * min(u, slab4 - 1)); }
         }
         TapSrc nxt = cur;
         if (more) nxt = tap_src(it + 1);
+        f32x4 wfb[2];
         for (int g = 0; g < a.Gk; ++g) {
-          if (g + 1 < a.Gk) {
+          {   // the next step's operands: this tap's next channel block, else the next tap's first (the very last step re-reads)
+            const bool same = g + 1 < a.Gk;
+            const long go = same ? goff(g + 1, a.i_gpu, a.i_sU, a.i_sG) : 0;
   #pragma unroll
-            for (int m = 0; m < MT; ++m) xn[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(g + 1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
-          } else if (more) {
-  #pragma unroll
-            for (int m = 0; m < MT; ++m) xn[m] = nxt.okm[m] ? ld4(in_b + nxt.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MT; ++m) xn[m] = ld4(in_b + (same ? cur.off[m] : nxt.off[m]) + go);
+            okn = same ? cur.ok : more ? nxt.ok : 0u;
           }
           if (row_ok) {
+            // weight fragments one output block ahead (the read for block n + 1 — or block 0 of the next channel block — goes out
+            // before block n's MFMAs: left to the compiler it sat right in front of its first use, 6 exposed LDS round trips per step)
+            if (g == 0) wfb[0] = ld4(wcur + lane * 4);
   #pragma unroll
             for (int n = 0; n < NT; ++n) {
-              const f32x4 wf = ld4(wcur + (g * NT + n) * 256 + lane * 4);
+              if (n + 1 < NT) wfb[(n + 1) & 1] = ld4(wcur + (g * NT + n + 1) * 256 + lane * 4);
+              else if (g + 1 < a.Gk) wfb[(n + 1) & 1] = ld4(wcur + (g + 1) * NT * 256 + lane * 4);
+              __builtin_amdgcn_sched_barrier(0);
+              const f32x4 wf = wfb[n & 1];
   #pragma unroll
-              for (int m = 0; m < MT; ++m)      // (no guard m < nm: see conv_wide_split_kernel)
+              for (int m = 0; m < MT; ++m)
   #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xc[m][s], acc[m][n], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
             }
+            if (NT & 1) wfb[0] = wfb[1];
           }
   #pragma unroll
-          for (int m = 0; m < MT; ++m) xc[m] = xn[m];
+          for (int m = 0; m < MT; ++m) xc[m] = ((okn >> m) & 1u) ? xn[m] : zero4;
         }
         cur = nxt;
         if constexpr (!RES) {
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
 
     }
 
-    if (!row_ok) continue;
+    if (!row_ok) return;
     // the NT bias vectors in one batch ahead of the stores (a load between stores waits, through vmcnt(0), for every store
     // before it: 24 serialized memory round trips per chunk)
     f32x4 biasv[NT];
@@ -465,6 +486,15 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvArgs a) {
         st4(out_r + o, v);
       }
     }
+   };
+   for (int c0 = r_lo; c0 < r_hi; c0 += WAVES * MT) {
+    const int csize = min(r_hi - c0, WAVES * MT), cbase = csize / WAVES, cextra = csize - cbase * WAVES;
+    const int blk0 = c0 + wave * cbase + min(wave, cextra);
+    const int nm = __builtin_amdgcn_readfirstlane(cbase + (wave < cextra ? 1 : 0));
+    if (nm == 4) chunk(std::integral_constant<int, 4>{}, blk0, true);
+    else if (nm == 3) chunk(std::integral_constant<int, 3>{}, blk0, true);
+    else if (nm == 2) chunk(std::integral_constant<int, 2>{}, blk0, true);
+    else chunk(std::integral_constant<int, 1>{}, blk0, nm == 1);      // (nm == 0: staging and barriers only)
    }
   }
 }
@@ -569,10 +599,13 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
   for (int wgp = blockIdx.x; wgp < a.To * a.hgroups; wgp += gridDim.x) {     // ranges and chunks: see conv_wide_kernel
    const int t = wgp / a.hgroups, rg = wgp - t * a.hgroups;
    const int r_lo = (int)((long)rg * nblk / a.hgroups), r_hi = (int)((long)(rg + 1) * nblk / a.hgroups);
-   for (int c0 = r_lo; c0 < r_hi; c0 += WAVES * MT) {
-    const int blk0 = c0 + wave * MT;
-    const int nm = __builtin_amdgcn_readfirstlane(min(max(r_hi - blk0, 0), MT));
-    const bool row_ok = nm > 0;
+   // A chunk's blocks are dealt EVENLY to the 8 waves (waves w < cextra take one more: one per SIMD first), so the ragged last chunk
+   // of a range costs the most any SIMD holds of it, not a full chunk (2.54 chunks per workgroup at the headline shape ran as 3; the
+   // data gradient's 5.08 as 6).  The chunk body is compiled once per block count of a wave (MT = 1..4: arrays, loads and MFMA
+   // blocks sized to it; the waves of a chunk may run different copies — every copy passes the same barriers).
+   auto chunk = [&](auto mtc, const int blk0, const bool row_ok) __attribute__((always_inline)) {
+    constexpr int MT = decltype(mtc)::value;
+    const int nm = row_ok ? MT : 0;
     int hm[MT], wm[MT];
     bool vm[MT];
 #pragma unroll
@@ -613,9 +646,10 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
     }
     __syncthreads();
 
-    struct TapSrc { int off[MT]; bool okm[MT]; };     // (element offsets inside one batch item: 32 bits, checked by the host)
+    struct TapSrc { int off[MT]; unsigned ok; __device__ bool okm(int m) const { return (ok >> m) & 1u; } };     // (element offsets inside one batch item: 32 bits, checked by the host)
     auto tap_src = [&](int it) {
       TapSrc sx;
+      sx.ok = 0;
       const int ot = it / 9, oh = (it / 3) % 3, ow = it % 3;
       const Slot st = slot_t<MODE>(ot, t, a.Ti, a.kt);
 #pragma unroll
@@ -623,17 +657,23 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
         const Slot sh = slot_h<MODE>(oh, hm[m], a.Hi);
         bool ok;
         const int q = src_w<MODE>(ow, wm[m], a.Wi, ok);
-        sx.okm[m] = vm[m] && st.ok && sh.ok && ok;
-        sx.off[m] = sx.okm[m] ? (int)((long)st.src * a.i_sT + (long)sh.src * a.i_sH + (long)q * a.i_sW) : 0;
+        const bool okm = vm[m] && st.ok && sh.ok && ok;
+        sx.ok |= okm ? 1u << m : 0u;
+        sx.off[m] = okm ? (int)((long)st.src * a.i_sT + (long)sh.src * a.i_sH + (long)q * a.i_sW) : 0;
       }
       return sx;
     };
     TapSrc cur = tap_src(0);
     f32x4 xa[MT], xb[MT], na[MT], nb_[MT];
+    // (activation loads unconditional, masked when they become the current operand: see conv_wide_kernel)
+    unsigned okn = 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      xa[m] = cur.okm[m] ? ld4(in_b + cur.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
-      xb[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xa[m] = ld4(in_b + cur.off[m]);
+      xb[m] = ld4(in_b + cur.off[m] + goff(1, a.i_gpu, a.i_sU, a.i_sG));
+      xa[m] = cur.okm(m) ? xa[m] : zero4;
+      xb[m] = cur.okm(m) ? xb[m] : zero4;
     }
     for (int it = 0; it < ntap_it; ++it) {
       const unsigned* wcur = s_ws + (it & 1) * slab;
@@ -652,19 +692,19 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       }
       TapSrc nxt = cur;
       if (more) nxt = tap_src(it + 1);
+      u32x4 ahb[2], alb[2];
       for (int gp = 0; gp < GP; ++gp) {
-        if (gp + 1 < GP) {
+        {   // the next step's operands: this tap's next group pair, else the next tap's first (the very last step re-reads)
+          const bool same = gp + 1 < GP;
+          const long g0 = same ? goff(2 * gp + 2, a.i_gpu, a.i_sU, a.i_sG) : 0;
+          const long g1 = same ? goff(2 * gp + 3, a.i_gpu, a.i_sU, a.i_sG) : goff(1, a.i_gpu, a.i_sU, a.i_sG);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            na[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(2 * gp + 2, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            nb_[m] = cur.okm[m] ? ld4(in_b + cur.off[m] + goff(2 * gp + 3, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int o = same ? cur.off[m] : nxt.off[m];
+            na[m] = ld4(in_b + o + g0);
+            nb_[m] = ld4(in_b + o + g1);
           }
-        } else if (more) {
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            na[m] = nxt.okm[m] ? ld4(in_b + nxt.off[m]) : f32x4{0.f, 0.f, 0.f, 0.f};
-            nb_[m] = nxt.okm[m] ? ld4(in_b + nxt.off[m] + goff(1, a.i_gpu, a.i_sU, a.i_sG)) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+          okn = same ? cur.ok : more ? nxt.ok : 0u;
         }
         if (row_ok) {
           u32x4 bh[MT], bl[MT];
@@ -711,23 +751,29 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
             bh[m] = u32x4{sa.h01, sa.h23, sb.h01, sb.h23};
             bl[m] = u32x4{sa.l01, sa.l23, sb.l01, sb.l23};
           }
-          // (no per-column guard `m < nm`: it compiled to a scalar branch around every group of three MFMAs; only the one wave
-          //  that holds the ragged end of a workgroup's range has 0 < nm < MT, and its absent columns multiply zeros that are
-          //  never stored)
+          // weight piece fragments one output block ahead (see conv_wide_kernel)
+          auto wfrag = [&](int idx, int part) __attribute__((always_inline)) {
+            return *reinterpret_cast<const u32x4*>(wcur + ((idx * 2 + part) * 64 + lane) * 4);
+          };
+          if (gp == 0) { ahb[0] = wfrag(0, 0); alb[0] = wfrag(0, 1); }
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            const u32x4 ah = *reinterpret_cast<const u32x4*>(wcur + (((gp * NT + n) * 2 + 0) * 64 + lane) * 4);
-            const u32x4 al = *reinterpret_cast<const u32x4*>(wcur + (((gp * NT + n) * 2 + 1) * 64 + lane) * 4);
+            if (n + 1 < NT) { ahb[(n + 1) & 1] = wfrag(gp * NT + n + 1, 0); alb[(n + 1) & 1] = wfrag(gp * NT + n + 1, 1); }
+            else if (gp + 1 < GP) { ahb[(n + 1) & 1] = wfrag((gp + 1) * NT, 0); alb[(n + 1) & 1] = wfrag((gp + 1) * NT, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 ah = ahb[n & 1], al = alb[n & 1];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(ah, bh[m], acc[m][n]);
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(ah, bl[m], acc[m][n]);
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][n] = mfma_s<F16>(al, bh[m], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
           }
+          if (NT & 1) { ahb[0] = ahb[1]; alb[0] = alb[1]; }
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { xa[m] = na[m]; xb[m] = nb_[m]; }
+        for (int m = 0; m < MT; ++m) { const bool ok_ = (okn >> m) & 1u; xa[m] = ok_ ? na[m] : zero4; xb[m] = ok_ ? nb_[m] : zero4; }
       }
       cur = nxt;
       if (PRE && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA blocks have landed (the barrier below: all)
@@ -747,7 +793,7 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
       }
       __syncthreads();
     }
-    if (!row_ok) continue;
+    if (!row_ok) return;
     // the NT bias vectors in one batch ahead of the stores (a load between stores waits, through vmcnt(0), for every store
     // before it: 24 serialized memory round trips per chunk)
     f32x4 biasv[NT];
@@ -782,6 +828,15 @@ __global__ __launch_bounds__(512) void conv_wide_split_kernel(ConvArgs a) {
         st4(out_r + o, v);
       }
     }
+   };
+   for (int c0 = r_lo; c0 < r_hi; c0 += WAVES * MT) {
+    const int csize = min(r_hi - c0, WAVES * MT), cbase = csize / WAVES, cextra = csize - cbase * WAVES;
+    const int blk0 = c0 + wave * cbase + min(wave, cextra);
+    const int nm = __builtin_amdgcn_readfirstlane(cbase + (wave < cextra ? 1 : 0));
+    if (nm == 4) chunk(std::integral_constant<int, 4>{}, blk0, true);
+    else if (nm == 3) chunk(std::integral_constant<int, 3>{}, blk0, true);
+    else if (nm == 2) chunk(std::integral_constant<int, 2>{}, blk0, true);
+    else chunk(std::integral_constant<int, 1>{}, blk0, nm == 1);      // (nm == 0: staging and barriers only)
    }
   }
 }
