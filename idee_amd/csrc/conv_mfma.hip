@@ -2173,7 +2173,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
   f32x4 acc[NTAPS][NB];
   float bsum[NB];
   GradScale gs;
-  ActGuard ag;                                     // (F16) range guard of the x rows, per work unit
+  ActGuard ag;                                     // (F16) range guard of the x rows, moving down only over the wave's whole share
   auto scale_acc = [&](float f) __attribute__((always_inline)) {
 #pragma unroll
     for (int tp = 0; tp < NTAPS; ++tp)
@@ -2214,10 +2214,10 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split_kernel(WgradArgs a, int 
     int tsrc[TSL];
 #pragma unroll
     for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : a.kt * t + ot;
-    if (F16 && ag.k != 0) {          // a new unit starts unguarded again (wave-uniform; rare)
-      scale_acc(pow2i(-ag.k < 126 ? -ag.k : 126));
-      ag = ActGuard();
-    }
+    // (the activation guard is NOT reset between the units of a wave: its scale only moves down over the wave's whole share and
+    //  is taken out once, at the flush, separately from the gradient scale.  Multiplying the persistent accumulators back up at a
+    //  unit boundary — by up to 2^116 while they still carry the gradient scale — overflowed for large finite activations whose true
+    //  dW is finite; a quiet unit behind a loud one adds its terms at the loud unit's scale, i.e. rounded relative to the total.)
 
     for (int h = h0; h < h1;) {
       wave_fence();
@@ -2430,10 +2430,10 @@ __global__ __launch_bounds__(256, 2) void wgrad16_shift_kernel(WgradArgs a, int 
     int tsrc[TSL];
 #pragma unroll
     for (int ot = 0; ot < TSL; ++ot) tsrc[ot] = MODE == FWD_REP ? min(max(t + ot - 1, 0), a.T - 1) : a.kt * t + ot;
-    if (F16 && ag.k != 0) {          // a new unit starts unguarded again (wave-uniform; rare)
-      scale_acc(pow2i(-ag.k < 126 ? -ag.k : 126));
-      ag = ActGuard();
-    }
+    // (the activation guard is NOT reset between the units of a wave: its scale only moves down over the wave's whole share and
+    //  is taken out once, at the flush, separately from the gradient scale.  Multiplying the persistent accumulators back up at a
+    //  unit boundary — by up to 2^116 while they still carry the gradient scale — overflowed for large finite activations whose true
+    //  dW is finite; a quiet unit behind a loud one adds its terms at the loud unit's scale, i.e. rounded relative to the total.)
 
     // dy of a row: e[i] = dy[q0 + 8 kq - 2 + i] of output channel r16; ten loads from clamped addresses, masked at their use
     auto load_dy = [&](int hh, float (&ee)[10]) __attribute__((always_inline)) {
@@ -2965,7 +2965,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
 
   f32x4 acc[FPW][GB];
   GradScale gs;
-  ActGuard ag;                                       // range guard of the x rows (workgroup-uniform), per work unit
+  ActGuard ag;                                       // range guard of the x rows (workgroup-uniform), moving down only over the workgroup's whole share
   auto scale_acc = [&](float f) __attribute__((always_inline)) {
 #pragma unroll
     for (int ff = 0; ff < FPW; ++ff)
@@ -3066,10 +3066,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_wide_split_kernel(WgradArgs 
       for (int w = 0; w < WAVES; ++w) m = m > red[w] ? m : red[w];
       return m;
     };
-    if (ag.k != 0) {                                 // (workgroup-uniform) a new unit starts unguarded again
-      scale_acc(pow2i(-ag.k < 126 ? -ag.k : 126));
-      ag = ActGuard();
-    }
+    // (the activation guard is not reset between the units of a workgroup: see wgrad16_split_kernel)
     // A unit is walked in one segment — or, when the guard fires for a row (workgroup-uniform, rare), begun again from that row
     // at the lower scale through the same segment-start code.
     int pend_dk = 0;

@@ -407,6 +407,60 @@ def test_conv_f22_error_against_float64(profile, set_opt):
         assert q["f22"] <= 4.0 * q["f32"] + 2e-7 and qd["f22"] <= 4.0 * qd["f32"] + 2e-7, (q, qd)
 
 
+@pytest.mark.parametrize("shape", ["k333_16", "k233_96"])
+def test_wgrad_f22_activation_guard_keeps_finite_dw(shape, set_opt):
+    """IDEE_CONV_MATH=f22 weight gradients (wgrad16_shift_kernel, wgrad_wide_split_kernel) at the far end of the range: activations
+    of magnitude 3e36 in ONE batch item (the activation guard of the waves that meet it drops to k ~ -110; the other item is O(1))
+    under gradients of magnitude 1e-18 (gradient scale at its cap 2^63): dW ~ 1e20 is finite and must come out finite and within 4x
+    the exact kernels' error (+ 2e-7) of a float64 reference.  A guard that is reset at unit boundaries multiplies the persistent
+    accumulators by 2^110 while they still carry the gradient scale 2^63: inf."""
+    from idee_amd import _lib as L
+    ops = _ops()
+    if shape == "k333_16":
+        # 2 rows per work unit: ~4,600 units per weight set, several per wave, in batch-item-major order — the waves that meet the
+        # loud item 0 go on to quiet items with their accumulators still in registers
+        set_opt("IDEE_CONV_HRUN", "2")
+        mode, B, wsets, T, H, W, Cin, Cout, kt, pad = L.CONV_K333_REPLICATE, 12, 2, 8, 64, 72, 16, 16, 3, "replicate"
+    else:
+        mode, B, wsets, T, H, W, Cin, Cout, kt, pad = L.CONV_K233_S2_ZERO, 2, 1, 4, 12, 72, 96, 96, 2, "zeros"
+    To = (T - 2) // 2 + 1 if kt == 2 else T
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((B, T, H, W, Cin), generator=g)
+    x[0] *= 3e36
+    dy = torch.randn((B, To, H, W, Cout), generator=g) * 1e-18
+    w = torch.zeros((wsets, Cout, Cin, kt, 3, 3))
+    # float64 reference: dW[s] = sum over the items of set s of the correlation of the padded input with dy
+    import torch.nn.functional as F
+    ref = torch.zeros_like(w, dtype=torch.float64)
+    for b in range(B):
+        xb = x[b].double().permute(3, 0, 1, 2)[None]                      # (1, Cin, T, H, W)
+        if pad == "replicate":
+            xb = F.pad(xb, (1, 1, 1, 1, 1, 1), mode="replicate")
+            stride = (1, 1, 1)
+        else:
+            xb = F.pad(xb, (1, 1, 1, 1, 0, 0))
+            stride = (2, 1, 1)
+        wz = torch.zeros((Cout, Cin, kt, 3, 3), dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xb, wz, stride=stride)
+        y.backward(dy[b].double().permute(3, 0, 1, 2)[None])
+        ref[b % wsets] += wz.grad
+    assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 1e-6
+
+    def run(math):
+        set_opt("IDEE_CONV_MATH", math)
+        conv = ops.ConvLayer(mode, B, wsets, T, H, W, Cin, Cout, ops._cl_strides(T, H, W, Cin), ops._cl_strides(To, H, W, Cout), True)
+        dw, _ = conv.wgrad(dev(x), dev(dy), dev(w))
+        return dw.cpu().double()
+
+    err = {}
+    for math in ("f32", "f22"):
+        dw = run(math)
+        assert bool(torch.isfinite(dw).all()), math
+        err[math] = float((dw - ref).norm() / ref.norm())
+    print(f"\n[wgrad {shape}, |x| 3e36 in one item, |dy| 1e-18] relative L2 error of dW: exact {err['f32']:.2e}  f22 {err['f22']:.2e}")
+    assert err["f22"] <= 4.0 * err["f32"] + 2e-7, err
+
+
 @pytest.mark.parametrize("profile", ["loss_scale", "ragged_rows", "huge_x", "ragged_x"])
 def test_classifier_f22_error_against_float64(profile, set_opt):
     """The classifier on z_q (plain path) at V = 6: the 96 -> 96 joint head — conv_wide_split_kernel forward / data gradient and
