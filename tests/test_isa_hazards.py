@@ -66,3 +66,24 @@ def test_probe_table_matches_committed_measurement():
     assert H.HW["valu_to_mfma"] == {("v", "xdl"): max(x["valu_to_ab"], x["valu_to_c"]), ("v", "smfma"): max(s_["valu_to_ab"], s_["valu_to_c"])}
     assert x["d_on_a"] == x["d_on_b"] == s_["d_on_a"] == s_["d_on_b"] == 0 and H.SAME_MFMA_DST_ON_SRCAB_OK
     assert got["x"]["pv_chain"] == 0
+
+
+def test_isa_sched_summary_tokens():
+    """tools/isa_sched.py: the token summary of an instruction stream (the scan DESIGN.md section 6 describes)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import isa_sched
+    body = """
+	global_load_dwordx4 v[0:3], v[8:9], off                    // 0000
+	s_waitcnt vmcnt(0)                                         // 0004
+	ds_read_b128 v[4:7], v10                                   // 0008
+	s_waitcnt lgkmcnt(0)                                       // 000C
+	v_mfma_f32_16x16x4_f32 v[12:15], v4, v0, v[12:15]          // 0010
+	v_mfma_f32_16x16x4_f32 v[12:15], v5, v1, v[12:15]          // 0018
+	v_add_u32_e32 v8, 4, v8                                    // 0020
+	v_add_u32_e32 v9, 4, v9                                    // 0024
+	scratch_load_dword v20, off, off                           // 0028
+	s_cbranch_scc1 65530                                       // 002C
+	global_load_lds_dwordx4 v[8:9], off                        // 0030
+	s_barrier                                                  // 0034
+""".split("\n")
+    assert isa_sched.summarize(body) == ["GL", "W[vm(0)]", "DSR", "W[lg(0)]", "M2", "v2", "SCR", "BR", "DMA", "BAR"]
